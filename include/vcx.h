@@ -1,0 +1,195 @@
+/*
+ * vcx.h — C ABI of libvcx.so, the MI355X (gfx950) kernel library behind the
+ * ViewCrafter DDIM denoising hot path.
+ *
+ * The reference (Drexubery/ViewCrafter) is pure PyTorch on this path; it has no FFI of
+ * its own.  Each entry point below names the reference call site(s) (file:line under the
+ * reference tree) whose arithmetic it replaces.  A maintainer binds these with ctypes
+ * (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - activations are fp16, channels-last: [B, T, H, W, C] (C contiguous). Spatial ops see
+ *     it as [(B T), H, W, C], token ops as [(B T H W), C];
+ *   - weights are fp16 [N_out][K] row-major with K ordered (ky, kx, cin) for convolutions;
+ *   - bias / per-image add vectors / norm affine parameters / statistics are fp32;
+ *   - all functions are stream-ordered on `stream` (a hipStream_t passed as void*), never
+ *     synchronise, never allocate, and are capturable into a hipGraph;
+ *   - return 0 on success, a negative VCX_E* code on failure; vcx_last_error() gives text.
+ */
+#ifndef VCX_H
+#define VCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCX_OK 0
+#define VCX_EINVAL (-1)   /* bad argument / unsupported shape            */
+#define VCX_ELAUNCH (-2)  /* HIP launch or runtime error                 */
+#define VCX_ENODEV (-3)   /* no gfx950 device                            */
+
+#define VCX_ABI_VERSION 1
+
+int vcx_abi_version(void);
+const char* vcx_last_error(void);
+/* Fills name[0..len) with the gcnArchName of the current device. */
+int vcx_device_arch(char* name_host, int len);
+
+/* ------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM convolution engine (MFMA f16 -> f32 accumulate).
+ *
+ *   out[m, n] = epilogue( alpha * sum_k X[m, k] * W[n, k] )
+ *
+ * X rows are gathered either linearly (mode 0: X[m, k] = A[m*lda + k]) or as an im2col
+ * view of a channels-last image (mode 1), so that one kernel serves
+ *   nn.Linear            lvdm/modules/attention.py:53-57,269,290,336,362,418,438
+ *   nn.Conv2d 3x3 / 1x1  lvdm/modules/networks/openaimodel3d.py:143-147,174-186,69-71,93-106
+ *                        lvdm/modules/networks/ae_modules.py:33-52,99-106,118-127,162-197
+ *   nn.Conv3d (3,1,1)    lvdm/modules/networks/openaimodel3d.py:255-266
+ *   nn.Conv1d k=1        lvdm/modules/attention.py:332-334 (init_attn proj)
+ * Mode 1 geometry: image [n_img, in_h, in_w, cin] with pixel stride lda (elements);
+ * K = kh*kw*cin ordered (ky, kx, c); output pixel (oy, ox) reads input pixel
+ * ((oy*stride + ky - pad_h) >> ups, (ox*stride + kx - pad_w) >> ups), zero outside
+ * [0, in_h<<ups) x [0, in_w<<ups)  (ups=1 fuses F.interpolate(scale_factor=2,'nearest'),
+ * openaimodel3d.py:100-103, ae_modules.py:124).  A temporal (3,1,1) convolution is the
+ * same gather with in_h = T, in_w = H*W, kh = 3, kw = 1, pad_h = 1, pad_w = 0.
+ * ---------------------------------------------------------------------------------- */
+#define VCX_GEMM_BIAS_N 0x1     /* + bias[n]                                              */
+#define VCX_GEMM_BIAS_M 0x2     /* + bias[m]  (used for the transposed V projection)     */
+#define VCX_GEMM_ROWADD 0x4     /* + rowadd[(m / rowadd_div) * N + n]  (ResBlock emb add,
+                                   openaimodel3d.py:216-226)                              */
+#define VCX_GEMM_RESIDUAL 0x8   /* + residual[m*ldr + n]                                  */
+#define VCX_GEMM_GEGLU 0x10     /* out[m, j] = x * gelu_erf(gate), attention.py:415-422;
+                                   W/bias rows pre-interleaved in blocks of 32: rows
+                                   [64b, 64b+32) are x for output cols [32b, 32b+32),
+                                   rows [64b+32, 64b+64) their gates; out has N/2 columns */
+#define VCX_GEMM_OUT_F32 0x20   /* store fp32 instead of fp16                             */
+
+typedef struct vcx_gemm_desc {
+    const void* A;        /* fp16 activations                                             */
+    const void* W;        /* fp16 weights [N][ldw]                                        */
+    void* C;              /* fp16 (or fp32) output [M][ldc]                               */
+    const float* bias;    /* fp32 [N] or [M]                                              */
+    const float* rowadd;  /* fp32 [ceil(M/rowadd_div)][N]                                 */
+    const void* residual; /* fp16 [M][ldr]                                                */
+    int64_t lda;          /* linear: row stride; conv: pixel stride (elements)            */
+    int32_t M, N, K;
+    int32_t ldw, ldc, ldr;
+    int32_t mode;         /* 0 linear, 1 conv gather                                      */
+    int32_t in_h, in_w, out_h, out_w, cin, kh, kw, stride, pad_h, pad_w, ups;
+    int32_t rowadd_div;
+    int32_t flags;
+    float alpha;
+} vcx_gemm_desc;
+
+int vcx_gemm_f16(const vcx_gemm_desc* desc_host, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) on channels-last fp16 with fp32 statistics.
+ *   per-frame   GroupNormSpecific lvdm/basics.py:76-81 (ResBlock in/out layers, UNet out),
+ *               SpatialTransformer.norm attention.py:265, VAE Normalize ae_modules.py:15-16
+ *   per-video   TemporalConvBlock GN openaimodel3d.py:256-266, TemporalTransformer.norm
+ *               attention.py:331   (statistics span T*H*W)
+ * x is [n_outer][pixels][C]; statistics are taken over (pixels, C/groups) per (n, group).
+ * stats: fp32 [n_outer][groups][2] = (sum, sum of squares); written by _stats (it clears
+ * the buffer first), consumed by _apply which computes
+ *   y = (x - mean) * rsqrt(var + eps) * gamma[c] + beta[c], then x*sigmoid(x) if silu.
+ * ---------------------------------------------------------------------------------- */
+int vcx_groupnorm_stats_f16(const void* x, float* stats, int n_outer, int64_t pixels, int C,
+                            int groups, void* stream);
+int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stats, const float* gamma,
+                            const float* beta, int n_outer, int64_t pixels, int C, int groups,
+                            float eps, int silu, void* stream);
+
+/* LayerNorm over the last dim (nn.LayerNorm, attention.py:226-228), fp32 statistics. */
+int vcx_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,
+                      int64_t rows, int C, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Flash attention, head dim 64, no mask:  O = softmax(scale * Q K^T) V
+ *   spatial self-attention / text and image cross-attention
+ *   (CrossAttention.forward / efficient_forward, lvdm/modules/attention.py:81-209)
+ * Problem p = (group g, head h): g in [0, n_groups), h in [0, heads).
+ *   Q rows   : q  + (g*nq)*ldq + h*64          nq rows, row stride ldq
+ *   K rows   : k  + ((g / kv_div) * kv_rows)*ldk + h*64      nk valid rows
+ *   V^T rows : vt + (h*64)*ldvt + (g / kv_div)*kv_rows       64 rows (d) x nk cols (keys)
+ *   O rows   : o  + (g*nq)*ldo + h*64
+ * kv_rows is the row count between consecutive K/V groups (>= nk, multiple of 8).
+ * accumulate != 0 adds into O (second softmax of the text (+) image cross-attention,
+ * attention.py:129-142).
+ * ---------------------------------------------------------------------------------- */
+int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* vt, void* o, int n_groups,
+                           int heads, int nq, int nk, int kv_rows, int kv_div, int64_t ldq,
+                           int64_t ldk, int64_t ldvt, int64_t ldo, float scale, int accumulate,
+                           void* stream);
+
+/* Temporal self-attention over T <= 32 frames per pixel, head dim 64
+ * (TemporalTransformer -> CrossAttention.forward, attention.py:365-412, 81-126).
+ * qkv is [(b t p)][ld] with q at col 0, k at col k_off, v at col v_off (+ h*64);
+ * token (b, t, p) is row (b*T + t)*P + p.  o is [(b t p)][ldo]. */
+int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads,
+                              int64_t ld, int k_off, int v_off, int64_t ldo, float scale,
+                              void* stream);
+
+/* Row softmax in place on fp16 [rows][ld] over the first n columns (fp32 math):
+ * VAE AttnBlock, ae_modules.py:66-69. */
+int vcx_softmax_rows_f16(void* x, int64_t rows, int n, int64_t ld, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Element-wise / layout helpers
+ * ---------------------------------------------------------------------------------- */
+/* x*sigmoid(x) on fp32 -> fp32 (emb_layers SiLU, openaimodel3d.py:158-164). */
+int vcx_silu_f32(const float* x, float* y, int64_t n, void* stream);
+/* sinusoidal embedding, lvdm/models/utils_diffusion.py:8-28: out[b] = [cos(t f) | sin(t f)] */
+int vcx_timestep_embedding_f32(const int64_t* t, float* out, int B, int dim, float max_period,
+                               void* stream);
+/* fp32 -> fp16 / fp16 -> fp32 casts (n elements). */
+int vcx_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
+int vcx_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream);
+/* strided 2-D copy of fp16: dst[r*ldd + c] = src[r*lds + c], c < cols (skip concat,
+ * openaimodel3d.py:596). cols, ldd, lds multiples of 8. */
+int vcx_copy2d_f16(const void* src, void* dst, int64_t rows, int cols, int64_t lds, int64_t ldd,
+                   void* stream);
+/* fp32 [B, C, T, H, W] -> fp16 channels-last [B, T, H, W, ldc] at channel offset c_off
+ * (DiffusionWrapper concat, ddpm3d.py:1437-1443; 'b c t h w -> (b t) c h w',
+ * openaimodel3d.py:566); `scale` multiplies (VAE 1/scale_factor, ddpm3d.py:657-661). */
+int vcx_ncthw_f32_to_nthwc_f16(const float* src, void* dst, int B, int C, int T, int64_t HW,
+                               int ldc, int c_off, float scale, void* stream);
+/* channels-last [B, T, HW, ldc] (fp16 or fp32 per src_f32) -> fp32 [B, C, T, H, W]
+ * ('(b t) c h w -> b c t h w', openaimodel3d.py:601-602). */
+int vcx_nthwc_to_ncthw_f32(const void* src, float* dst, int B, int C, int T, int64_t HW, int ldc,
+                           int src_f32, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DDIM step (v-prediction, classifier-free guidance, guidance rescale, dynamic rescale):
+ * DDIMSampler.p_sample_ddim lvdm/models/samplers/ddim.py:208-281,
+ * rescale_noise_cfg utils_diffusion.py:147-158, predict_*_from_z_and_v ddpm3d.py:239-251.
+ * All tensors fp32 [B][n] (n = C*T*H*W).  coef_host[8] =
+ *   { sqrt_acp_t, sqrt_1m_acp_t, a_prev, sigma_t, scale_ratio(prev/t), cfg_scale,
+ *     guidance_rescale, parameterization_is_v }.
+ * v_uncond may be NULL (no guidance).  noise may be NULL when sigma_t == 0.
+ * ws: device workspace of 32*B bytes (4 fp64 sums per sample), 8-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+int vcx_ddim_step_f32(const float* x, const float* v_cond, const float* v_uncond,
+                      const float* noise, float* x_prev, float* pred_x0, void* ws, int B,
+                      int64_t n, const float* coef_host, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Lightweight per-kernel-family profiling with HIP events (used by bench.py to fill
+ * `roofline`): between begin/end every launch of a family is bracketed by an event pair on
+ * its own stream.  family ids: 0 gemm/conv, 1 flash attention, 2 temporal attention,
+ * 3 groupnorm, 4 layernorm, 5 elementwise.  out_host[6][4] = {launches, total_ms,
+ * total_flops, total_bytes}.  vcx_profile_end synchronises the recorded events.
+ * ---------------------------------------------------------------------------------- */
+#define VCX_PROF_FAMILIES 6
+int vcx_profile_begin(int max_records);
+int vcx_profile_end(double* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCX_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of libvcx.so (include/vcx.h).
+
+The library is the only compute backend of this package: there is no CPU or PyTorch fallback.
+`lib()` raises if the shared object is missing, and every op wrapper raises on a non-zero
+return code with the library's own error text.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvcx.so")
+
+# every symbol include/vcx.h declares (tests/test_abi.py checks the library exports them all)
+SYMBOLS = [
+    "vcx_abi_version", "vcx_last_error", "vcx_device_arch", "vcx_gemm_f16",
+    "vcx_groupnorm_stats_f16", "vcx_groupnorm_apply_f16", "vcx_layernorm_f16",
+    "vcx_attn_flash_d64_f16", "vcx_attn_temporal_d64_f16", "vcx_softmax_rows_f16",
+    "vcx_silu_f32", "vcx_timestep_embedding_f32", "vcx_cast_f32_to_f16", "vcx_cast_f16_to_f32",
+    "vcx_copy2d_f16", "vcx_ncthw_f32_to_nthwc_f16", "vcx_nthwc_to_ncthw_f32", "vcx_ddim_step_f32",
+    "vcx_profile_begin", "vcx_profile_end",
+]
+
+GEMM_BIAS_N, GEMM_BIAS_M, GEMM_ROWADD, GEMM_RESIDUAL, GEMM_GEGLU, GEMM_OUT_F32 = 1, 2, 4, 8, 16, 32
+PROF_FAMILIES = ("gemm", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "elementwise")
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("rowadd", c_void_p),
+        ("residual", c_void_p), ("lda", c_int64), ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("ldw", c_int32), ("ldc", c_int32), ("ldr", c_int32), ("mode", c_int32),
+        ("in_h", c_int32), ("in_w", c_int32), ("out_h", c_int32), ("out_w", c_int32), ("cin", c_int32),
+        ("kh", c_int32), ("kw", c_int32), ("stride", c_int32), ("pad_h", c_int32), ("pad_w", c_int32),
+        ("ups", c_int32), ("rowadd_div", c_int32), ("flags", c_int32), ("alpha", c_float),
+    ]
+
+
+_lib = None
+
+
+class VcxError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libvcx.so once; fail loudly if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VcxError(
+            f"{LIB_PATH} not found: build it with `make -C viewcrafter_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.vcx_abi_version.restype = c_int
+    L.vcx_last_error.restype = c_char_p
+    L.vcx_device_arch.argtypes = [c_char_p, c_int]
+    L.vcx_gemm_f16.argtypes = [POINTER(GemmDesc), c_void_p]
+    L.vcx_groupnorm_stats_f16.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]
+    L.vcx_groupnorm_apply_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
+                                          c_int, c_float, c_int, c_void_p]
+    L.vcx_layernorm_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]
+    L.vcx_attn_flash_d64_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p]
+    L.vcx_attn_temporal_d64_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int64, c_int, c_int,
+                                            c_int64, c_float, c_void_p]
+    L.vcx_softmax_rows_f16.argtypes = [c_void_p, c_int64, c_int, c_int64, c_void_p]
+    L.vcx_silu_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+    L.vcx_timestep_embedding_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
+    L.vcx_cast_f32_to_f16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+    L.vcx_cast_f16_to_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+    L.vcx_copy2d_f16.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p]
+    L.vcx_ncthw_f32_to_nthwc_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_float,
+                                             c_void_p]
+    L.vcx_nthwc_to_ncthw_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]
+    L.vcx_ddim_step_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_int64, POINTER(c_float), c_void_p]
+    L.vcx_profile_begin.argtypes = [c_int]
+    L.vcx_profile_end.argtypes = [POINTER(c_double)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name != "vcx_last_error":
+            fn.restype = c_int
+    if L.vcx_abi_version() != 1:
+        raise VcxError(f"libvcx ABI version {L.vcx_abi_version()} != 1; rebuild the library")
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().vcx_last_error().decode("utf-8", "replace")
+        raise VcxError(f"libvcx call failed ({rc}) {what}: {msg}")

@@ -1,0 +1,110 @@
+// libvcx: error reporting, device query, HIP-event profiling of kernel families.
+#include "vcx_common.h"
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void vcx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int vcx_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        vcx_set_error("%s: %s", what, hipGetErrorString(e));
+        return VCX_ELAUNCH;
+    }
+    return VCX_OK;
+}
+
+extern "C" int vcx_abi_version(void) { return VCX_ABI_VERSION; }
+extern "C" const char* vcx_last_error(void) { return g_err; }
+
+extern "C" int vcx_device_arch(char* name_host, int len) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        vcx_set_error("no HIP device");
+        return VCX_ENODEV;
+    }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        vcx_set_error("hipGetDeviceProperties failed");
+        return VCX_ENODEV;
+    }
+    if (name_host && len > 0) {
+        strncpy(name_host, p.gcnArchName, len - 1);
+        name_host[len - 1] = 0;
+    }
+    return VCX_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Profiling: a pool of event pairs; each profiled launch takes the next pair.
+// ---------------------------------------------------------------------------------------
+struct ProfRec {
+    hipEvent_t a, b;
+    int family;
+    double flops, bytes;
+};
+static std::vector<ProfRec> g_recs;
+static int g_nrec = 0;
+static bool g_prof_on = false;
+
+extern "C" int vcx_profile_begin(int max_records) {
+    if (max_records <= 0) max_records = 1;
+    while ((int)g_recs.size() < max_records) {
+        ProfRec r;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+            vcx_set_error("hipEventCreate failed");
+            return VCX_ELAUNCH;
+        }
+        r.family = 0;
+        r.flops = r.bytes = 0;
+        g_recs.push_back(r);
+    }
+    g_nrec = 0;
+    g_prof_on = true;
+    return VCX_OK;
+}
+
+extern "C" int vcx_profile_end(double* out_host) {
+    g_prof_on = false;
+    for (int i = 0; i < VCX_PROF_FAMILIES * 4; ++i) out_host[i] = 0.0;
+    for (int i = 0; i < g_nrec; ++i) {
+        ProfRec& r = g_recs[i];
+        if (hipEventSynchronize(r.b) != hipSuccess) {
+            vcx_set_error("hipEventSynchronize failed");
+            return VCX_ELAUNCH;
+        }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) {
+            vcx_set_error("hipEventElapsedTime failed");
+            return VCX_ELAUNCH;
+        }
+        double* o = out_host + 4 * r.family;
+        o[0] += 1.0;
+        o[1] += (double)ms;
+        o[2] += r.flops;
+        o[3] += r.bytes;
+    }
+    g_nrec = 0;
+    return VCX_OK;
+}
+
+VcxProfScope::VcxProfScope(int family, hipStream_t stream, double flops, double bytes) : rec(-1), s(stream) {
+    if (!g_prof_on || g_nrec >= (int)g_recs.size()) return;
+    rec = g_nrec++;
+    ProfRec& r = g_recs[rec];
+    r.family = family;
+    r.flops = flops;
+    r.bytes = bytes;
+    (void)hipEventRecord(r.a, s);
+}
+VcxProfScope::~VcxProfScope() {
+    if (rec >= 0) (void)hipEventRecord(g_recs[rec].b, s);
+}

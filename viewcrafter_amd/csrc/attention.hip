@@ -1,0 +1,386 @@
+// Attention kernels for gfx950: flash attention (head dim 64) on MFMA 32x32x16 f16, temporal
+// attention over T <= 32 frames on the VALU, and an in-place row softmax.
+#include "vcx_common.h"
+
+namespace {
+
+// =======================================================================================
+// Flash attention, d = 64.
+//
+// Block = 4 waves, wave w owns 32 query rows; K/V are streamed in 64-key tiles through LDS
+// (K tile [64 keys][64 d], V^T tile [64 d][64 keys], both XOR-swizzled, double buffered).
+//
+// Per wave and key tile (all on v_mfma_f32_32x32x16_f16):
+//   S^T[key, q]  = K[key, :] . Q[q, :]         (A = K fragment, B = Q fragment)
+//   O^T[d, q]   += V^T[d, key] . P^T[key, q]   (A = V^T fragment, B = P fragment)
+// In both products the MFMA column index is the query row (lane & 31), so the softmax
+// statistics of a query live in one lane pair (lane, lane^32): the running max / sum are
+// per-lane scalars and rescaling O^T is a per-lane multiply.  The S^T accumulator of lane
+// (q, hi) holds keys {r&3 + 8*(r>>2) + 4*hi}; it is fed back as the B operand of the PV MFMA
+// WITHOUT any cross-lane movement by reading the V^T fragment with the same key permutation
+// (a sum over keys does not care about the order as long as P and V agree on it).
+// =======================================================================================
+constexpr int FQ = 128;  // query rows per block
+constexpr int FK = 64;   // keys per tile
+
+struct FlashArgs {
+    const half_t* q;
+    const half_t* k;
+    const half_t* vt;
+    half_t* o;
+    int heads, nq, nk, kv_rows, kv_div;
+    int64_t ldq, ldk, ldvt, ldo;
+    float scale_log2;
+    int accumulate;
+};
+
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+__global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
+    __shared__ __attribute__((aligned(16))) half_t sK[2][64 * 64];
+    __shared__ __attribute__((aligned(16))) half_t sV[2][64 * 64];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int g = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
+    const int q0 = blockIdx.x * FQ + wave * 32;
+
+    const half_t* qbase = p.q + ((int64_t)g * p.nq) * p.ldq + h * 64;
+    const int64_t kvrow0 = (int64_t)(g / p.kv_div) * p.kv_rows;
+    const half_t* kbase = p.k + kvrow0 * p.ldk + h * 64;
+    const half_t* vbase = p.vt + (int64_t)(h * 64) * p.ldvt + kvrow0;
+
+    // Q fragments (B operand): lane (q = lq, hi) holds Q[q][s*16 + hi*8 .. +7]
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    h8 qf[4];
+    const int qrow = q0 + lq;
+    const bool qvalid = qrow < p.nq;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        qf[s] = qvalid ? *reinterpret_cast<const h8*>(qbase + (int64_t)qrow * p.ldq + s * 16 + hi * 8) : zero8;
+
+    // staging map: 512 chunks per tile, 2 per thread
+    const int srow = tid >> 3, schunk = tid & 7;
+    h8 kreg[2], vreg[2];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = srow + 32 * i;
+            const int key = kt * FK + r;
+            kreg[i] = (key < p.nk) ? *reinterpret_cast<const h8*>(kbase + (int64_t)key * p.ldk + schunk * 8) : zero8;
+            const int kc = kt * FK + schunk * 8;  // first key of this V^T chunk
+            vreg[i] = (kc < p.nk) ? *reinterpret_cast<const h8*>(vbase + (int64_t)r * p.ldvt + kc) : zero8;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = srow + 32 * i;
+            *reinterpret_cast<h8*>(&sK[buf][tile_off(r, schunk)]) = kreg[i];
+            *reinterpret_cast<h8*>(&sV[buf][tile_off(r, schunk)]) = vreg[i];
+        }
+    };
+
+    f16v oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int ntiles = (p.nk + FK - 1) / FK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const bool more = kt + 1 < ntiles;
+        if (more) load_tile(kt + 1);
+        const half_t* cK = sK[cur];
+        const half_t* cV = sV[cur];
+
+        // ---- S^T = K Q^T for the two 32-key halves of the tile
+        f16v sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const h8 kf = *reinterpret_cast<const h8*>(cK + tile_off(kb * 32 + lq, s * 2 + hi));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
+            }
+        }
+        // ---- scale, mask the tail keys, online softmax
+        const int key_base = kt * FK;
+        const bool tail = key_base + FK > p.nk;
+        float mx = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = sacc[kb][r] * p.scale_log2;
+                if (tail) {
+                    const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.nk) v = -1e30f;
+                }
+                sacc[kb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new);
+                sacc[kb][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                h8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[kb][8 * s + j];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const int row = db * 32 + lq;
+                    const int c0 = kb * 4 + 2 * s;
+                    const h4 lo = *reinterpret_cast<const h4*>(cV + tile_off(row, c0) + 4 * hi);
+                    const h4 hi4 = *reinterpret_cast<const h4*>(cV + tile_off(row, c0 + 1) + 4 * hi);
+                    const h8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (qvalid) {
+        half_t* orow = p.o + ((int64_t)g * p.nq + qrow) * p.ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d0 = db * 32 + 8 * gq + 4 * hi;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = oacc[db][gq * 4 + r] * inv;
+                if (p.accumulate) {
+                    const h4 old = *reinterpret_cast<const h4*>(orow + d0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                }
+                *reinterpret_cast<h4*>(orow + d0) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            }
+    }
+}
+
+// =======================================================================================
+// Temporal attention: T <= 32 frames, d = 64.  One half-wave (32 lanes) per (pixel, head);
+// lane i is query frame i.  K and V of the pair sit in LDS ([T][64] fp16 each) and are read
+// as broadcasts; scores and the output row are kept in registers.
+// =======================================================================================
+struct TAttnArgs {
+    const half_t* qkv;
+    half_t* o;
+    int B, T, heads;
+    int64_t P, ld, ldo;
+    int k_off, v_off;
+    float scale;
+    int64_t npairs;
+};
+
+__global__ void __launch_bounds__(256) tattn_d64_kernel(TAttnArgs p) {
+    __shared__ __attribute__((aligned(16))) half_t sKV[8][2][32 * 64];  // [half-wave][K|V][t][d]
+    const int tid = threadIdx.x;
+    const int hw = tid >> 5;        // half-wave id in block, 0..7
+    const int i = tid & 31;         // query frame
+    const int64_t pair = (int64_t)blockIdx.x * 8 + hw;
+    const bool pvalid = pair < p.npairs;
+    const int64_t pr = pvalid ? pair : 0;
+    const int h = (int)(pr % p.heads);
+    const int64_t pix = (pr / p.heads) % p.P;
+    const int b = (int)(pr / (p.heads * p.P));
+    const half_t* base = p.qkv + ((int64_t)b * p.T * p.P + pix) * p.ld + h * 64;  // frame 0 row
+    const int64_t fstride = p.P * p.ld;
+
+    // stage K, V rows of this pair: T rows x 8 chunks each
+    half_t* sk = sKV[hw][0];
+    half_t* sv = sKV[hw][1];
+    for (int c = i; c < p.T * 8; c += 32) {
+        const int t = c >> 3, ch = c & 7;
+        const half_t* src = base + (int64_t)t * fstride + ch * 8;
+        *reinterpret_cast<h8*>(sk + t * 64 + ch * 8) = *reinterpret_cast<const h8*>(src + p.k_off);
+        *reinterpret_cast<h8*>(sv + t * 64 + ch * 8) = *reinterpret_cast<const h8*>(src + p.v_off);
+    }
+    const bool active = pvalid && i < p.T;
+    h8 qv[8];
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        qv[c] = active ? *reinterpret_cast<const h8*>(base + (int64_t)i * fstride + c * 8) : zero8;
+    __syncthreads();
+
+    float s[32];
+    float mx = -1e30f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        float acc = 0.f;
+        if (j < p.T) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const h8 kv = *reinterpret_cast<const h8*>(sk + j * 64 + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2)
+                    acc = __builtin_amdgcn_fdot2(h2{qv[c][e], qv[c][e + 1]}, h2{kv[e], kv[e + 1]}, acc, false);
+            }
+            acc *= p.scale;
+            mx = fmaxf(mx, acc);
+        } else {
+            acc = -1e30f;
+        }
+        s[j] = acc;
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float e = (j < p.T) ? __expf(s[j] - mx) : 0.f;
+        s[j] = e;
+        l += e;
+    }
+    const float inv = 1.0f / l;
+    float oacc[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) oacc[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        if (j < p.T) {
+            // reference multiplies the fp16-rounded probabilities (autocast einsum)
+            const float pj = (float)(half_t)(s[j] * inv);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const h8 vv = *reinterpret_cast<const h8*>(sv + j * 64 + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) oacc[c * 8 + e] += pj * (float)vv[e];
+            }
+        }
+    }
+    if (active) {
+        half_t* dst = p.o + (((int64_t)b * p.T + i) * p.P + pix) * p.ldo + h * 64;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            h8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (half_t)oacc[c * 8 + e];
+            *reinterpret_cast<h8*>(dst + c * 8) = ov;
+        }
+    }
+}
+
+// =======================================================================================
+// Row softmax in place (fp16 storage, fp32 math), one block per row.
+// =======================================================================================
+__global__ void __launch_bounds__(256) softmax_rows_kernel(half_t* x, int n, int64_t ld) {
+    __shared__ float red[8];
+    half_t* row = x + (int64_t)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    const int nch = n >> 3;
+    float mx = -1e30f;
+    for (int c = tid; c < nch; c += 256) {
+        const h8 v = *reinterpret_cast<const h8*>(row + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[e]);
+    }
+    mx = vcx_wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int c = tid; c < nch; c += 256) {
+        const h8 v = *reinterpret_cast<const h8*>(row + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += __expf((float)v[e] - mx);
+    }
+    sum = vcx_wave_sum(sum);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    sum = red[4] + red[5] + red[6] + red[7];
+    const float inv = 1.0f / sum;
+    for (int c = tid; c < nch; c += 256) {
+        h8 v = *reinterpret_cast<const h8*>(row + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)(__expf((float)v[e] - mx) * inv);
+        *reinterpret_cast<h8*>(row + c * 8) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* vt, void* o, int n_groups, int heads,
+                                      int nq, int nk, int kv_rows, int kv_div, int64_t ldq, int64_t ldk, int64_t ldvt,
+                                      int64_t ldo, float scale, int accumulate, void* stream) {
+    VCX_REQUIRE(q && k && vt && o, "vcx_attn_flash_d64_f16: null pointer");
+    VCX_REQUIRE(n_groups > 0 && heads > 0 && nq > 0 && nk > 0 && kv_div > 0, "vcx_attn_flash_d64_f16: empty problem");
+    VCX_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && kv_rows % 8 == 0 && kv_rows >= nk,
+                "vcx_attn_flash_d64_f16: strides must be multiples of 8 and kv_rows >= nk (ldq=%lld ldk=%lld ldvt=%lld kv_rows=%d nk=%d)",
+                (long long)ldq, (long long)ldk, (long long)ldvt, kv_rows, nk);
+    VCX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0 && ((uintptr_t)o & 7) == 0,
+                "vcx_attn_flash_d64_f16: pointers must be 16-byte aligned");
+    VCX_REQUIRE((int64_t)n_groups * heads <= 65535, "vcx_attn_flash_d64_f16: too many (group, head) problems");
+    FlashArgs a;
+    a.q = (const half_t*)q; a.k = (const half_t*)k; a.vt = (const half_t*)vt; a.o = (half_t*)o;
+    a.heads = heads; a.nq = nq; a.nk = nk; a.kv_rows = kv_rows; a.kv_div = kv_div;
+    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.accumulate = accumulate;
+    hipStream_t s = (hipStream_t)stream;
+    const double nprob = (double)n_groups * heads;
+    VcxProfScope prof(VCX_FAM_FLASH, s, 4.0 * nprob * nq * (double)nk * 64, 2.0 * nprob * 64 * (2.0 * nq + 2.0 * nk));
+    dim3 grid((nq + FQ - 1) / FQ, n_groups * heads);
+    hipLaunchKernelGGL(flash_d64_kernel, grid, dim3(256), 0, s, a);
+    return vcx_check_launch("vcx_attn_flash_d64_f16");
+}
+
+extern "C" int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads, int64_t ld,
+                                         int k_off, int v_off, int64_t ldo, float scale, void* stream) {
+    VCX_REQUIRE(qkv && o, "vcx_attn_temporal_d64_f16: null pointer");
+    VCX_REQUIRE(B > 0 && T > 0 && T <= 32 && P > 0 && heads > 0, "vcx_attn_temporal_d64_f16: need 0 < T <= 32 (T=%d)", T);
+    VCX_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0,
+                "vcx_attn_temporal_d64_f16: strides/offsets must be multiples of 8");
+    VCX_REQUIRE((((uintptr_t)qkv | (uintptr_t)o) & 15) == 0, "vcx_attn_temporal_d64_f16: pointers must be 16-byte aligned");
+    TAttnArgs a;
+    a.qkv = (const half_t*)qkv; a.o = (half_t*)o;
+    a.B = B; a.T = T; a.heads = heads; a.P = P; a.ld = ld; a.ldo = ldo;
+    a.k_off = k_off; a.v_off = v_off; a.scale = scale;
+    a.npairs = (int64_t)B * P * heads;
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_TATTN, s, 4.0 * a.npairs * (double)T * T * 64, 2.0 * a.npairs * T * 64 * 4.0);
+    const int64_t nblk = (a.npairs + 7) / 8;
+    VCX_REQUIRE(nblk < (1ll << 31), "vcx_attn_temporal_d64_f16: grid too large");
+    hipLaunchKernelGGL(tattn_d64_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    return vcx_check_launch("vcx_attn_temporal_d64_f16");
+}
+
+extern "C" int vcx_softmax_rows_f16(void* x, int64_t rows, int n, int64_t ld, void* stream) {
+    VCX_REQUIRE(x && rows > 0 && n > 0, "vcx_softmax_rows_f16: empty problem");
+    VCX_REQUIRE(n % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x & 15) == 0, "vcx_softmax_rows_f16: n, ld multiples of 8");
+    VCX_REQUIRE(rows < (1ll << 31), "vcx_softmax_rows_f16: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 4.0 * rows * (double)n);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, (half_t*)x, n, ld);
+    return vcx_check_launch("vcx_softmax_rows_f16");
+}

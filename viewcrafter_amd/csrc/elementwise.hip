@@ -1,0 +1,250 @@
+// Element-wise, layout and DDIM-update kernels (all HBM/launch bound).
+#include "vcx_common.h"
+#include <math.h>
+
+namespace {
+
+__global__ void silu_f32_kernel(const float* x, float* y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = vcx_silu(x[i]);
+}
+
+// out[b][0:half] = cos(t*f_j), out[b][half:2*half] = sin(t*f_j), f_j = exp(-ln(max_period) j / half)
+__global__ void timestep_embedding_kernel(const int64_t* t, float* out, int B, int dim, float log_max_period) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i % half;
+    const float freq = expf(-log_max_period * (float)j / (float)half);
+    const float arg = (float)t[b] * freq;
+    out[(int64_t)b * dim + j] = cosf(arg);
+    out[(int64_t)b * dim + half + j] = sinf(arg);
+    if ((dim & 1) && j == 0) out[(int64_t)b * dim + dim - 1] = 0.f;
+}
+
+__global__ void cast_f32_f16_kernel(const float* x, half_t* y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (half_t)x[i];
+}
+__global__ void cast_f16_f32_kernel(const half_t* x, float* y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (float)x[i];
+}
+
+__global__ void copy2d_kernel(const half_t* src, half_t* dst, int64_t rows, int c8, int64_t lds_, int64_t ldd) {
+    const int64_t total = rows * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / c8;
+        const int c = (int)(i - r * c8);
+        *reinterpret_cast<h8*>(dst + r * ldd + c * 8) = *reinterpret_cast<const h8*>(src + r * lds_ + c * 8);
+    }
+}
+
+// src fp32 [B][C][T][HW] -> dst fp16 [B][T][HW][ldc] at channel offset c_off
+__global__ void ncthw_to_nthwc_kernel(const float* src, half_t* dst, int B, int C, int T, int64_t HW, int ldc, int c_off,
+                                      float scale) {
+    const int64_t total = (int64_t)B * C * T * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i % HW;
+        int64_t r = i / HW;
+        const int t = (int)(r % T);
+        r /= T;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        dst[(((int64_t)b * T + t) * HW + p) * ldc + c_off + c] = (half_t)(src[i] * scale);
+    }
+}
+
+template <bool SRC_F32>
+__global__ void nthwc_to_ncthw_kernel(const void* src, float* dst, int B, int C, int T, int64_t HW, int ldc) {
+    const int64_t total = (int64_t)B * C * T * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i % HW;
+        int64_t r = i / HW;
+        const int t = (int)(r % T);
+        r /= T;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const int64_t si = (((int64_t)b * T + t) * HW + p) * ldc + c;
+        dst[i] = SRC_F32 ? reinterpret_cast<const float*>(src)[si] : (float)reinterpret_cast<const half_t*>(src)[si];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// DDIM step.  Pass 1: per-sample sums needed by the guidance rescale (unbiased std of v_cond
+// and of the guided v).  Pass 2: the update.
+// ---------------------------------------------------------------------------------------
+struct DdimCoef {
+    float sqrt_acp, sqrt_1m_acp, sqrt_a_prev, dir_coef, sigma, scale_ratio, cfg, rescale;
+    int is_v, has_uncond, has_noise;
+};
+
+__global__ void __launch_bounds__(256) ddim_reduce_kernel(const float* vc, const float* vu, double* ws, int64_t n, float cfg) {
+    __shared__ double red[4][4];
+    const int b = blockIdx.y;
+    const float* c = vc + (int64_t)b * n;
+    const float* u = vu + (int64_t)b * n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = c[i];
+        const float g = u[i] + cfg * (a - u[i]);
+        s0 += a; s1 += a * a; s2 += g; s3 += g * g;
+    }
+    s0 = vcx_wave_sum(s0); s1 = vcx_wave_sum(s1); s2 = vcx_wave_sum(s2); s3 = vcx_wave_sum(s3);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = s0; red[w][1] = s1; red[w][2] = s2; red[w][3] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(&ws[b * 4 + threadIdx.x], t);
+    }
+}
+
+__global__ void __launch_bounds__(256) ddim_update_kernel(const float* x, const float* vc, const float* vu, const float* noise,
+                                                          float* x_prev, float* pred_x0, const double* ws, int64_t n,
+                                                          DdimCoef k) {
+    const int b = blockIdx.y;
+    float mix = 1.0f;  // v = v_guided * mix
+    if (k.has_uncond && k.rescale > 0.f) {
+        const double nn = (double)n;
+        const double sc = ws[b * 4 + 0], qc = ws[b * 4 + 1], sg = ws[b * 4 + 2], qg = ws[b * 4 + 3];
+        const double var_c = (qc - sc * sc / nn) / (nn - 1.0), var_g = (qg - sg * sg / nn) / (nn - 1.0);
+        const float std_c = (float)sqrt(var_c > 0 ? var_c : 0), std_g = (float)sqrt(var_g > 0 ? var_g : 0);
+        mix = k.rescale * (std_c / std_g) + (1.0f - k.rescale);
+    }
+    const int64_t off = (int64_t)b * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float xi = x[off + i];
+        float v = vc[off + i];
+        if (k.has_uncond) {
+            const float u = vu[off + i];
+            v = (u + k.cfg * (v - u)) * mix;
+        }
+        float e_t, x0;
+        if (k.is_v) {
+            e_t = k.sqrt_acp * v + k.sqrt_1m_acp * xi;
+            x0 = k.sqrt_acp * xi - k.sqrt_1m_acp * v;
+        } else {
+            e_t = v;
+            x0 = (xi - k.sqrt_1m_acp * v) / k.sqrt_acp;
+        }
+        x0 *= k.scale_ratio;
+        float xp = k.sqrt_a_prev * x0 + k.dir_coef * e_t;
+        if (k.has_noise) xp += k.sigma * noise[off + i];
+        pred_x0[off + i] = x0;
+        x_prev[off + i] = xp;
+    }
+}
+
+inline unsigned grid_for(int64_t n, int cap = 4096) {
+    int64_t g = (n + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int vcx_silu_f32(const float* x, float* y, int64_t n, void* stream) {
+    VCX_REQUIRE(x && y && n > 0, "vcx_silu_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 8.0 * n);
+    hipLaunchKernelGGL(silu_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+    return vcx_check_launch("vcx_silu_f32");
+}
+
+extern "C" int vcx_timestep_embedding_f32(const int64_t* t, float* out, int B, int dim, float max_period, void* stream) {
+    VCX_REQUIRE(t && out && B > 0 && dim >= 2, "vcx_timestep_embedding_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 4.0 * B * dim);
+    const int total = B * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, s, t, out, B, dim,
+                       logf(max_period));
+    return vcx_check_launch("vcx_timestep_embedding_f32");
+}
+
+extern "C" int vcx_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream) {
+    VCX_REQUIRE(x && y && n > 0, "vcx_cast_f32_to_f16: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 6.0 * n);
+    hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, (half_t*)y, n);
+    return vcx_check_launch("vcx_cast_f32_to_f16");
+}
+
+extern "C" int vcx_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream) {
+    VCX_REQUIRE(x && y && n > 0, "vcx_cast_f16_to_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 6.0 * n);
+    hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, (const half_t*)x, y, n);
+    return vcx_check_launch("vcx_cast_f16_to_f32");
+}
+
+extern "C" int vcx_copy2d_f16(const void* src, void* dst, int64_t rows, int cols, int64_t lds_, int64_t ldd, void* stream) {
+    VCX_REQUIRE(src && dst && rows > 0 && cols > 0, "vcx_copy2d_f16: bad arguments");
+    VCX_REQUIRE(cols % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
+                "vcx_copy2d_f16: cols/strides must be multiples of 8 and pointers 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 4.0 * rows * (double)cols);
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * (cols / 8), 16384)), dim3(256), 0, s, (const half_t*)src,
+                       (half_t*)dst, rows, cols / 8, lds_, ldd);
+    return vcx_check_launch("vcx_copy2d_f16");
+}
+
+extern "C" int vcx_ncthw_f32_to_nthwc_f16(const float* src, void* dst, int B, int C, int T, int64_t HW, int ldc, int c_off,
+                                          float scale, void* stream) {
+    VCX_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && c_off >= 0 && c_off + C <= ldc,
+                "vcx_ncthw_f32_to_nthwc_f16: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * C * T * HW;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 6.0 * n);
+    hipLaunchKernelGGL(ncthw_to_nthwc_kernel, dim3(grid_for(n, 16384)), dim3(256), 0, s, src, (half_t*)dst, B, C, T, HW, ldc,
+                       c_off, scale);
+    return vcx_check_launch("vcx_ncthw_f32_to_nthwc_f16");
+}
+
+extern "C" int vcx_nthwc_to_ncthw_f32(const void* src, float* dst, int B, int C, int T, int64_t HW, int ldc, int src_f32,
+                                      void* stream) {
+    VCX_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && C <= ldc, "vcx_nthwc_to_ncthw_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * C * T * HW;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 6.0 * n);
+    if (src_f32)
+        hipLaunchKernelGGL(nthwc_to_ncthw_kernel<true>, dim3(grid_for(n, 16384)), dim3(256), 0, s, src, dst, B, C, T, HW, ldc);
+    else
+        hipLaunchKernelGGL(nthwc_to_ncthw_kernel<false>, dim3(grid_for(n, 16384)), dim3(256), 0, s, src, dst, B, C, T, HW, ldc);
+    return vcx_check_launch("vcx_nthwc_to_ncthw_f32");
+}
+
+extern "C" int vcx_ddim_step_f32(const float* x, const float* v_cond, const float* v_uncond, const float* noise,
+                                 float* x_prev, float* pred_x0, void* ws, int B, int64_t n, const float* coef_host,
+                                 void* stream) {
+    VCX_REQUIRE(x && v_cond && x_prev && pred_x0 && ws && coef_host, "vcx_ddim_step_f32: null pointer");
+    VCX_REQUIRE(B > 0 && B <= 65535 && n > 1, "vcx_ddim_step_f32: bad sizes");
+    VCX_REQUIRE(((uintptr_t)ws & 7) == 0, "vcx_ddim_step_f32: ws must be 8-byte aligned");
+    DdimCoef k;
+    const float a_prev = coef_host[2], sigma = coef_host[3];
+    k.sqrt_acp = coef_host[0];
+    k.sqrt_1m_acp = coef_host[1];
+    k.sqrt_a_prev = sqrtf(a_prev);
+    const float dir2 = 1.0f - a_prev - sigma * sigma;
+    k.dir_coef = sqrtf(dir2 > 0.f ? dir2 : 0.f);
+    k.sigma = sigma;
+    k.scale_ratio = coef_host[4];
+    k.cfg = coef_host[5];
+    k.rescale = coef_host[6];
+    k.is_v = coef_host[7] != 0.f;
+    k.has_uncond = v_uncond != nullptr;
+    k.has_noise = (noise != nullptr) && sigma != 0.f;
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 4.0 * B * (double)n * 8);
+    const unsigned gx = grid_for(n, 256);
+    if (k.has_uncond && k.rescale > 0.f) {
+        if (hipMemsetAsync(ws, 0, sizeof(double) * 4 * B, s) != hipSuccess) {
+            vcx_set_error("vcx_ddim_step_f32: memset failed");
+            return VCX_ELAUNCH;
+        }
+        hipLaunchKernelGGL(ddim_reduce_kernel, dim3(gx, B), dim3(256), 0, s, v_cond, v_uncond, (double*)ws, n, k.cfg);
+        int rc = vcx_check_launch("vcx_ddim_step_f32(reduce)");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(ddim_update_kernel, dim3(gx, B), dim3(256), 0, s, x, v_cond, v_uncond, noise, x_prev, pred_x0,
+                       (const double*)ws, n, k);
+    return vcx_check_launch("vcx_ddim_step_f32");
+}

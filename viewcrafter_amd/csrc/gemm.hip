@@ -1,0 +1,366 @@
+// GEMM / implicit-GEMM convolution engine for gfx950 (CDNA4), fp16 in, fp32 accumulate.
+//
+//   out[m, n] = epilogue(alpha * sum_k X[m, k] * W[n, k])
+//
+// Tile: BM=128 output rows x BN (128 or 160) output columns x BK=64, 256 threads = 4 waves
+// arranged 2 (m) x 2 (n); a wave owns 64 x BN/2 outputs as 4 x (BN/32) fragments of
+// v_mfma_f32_16x16x32_f16.  The MFMA is issued with the WEIGHT fragment as operand A and the
+// ACTIVATION fragment as operand B, so D[i][j] = out[m = j][n = i]: a lane then holds 4
+// consecutive output columns of one output row (row = lane&15, cols = 4*(lane>>4)+r) and the
+// epilogue stores 8 contiguous bytes per fragment instead of four 2-byte scatters.
+//
+// Staging is global -> registers -> LDS (ds_write_b128) with the 16-byte chunk index XORed by
+// ((row>>1)&7): 128-byte rows would otherwise put every lane of a ds_read_b128 group on the
+// same bank slots.  LDS is double buffered; the next tile's global loads are issued before the
+// current tile's MFMAs and written to the other buffer after them (one barrier per K-step).
+//
+// X rows are either linear (mode 0) or an im2col gather over a channels-last image (mode 1):
+// every 16-byte load is 8 consecutive input channels of one tap, so a 3x3 / (3,1,1) / strided /
+// nearest-upsampled convolution is the same main loop with a different address function and
+// zero fill outside the image.
+#include "vcx_common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr int NTHREADS = 256;
+
+struct GemmArgs {
+    const half_t* A;
+    const half_t* W;
+    void* C;
+    const float* bias;
+    const float* rowadd;
+    const half_t* R;
+    int64_t lda;
+    int M, N, K;
+    int ldw, ldc, ldr;
+    int in_h, in_w, out_h, out_w, cin, kw, stride, pad_h, pad_w, ups;
+    int rowadd_div;
+    int flags;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    // element offset of a 16-byte chunk inside a [rows][64] fp16 tile
+    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
+    constexpr int NFRAG = BN / 32;          // 16-wide n fragments per wave
+    constexpr int WROWS = BN / 32;          // weight rows staged per thread (BN*8 chunks / 256)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    half_t* sX = reinterpret_cast<half_t*>(smem_raw);              // [2][BM*BK]
+    half_t* sW = sX + 2 * BM * BK;                                  // [2][BN*BK]
+
+    // ---- XCD-aware tile mapping: XCD x (= blockIdx % 8) walks a contiguous band of tiles so
+    // that the tiles sharing an activation panel hit the same L2.
+    const int nb = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int tile_n = vid % p.tiles_n;
+    const int tile_m = vid / p.tiles_n;
+
+    const int tid = threadIdx.x;
+    const int chunk = tid & 7;   // 16-byte chunk inside the BK=64 slice
+    const int r0 = tid >> 3;     // 0..31
+
+    // ---- per-thread gather state for the 4 activation rows this thread stages
+    int64_t xbase[4];  // linear: element offset of the row; conv: image base pixel index
+    int xoy[4], xox[4];
+    bool xvalid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = tile_m * BM + r0 + 32 * i;
+        xvalid[i] = m < p.M;
+        if (CONV) {
+            const int hw = p.out_h * p.out_w;
+            const int mm = xvalid[i] ? m : 0;
+            const int img = mm / hw;
+            const int rem = mm - img * hw;
+            const int oy = rem / p.out_w;
+            const int ox = rem - oy * p.out_w;
+            xbase[i] = (int64_t)img * p.in_h * p.in_w;
+            xoy[i] = oy * p.stride - p.pad_h;
+            xox[i] = ox * p.stride - p.pad_w;
+        } else {
+            xbase[i] = (int64_t)m * p.lda;
+            xoy[i] = xox[i] = 0;
+        }
+    }
+    // conv tap walker: k = (ky*kw + kx)*cin + ci, advanced by BK per K-step
+    int ci = chunk * 8, ky = 0, kx = 0;
+    if (CONV) {
+        while (ci >= p.cin) {
+            ci -= p.cin;
+            if (++kx == p.kw) { kx = 0; ++ky; }
+        }
+    }
+    // weight rows
+    const half_t* wptr[WROWS];
+    bool wvalid[WROWS];
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) {
+        const int n = tile_n * BN + r0 + 32 * i;
+        wvalid[i] = n < p.N;
+        wptr[i] = p.W + (int64_t)(wvalid[i] ? n : 0) * p.ldw + chunk * 8;
+    }
+
+    h8 xreg[4];
+    h8 wreg[WROWS];
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int lim_h = p.in_h << p.ups, lim_w = p.in_w << p.ups;
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK + chunk * 8;
+        const bool kin = k0 < p.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h8 v = zero8;
+            if (CONV) {
+                const int iy = xoy[i] + ky, ix = xox[i] + kx;
+                if (kin && xvalid[i] && iy >= 0 && iy < lim_h && ix >= 0 && ix < lim_w) {
+                    const int64_t pix = xbase[i] + (int64_t)(iy >> p.ups) * p.in_w + (ix >> p.ups);
+                    v = *reinterpret_cast<const h8*>(p.A + pix * p.lda + ci);
+                }
+            } else {
+                if (kin && xvalid[i]) v = *reinterpret_cast<const h8*>(p.A + xbase[i] + k0);
+            }
+            xreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            h8 v = zero8;
+            if (kin && wvalid[i]) v = *reinterpret_cast<const h8*>(wptr[i] + (int64_t)kt * BK);
+            wreg[i] = v;
+        }
+        if (CONV) {  // advance the tap walker to the next K-step
+            ci += BK;
+            while (ci >= p.cin) {
+                ci -= p.cin;
+                if (++kx == p.kw) { kx = 0; ++ky; }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        half_t* dx = sX + buf * BM * BK;
+        half_t* dw = sW + buf * BN * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<h8*>(dx + lds_off(r0 + 32 * i, chunk)) = xreg[i];
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) *reinterpret_cast<h8*>(dw + lds_off(r0 + 32 * i, chunk)) = wreg[i];
+    };
+
+    // ---- wave / lane decomposition
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    f4 acc[NFRAG][4];
+#pragma unroll
+    for (int a = 0; a < NFRAG; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) load_tile(kt + 1);
+        const half_t* cx = sX + cur * BM * BK;
+        const half_t* cw = sW + cur * BN * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 wf[NFRAG], xf[4];
+#pragma unroll
+            for (int a = 0; a < NFRAG; ++a)
+                wf[a] = *reinterpret_cast<const h8*>(cw + lds_off(wn * (BN / 2) + a * 16 + lr, kk * 4 + lg));
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(wm * 64 + b * 16 + lr, kk * 4 + lg));
+#pragma unroll
+            for (int a = 0; a < NFRAG; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue.  acc[a][b][r] = out[m][n], m = tile_m*BM + wm*64 + b*16 + lr,
+    //      n = tile_n*BN + wn*(BN/2) + a*16 + lg*4 + r.
+    const int flags = p.flags;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int m = tile_m * BM + wm * 64 + b * 16 + lr;
+        if (m >= p.M) continue;
+        const float bias_m = (flags & VCX_GEMM_BIAS_M) ? p.bias[m] : 0.f;
+        const float* radd = (flags & VCX_GEMM_ROWADD) ? p.rowadd + (int64_t)(m / p.rowadd_div) * p.N : nullptr;
+        if (GEGLU) {
+#pragma unroll
+            for (int a = 0; a < NFRAG / 2; ++a) {
+                const int nx = tile_n * BN + wn * (BN / 2) + a * 16 + lg * 4;  // packed-space column of x
+                const int ng = nx + 32;                                        // its gate
+                const int j = tile_n * (BN / 2) + wn * (BN / 4) + a * 16 + lg * 4;  // output column
+                if (nx + 4 > p.N) continue;
+                half_t o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float xv = acc[a][b][r] * p.alpha, gv = acc[a + NFRAG / 2][b][r] * p.alpha;
+                    if (flags & VCX_GEMM_BIAS_N) { xv += p.bias[nx + r]; gv += p.bias[ng + r]; }
+                    o[r] = (half_t)(xv * gelu_erf(gv));
+                }
+                half_t* dst = reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + j;
+                *reinterpret_cast<h4*>(dst) = h4{o[0], o[1], o[2], o[3]};
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < NFRAG; ++a) {
+                const int n0 = tile_n * BN + wn * (BN / 2) + a * 16 + lg * 4;
+                if (n0 >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + bias_m;
+                const bool full = (n0 + 4 <= p.N);
+                if (full) {
+                    if (flags & VCX_GEMM_BIAS_N) {
+                        const f4 bv = *reinterpret_cast<const f4*>(p.bias + n0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+                    }
+                    if (radd) {
+                        const f4 rv = *reinterpret_cast<const f4*>(radd + n0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                    }
+                    if (flags & VCX_GEMM_RESIDUAL) {
+                        const h4 rr = *reinterpret_cast<const h4*>(p.R + (int64_t)m * p.ldr + n0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                    }
+                    if (OUT_F32) {
+                        float* dst = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n0;
+                        *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        half_t* dst = reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n0;
+                        *reinterpret_cast<h4*>(dst) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    }
+                } else {
+                    for (int r = 0; r < 4 && n0 + r < p.N; ++r) {
+                        float x = v[r];
+                        if (flags & VCX_GEMM_BIAS_N) x += p.bias[n0 + r];
+                        if (radd) x += radd[n0 + r];
+                        if (flags & VCX_GEMM_RESIDUAL) x += (float)p.R[(int64_t)m * p.ldr + n0 + r];
+                        if (OUT_F32)
+                            reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n0 + r] = x;
+                        else
+                            reinterpret_cast<half_t*>(p.C)[(int64_t)m * p.ldc + n0 + r] = (half_t)x;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
+int launch(const GemmArgs& a, hipStream_t s) {
+    constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+    static bool attr_set = false;
+    auto kern = gemm_kernel<BN, CONV, GEGLU, OUT_F32>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) {
+            vcx_set_error("vcx_gemm_f16: cannot reserve %zu bytes of LDS", smem);
+            return VCX_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const int nb = a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(NTHREADS), smem, s, a);
+    return vcx_check_launch("vcx_gemm_f16");
+}
+
+template <int BN>
+int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) {
+    if (geglu) return conv ? launch<BN, true, true, false>(a, s) : launch<BN, false, true, false>(a, s);
+    if (f32) return conv ? launch<BN, true, false, true>(a, s) : launch<BN, false, false, true>(a, s);
+    return conv ? launch<BN, true, false, false>(a, s) : launch<BN, false, false, false>(a, s);
+}
+
+}  // namespace
+
+extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
+    VCX_REQUIRE(d != nullptr, "vcx_gemm_f16: null descriptor");
+    VCX_REQUIRE(d->A && d->W && d->C, "vcx_gemm_f16: null A/W/C");
+    VCX_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "vcx_gemm_f16: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+    VCX_REQUIRE(d->K % 8 == 0 && d->ldw % 8 == 0 && d->lda % 8 == 0,
+                "vcx_gemm_f16: K (%d), ldw (%d), lda (%lld) must be multiples of 8", d->K, d->ldw, (long long)d->lda);
+    VCX_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->W & 15) == 0 && ((uintptr_t)d->C & 15) == 0,
+                "vcx_gemm_f16: A/W/C must be 16-byte aligned");
+    const int flags = d->flags;
+    VCX_REQUIRE(!(flags & (VCX_GEMM_BIAS_N | VCX_GEMM_BIAS_M)) || d->bias, "vcx_gemm_f16: bias flag without bias");
+    VCX_REQUIRE(!(flags & VCX_GEMM_ROWADD) || (d->rowadd && d->rowadd_div > 0), "vcx_gemm_f16: bad rowadd");
+    VCX_REQUIRE(!(flags & VCX_GEMM_RESIDUAL) || d->residual, "vcx_gemm_f16: residual flag without pointer");
+    const bool conv = d->mode == 1;
+    const bool geglu = flags & VCX_GEMM_GEGLU;
+    const bool f32 = flags & VCX_GEMM_OUT_F32;
+    VCX_REQUIRE(d->mode == 0 || d->mode == 1, "vcx_gemm_f16: unknown mode %d", d->mode);
+    VCX_REQUIRE(!(geglu && (f32 || (flags & (VCX_GEMM_ROWADD | VCX_GEMM_RESIDUAL | VCX_GEMM_BIAS_M)))),
+                "vcx_gemm_f16: GEGLU combines only with BIAS_N");
+    VCX_REQUIRE(!geglu || d->N % 64 == 0, "vcx_gemm_f16: GEGLU needs N %% 64 == 0 (N=%d)", d->N);
+    if (conv) {
+        VCX_REQUIRE(d->cin > 0 && d->cin % 8 == 0 && d->kh > 0 && d->kw > 0 && d->K == d->kh * d->kw * d->cin,
+                    "vcx_gemm_f16: conv needs cin %% 8 == 0 and K == kh*kw*cin (cin=%d kh=%d kw=%d K=%d)", d->cin,
+                    d->kh, d->kw, d->K);
+        VCX_REQUIRE(d->out_h > 0 && d->out_w > 0 && d->in_h > 0 && d->in_w > 0 && d->stride > 0 &&
+                        (d->ups == 0 || d->ups == 1) && d->M % (d->out_h * d->out_w) == 0,
+                    "vcx_gemm_f16: bad conv geometry");
+    }
+    // vector epilogue alignment
+    if (!geglu) {
+        VCX_REQUIRE(d->N < 4 || d->N % 4 != 0 || d->ldc % 4 == 0, "vcx_gemm_f16: ldc must be a multiple of 4");
+        if (flags & VCX_GEMM_RESIDUAL)
+            VCX_REQUIRE(d->ldr % 4 == 0 && ((uintptr_t)d->residual & 7) == 0, "vcx_gemm_f16: residual alignment");
+        if ((flags & VCX_GEMM_BIAS_N) && d->N >= 4) VCX_REQUIRE(((uintptr_t)d->bias & 15) == 0, "vcx_gemm_f16: bias alignment");
+        if (flags & VCX_GEMM_ROWADD) VCX_REQUIRE(((uintptr_t)d->rowadd & 15) == 0 && d->N % 4 == 0, "vcx_gemm_f16: rowadd alignment");
+    } else {
+        VCX_REQUIRE(d->ldc % 4 == 0, "vcx_gemm_f16: ldc must be a multiple of 4");
+    }
+
+    GemmArgs a;
+    a.A = (const half_t*)d->A;
+    a.W = (const half_t*)d->W;
+    a.C = d->C;
+    a.bias = d->bias;
+    a.rowadd = d->rowadd;
+    a.R = (const half_t*)d->residual;
+    a.lda = d->lda;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.ldw = d->ldw; a.ldc = d->ldc; a.ldr = d->ldr;
+    a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w;
+    a.cin = d->cin; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.ups = d->ups;
+    a.rowadd_div = d->rowadd_div > 0 ? d->rowadd_div : 1;
+    a.flags = flags;
+    a.alpha = d->alpha;
+    const bool use160 = !geglu && (d->N % 160 == 0);
+    const int bn = use160 ? 160 : 128;
+    a.tiles_m = (d->M + BM - 1) / BM;
+    a.tiles_n = (d->N + bn - 1) / bn;
+    hipStream_t s = (hipStream_t)stream;
+    const double flops = 2.0 * d->M * (double)d->N * d->K;
+    const double bytes = 2.0 * ((double)d->M * d->K / (conv ? d->kh * d->kw : 1) + (double)d->N * d->K + (double)d->M * d->N);
+    VcxProfScope prof(VCX_FAM_GEMM, s, flops, bytes);
+    return use160 ? dispatch<160>(a, conv, geglu, f32, s) : dispatch<128>(a, conv, geglu, f32, s);
+}

@@ -1,0 +1,48 @@
+// Shared device/host helpers for libvcx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/vcx.h"
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// ---- error plumbing (api.hip) ----
+void vcx_set_error(const char* fmt, ...);
+int vcx_check_launch(const char* what);
+
+#define VCX_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            vcx_set_error(__VA_ARGS__);   \
+            return VCX_EINVAL;            \
+        }                                 \
+    } while (0)
+
+// ---- profiling (api.hip) ----
+enum { VCX_FAM_GEMM = 0, VCX_FAM_FLASH = 1, VCX_FAM_TATTN = 2, VCX_FAM_GN = 3, VCX_FAM_LN = 4, VCX_FAM_ELT = 5 };
+struct VcxProfScope {
+    int rec;
+    hipStream_t s;
+    VcxProfScope(int family, hipStream_t stream, double flops, double bytes);
+    ~VcxProfScope();
+};
+
+// ---- device helpers ----
+__device__ __forceinline__ float vcx_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float vcx_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float vcx_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

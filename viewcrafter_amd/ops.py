@@ -1,0 +1,249 @@
+"""Thin torch-tensor front end of the libvcx C ABI.
+
+Tensors are only used for device memory and streams; every function below launches one (or two)
+hand-written gfx950 kernels through ctypes.  Activations are fp16 channels-last, i.e. a video
+latent is [B, T, H, W, C] and all token matrices are [rows, C] views of it.
+"""
+import ctypes
+import torch
+
+from ._lib import (GEMM_BIAS_M, GEMM_BIAS_N, GEMM_GEGLU, GEMM_OUT_F32, GEMM_RESIDUAL, GEMM_ROWADD, PROF_FAMILIES,
+                   GemmDesc, VcxError, check, lib)
+
+_f16 = torch.float16
+_f32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def require_gpu():
+    """Raise unless a gfx950 device and the built library are available (no fallback path)."""
+    if not torch.cuda.is_available():
+        raise VcxError("viewcrafter_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                       "and there is no CPU fallback")
+    lib()
+
+
+# ------------------------------------------------------------------------------------------
+# GEMM / convolution
+# ------------------------------------------------------------------------------------------
+def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, residual=None, ldr=None, rowadd=None,
+         rowadd_div=0, geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None):
+    """out[M, N] = epilogue(alpha * X W^T); see include/vcx.h.  `conv` = dict(in_h, in_w, out_h, out_w, cin, kh, kw,
+    stride, pad_h, pad_w, ups) switches X to the im2col gather of a channels-last image."""
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=_f32 if out_f32 else _f16, device=a.device)
+        ldc = n_out
+    elif ldc is None:
+        ldc = out.stride(0)
+    d = GemmDesc()
+    d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    flags = 0
+    if bias is not None:
+        d.bias = bias.data_ptr()
+        flags |= GEMM_BIAS_M if bias_m else GEMM_BIAS_N
+    if rowadd is not None:
+        d.rowadd = rowadd.data_ptr()
+        d.rowadd_div = rowadd_div
+        flags |= GEMM_ROWADD
+    if residual is not None:
+        d.residual = residual.data_ptr()
+        d.ldr = ldr if ldr is not None else residual.stride(0)
+        flags |= GEMM_RESIDUAL
+    if geglu:
+        flags |= GEMM_GEGLU
+    if out_f32:
+        flags |= GEMM_OUT_F32
+    d.lda, d.M, d.N, d.K = lda, M, N, K
+    d.ldw = ldw if ldw is not None else K
+    d.ldc = ldc
+    if conv is not None:
+        d.mode = 1
+        d.in_h, d.in_w, d.out_h, d.out_w = conv["in_h"], conv["in_w"], conv["out_h"], conv["out_w"]
+        d.cin, d.kh, d.kw = conv["cin"], conv["kh"], conv["kw"]
+        d.stride, d.pad_h, d.pad_w, d.ups = conv["stride"], conv["pad_h"], conv["pad_w"], conv.get("ups", 0)
+    d.flags = flags
+    d.alpha = alpha
+    check(lib().vcx_gemm_f16(ctypes.byref(d), _stream()), "vcx_gemm_f16")
+    return out
+
+
+def linear(x, w, bias=None, **kw):
+    """x [rows, K] (row stride may exceed K) times w [N, K]^T."""
+    rows, K = x.shape
+    return gemm(x, w, M=rows, N=w.shape[0], K=K, lda=x.stride(0), bias=bias, **kw)
+
+
+def conv2d(x, w, bias, *, kh, kw, stride=1, pad_h=None, pad_w=None, ups=0, out_hw=None, **kwargs):
+    """x [n, H, W, Cin] channels-last fp16, w [Cout, kh*kw*Cin] (tap-major).  Returns [n, Ho, Wo, Cout]."""
+    n, H, W, cin = x.shape
+    if pad_h is None:
+        pad_h = kh // 2
+    if pad_w is None:
+        pad_w = kw // 2
+    if out_hw is None:
+        He, We = H << ups, W << ups
+        out_hw = ((He + 2 * pad_h - kh) // stride + 1, (We + 2 * pad_w - kw) // stride + 1)
+    Ho, Wo = out_hw
+    cout = w.shape[0]
+    geom = dict(in_h=H, in_w=W, out_h=Ho, out_w=Wo, cin=cin, kh=kh, kw=kw, stride=stride, pad_h=pad_h, pad_w=pad_w,
+                ups=ups)
+    out = gemm(x, w, M=n * Ho * Wo, N=cout, K=kh * kw * cin, lda=x.stride(2), bias=bias, conv=geom, **kwargs)
+    return out.view(n, Ho, Wo, -1)
+
+
+def temporal_conv3(x, w, bias, **kwargs):
+    """x [B, T, P, C]; (3,1,1) convolution along T with zero padding; w [Cout, 3*Cin] (tap-major)."""
+    B, T, P, C = x.shape
+    geom = dict(in_h=T, in_w=P, out_h=T, out_w=P, cin=C, kh=3, kw=1, stride=1, pad_h=1, pad_w=0, ups=0)
+    out = gemm(x, w, M=B * T * P, N=w.shape[0], K=3 * C, lda=x.stride(2), bias=bias, conv=geom, **kwargs)
+    return out.view(B, T, P, -1)
+
+
+# ------------------------------------------------------------------------------------------
+# normalisation
+# ------------------------------------------------------------------------------------------
+def group_norm(x, gamma, beta, eps, silu, groups=32, out=None):
+    """x [n_outer, pixels, C] fp16 (contiguous).  Statistics over (pixels, C/groups)."""
+    n_outer, pixels, C = x.shape
+    stats = torch.empty((n_outer, groups, 2), dtype=_f32, device=x.device)
+    L = lib()
+    s = _stream()
+    check(L.vcx_groupnorm_stats_f16(x.data_ptr(), stats.data_ptr(), n_outer, pixels, C, groups, s), "groupnorm_stats")
+    if out is None:
+        out = torch.empty_like(x)
+    check(L.vcx_groupnorm_apply_f16(x.data_ptr(), out.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                    n_outer, pixels, C, groups, eps, 1 if silu else 0, s), "groupnorm_apply")
+    return out
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    rows, C = x.shape
+    out = torch.empty_like(x)
+    check(lib().vcx_layernorm_f16(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, eps,
+                                  _stream()), "layernorm")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------
+def flash_attn(q, k, vt, out, *, n_groups, heads, nq, nk, kv_rows, kv_div, ldq, ldk, ldvt, ldo, scale, accumulate=False):
+    check(lib().vcx_attn_flash_d64_f16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), n_groups, heads, nq,
+                                       nk, kv_rows, kv_div, ldq, ldk, ldvt, ldo, scale, 1 if accumulate else 0,
+                                       _stream()), "attn_flash_d64")
+    return out
+
+
+def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale):
+    check(lib().vcx_attn_temporal_d64_f16(qkv.data_ptr(), out.data_ptr(), B, T, P, heads, ld, k_off, v_off, ldo, scale,
+                                          _stream()), "attn_temporal_d64")
+    return out
+
+
+def softmax_rows_(x, n=None):
+    rows = x.shape[0]
+    check(lib().vcx_softmax_rows_f16(x.data_ptr(), rows, n if n is not None else x.shape[1], x.stride(0), _stream()),
+          "softmax_rows")
+    return x
+
+
+# ------------------------------------------------------------------------------------------
+# element-wise / layout
+# ------------------------------------------------------------------------------------------
+def silu_f32(x):
+    out = torch.empty_like(x)
+    check(lib().vcx_silu_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "silu")
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=_f32, device=t.device)
+    check(lib().vcx_timestep_embedding_f32(t.data_ptr(), out.data_ptr(), t.shape[0], dim, max_period, _stream()),
+          "timestep_embedding")
+    return out
+
+
+def to_f16(x):
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=_f16, device=x.device)
+    check(lib().vcx_cast_f32_to_f16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "cast_f32_to_f16")
+    return out
+
+
+def to_f32(x):
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=_f32, device=x.device)
+    check(lib().vcx_cast_f16_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "cast_f16_to_f32")
+    return out
+
+
+def copy2d(src, dst, rows, cols, lds, ldd):
+    check(lib().vcx_copy2d_f16(src.data_ptr(), dst.data_ptr(), rows, cols, lds, ldd, _stream()), "copy2d")
+
+
+def concat_channels(a, b):
+    """[rows, Ca] ++ [rows, Cb] -> [rows, Ca+Cb] (torch.cat(dim=1) of the reference's NCHW tensors)."""
+    rows, ca = a.shape
+    cb = b.shape[1]
+    out = torch.empty((rows, ca + cb), dtype=_f16, device=a.device)
+    copy2d(a, out, rows, ca, a.stride(0), ca + cb)
+    copy2d(b, out[:, ca:], rows, cb, b.stride(0), ca + cb)
+    return out
+
+
+def ncthw_to_nthwc(src, dst, c_off=0, scale=1.0):
+    """src fp32 [B, C, T, H, W] -> dst fp16 [B, T, H, W, ldc][..., c_off:c_off+C]."""
+    B, C, T, H, W = src.shape
+    src = src.contiguous()
+    check(lib().vcx_ncthw_f32_to_nthwc_f16(src.data_ptr(), dst.data_ptr(), B, C, T, H * W, dst.shape[-1], c_off, scale,
+                                           _stream()), "ncthw_to_nthwc")
+    return dst
+
+
+def nthwc_to_ncthw(src, C=None):
+    """src [B, T, H, W, ldc] (fp16 or fp32) -> fp32 [B, C, T, H, W]."""
+    B, T, H, W, ldc = src.shape
+    C = ldc if C is None else C
+    out = torch.empty((B, C, T, H, W), dtype=_f32, device=src.device)
+    check(lib().vcx_nthwc_to_ncthw_f32(src.data_ptr(), out.data_ptr(), B, C, T, H * W, ldc,
+                                       1 if src.dtype == _f32 else 0, _stream()), "nthwc_to_ncthw")
+    return out
+
+
+def ddim_step(x, v_cond, v_uncond, noise, coef, ws=None):
+    """One DDIM update on fp32 [B, ...] tensors; coef = 8 host floats (see include/vcx.h)."""
+    B = x.shape[0]
+    n = x.numel() // B
+    x_prev = torch.empty_like(x)
+    pred_x0 = torch.empty_like(x)
+    if ws is None:
+        ws = torch.empty((4 * B,), dtype=torch.float64, device=x.device)
+    c = (ctypes.c_float * 8)(*[float(v) for v in coef])
+    check(lib().vcx_ddim_step_f32(x.data_ptr(), v_cond.data_ptr(), _ptr(v_uncond), _ptr(noise), x_prev.data_ptr(),
+                                  pred_x0.data_ptr(), ws.data_ptr(), B, n, c, _stream()), "ddim_step")
+    return x_prev, pred_x0
+
+
+# ------------------------------------------------------------------------------------------
+# profiling
+# ------------------------------------------------------------------------------------------
+def profile_begin(max_records=1 << 16):
+    check(lib().vcx_profile_begin(max_records), "profile_begin")
+
+
+def profile_end():
+    buf = (ctypes.c_double * (4 * len(PROF_FAMILIES)))()
+    check(lib().vcx_profile_end(buf), "profile_end")
+    out = {}
+    for i, name in enumerate(PROF_FAMILIES):
+        out[name] = dict(launches=int(buf[4 * i]), ms=buf[4 * i + 1], flops=buf[4 * i + 2], bytes=buf[4 * i + 3])
+    return out

@@ -1,0 +1,35 @@
+"""One-time repacking of reference-layout parameters into the layouts the gfx950 kernels read.
+
+Reference layouts (binding because checkpoints are loaded with strict=True):
+conv weights [Cout, Cin, kh, kw] / [Cout, Cin, 3, 1, 1] / [Cout, Cin, 1], linear [out, in].
+Kernel layouts: fp16 [N_out][K] with K ordered (tap, cin); GEGLU rows interleaved in blocks of 32.
+"""
+import torch
+
+
+def pack_conv(w):
+    """[Cout, Cin, *kernel] -> [Cout, taps*Cin] with the tap index slow and Cin fast (im2col order of the
+    channels-last gather in csrc/gemm.hip)."""
+    cout, cin = w.shape[0], w.shape[1]
+    wk = w.reshape(cout, cin, -1)            # [Cout, Cin, taps]
+    return wk.permute(0, 2, 1).reshape(cout, -1).contiguous()
+
+
+def pad_cin(w, cin_to):
+    """Zero-pad the input-channel dim of a conv weight (e.g. the VAE's 4-channel conv_in to 8)."""
+    if w.shape[1] == cin_to:
+        return w
+    out = w.new_zeros((w.shape[0], cin_to) + tuple(w.shape[2:]))
+    out[:, :w.shape[1]] = w
+    return out
+
+
+def pack_geglu(w, b):
+    """GEGLU.proj (lvdm/modules/attention.py:415-422) has rows [0, D) = x and [D, 2D) = gate.  Interleave them in
+    blocks of 32 so that x_j and gate_j land in the same lane of one wave's accumulators (VCX_GEMM_GEGLU)."""
+    two_d = w.shape[0]
+    d = two_d // 2
+    assert d % 32 == 0, "GEGLU inner dim must be a multiple of 32"
+    idx = torch.arange(d, device=w.device).view(-1, 32)
+    perm = torch.cat([idx, idx + d], dim=1).reshape(-1)     # [x0..x31, g0..g31, x32.., ...]
+    return w[perm].contiguous(), (b[perm].contiguous() if b is not None else None)
