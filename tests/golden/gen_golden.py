@@ -1,0 +1,210 @@
+"""Generate the golden fixtures in this directory by running the REFERENCE code itself.
+
+Run in the build container only (needs /root/reference; the GPU box does not have it):
+    python tests/golden/gen_golden.py
+The reference (Drexubery/ViewCrafter) is imported unmodified with three module stubs (cv2,
+pytorch_lightning, torchvision are absent here and only needed for training/IO), built on tiny
+hyper-parameters, loaded with the deterministic synthetic weights of oracle/weights.py and run in fp32 on CPU.
+Inputs are regenerated from their names (oracle.weights.synth_input), so the fixtures hold outputs only.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("VCX_REFERENCE", "/root/reference")
+
+from oracle.weights import synth_input, synth_state_dict  # noqa: E402
+from tests.tiny_config import TINY_DDCONFIG, TINY_UNET, tiny_model_params  # noqa: E402
+
+
+class AttrDict(dict):
+    """Stand-in for OmegaConf: supports cfg['k'], cfg.k, 'k' in cfg, cfg.get."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    @staticmethod
+    def wrap(o):
+        if isinstance(o, dict):
+            return AttrDict({k: AttrDict.wrap(v) for k, v in o.items()})
+        if isinstance(o, (list, tuple)):
+            return [AttrDict.wrap(v) for v in o]
+        return o
+
+
+def import_reference():
+    """Stub the three absent third-party modules and put the reference on sys.path."""
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    if "pytorch_lightning" not in sys.modules:
+        pl = types.ModuleType("pytorch_lightning")
+
+        class LightningModule(torch.nn.Module):
+            @property
+            def device(self):
+                try:
+                    return next(self.parameters()).device
+                except StopIteration:
+                    return torch.device("cpu")
+        pl.LightningModule = LightningModule
+        plu = types.ModuleType("pytorch_lightning.utilities")
+        plu.rank_zero_only = lambda f: f
+        pl.utilities = plu
+        sys.modules["pytorch_lightning"] = pl
+        sys.modules["pytorch_lightning.utilities"] = plu
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tvu = types.ModuleType("torchvision.utils")
+        tvu.make_grid = lambda *a, **k: None
+        tv.utils = tvu
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.utils"] = tvu
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+SCHEDULE_BUFFERS = ("betas", "alphas", "sqrt_", "log_one", "posterior", "scale_arr", "lvlb", "logvar")
+
+
+def load_synth(module, seed=0, skip=()):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=seed, skip=skip)
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    assert not unexpected
+    return shapes
+
+
+def gen_schedules(out):
+    from lvdm.models import utils_diffusion as ud
+    betas = ud.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    out["betas_linear"] = betas
+    out["betas_zero_snr"] = ud.rescale_zero_terminal_snr(betas)
+    for method, n in (("uniform_trailing", 50), ("uniform_trailing", 5), ("uniform_trailing", 10), ("uniform", 50), ("quad", 20)):
+        out[f"ddim_timesteps_{method}_{n}"] = np.asarray(ud.make_ddim_timesteps(method, n, 1000, verbose=False))
+    acp = torch.tensor(np.cumprod(1.0 - out["betas_zero_snr"]), dtype=torch.float32)
+    ts = out["ddim_timesteps_uniform_trailing_50"]
+    for eta in (0.0, 1.0):
+        s, a, ap = ud.make_ddim_sampling_parameters(acp, ts, eta, verbose=False)
+        out[f"ddim_sigmas_eta{eta}"] = np.asarray(s, dtype=np.float64)
+        out[f"ddim_alphas_eta{eta}"] = np.asarray(a, dtype=np.float64)
+        out[f"ddim_alphas_prev_eta{eta}"] = np.asarray(ap, dtype=np.float64)
+    t = torch.tensor([0, 19, 500, 999])
+    out["timestep_embedding_320"] = ud.timestep_embedding(t, 320).numpy()
+    out["timestep_embedding_65"] = ud.timestep_embedding(t, 65).numpy()
+    a = synth_input("cfg_a", (2, 4, 3, 8, 8))
+    b = synth_input("cfg_b", (2, 4, 3, 8, 8))
+    out["rescale_noise_cfg"] = ud.rescale_noise_cfg(a, b, guidance_rescale=0.7).numpy()
+
+
+def gen_unet(out):
+    from lvdm.modules.networks.openaimodel3d import UNetModel
+    torch.manual_seed(0)
+    unet = UNetModel(**TINY_UNET).eval()
+    shapes = load_synth(unet)
+    out["unet_keys"] = np.array(sorted(shapes.keys()))
+    out["unet_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    cd = TINY_UNET["context_dim"]
+    with torch.no_grad():
+        for tag, (b, t, h, w, L) in {"perframe": (1, 4, 32, 16, 77 + 4 * 16), "shared": (2, 3, 16, 32, 77 + 40)}.items():
+            x = synth_input(f"unet_x_{tag}", (b, 8, t, h, w))
+            ts = torch.tensor([999, 399][:b])
+            ctx = synth_input(f"unet_ctx_{tag}", (b, L, cd))
+            fs = torch.tensor([10, 3][:b])
+            y = unet(x, ts, context=ctx, fs=fs)
+            out[f"unet_out_{tag}"] = y.numpy()
+            print("unet", tag, tuple(y.shape), float(y.abs().mean()))
+
+
+def gen_vae(out):
+    from lvdm.models.autoencoder import AutoencoderKL
+    torch.manual_seed(0)
+    vae = AutoencoderKL(ddconfig=TINY_DDCONFIG, lossconfig=AttrDict(target="torch.nn.Identity"), embed_dim=4).eval()
+    shapes = load_synth(vae)
+    out["vae_keys"] = np.array(sorted(shapes.keys()))
+    out["vae_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    with torch.no_grad():
+        z = synth_input("vae_z", (2, 4, 8, 16))
+        out["vae_decode"] = vae.decode(z).numpy()
+        img = synth_input("vae_img", (1, 3, 64, 32), scale=0.5)
+        post = vae.encode(img)
+        out["vae_encode_moments"] = post.parameters.numpy()
+        out["vae_encode_mode"] = post.mode().numpy()
+        print("vae", out["vae_decode"].shape, float(np.abs(out["vae_decode"]).mean()))
+
+
+def gen_ddim(out):
+    """Whole hot path through the reference classes: VIPLatentDiffusion + DDIMSampler + decode_first_stage."""
+    from lvdm.models.ddpm3d import VIPLatentDiffusion
+    from lvdm.models.samplers.ddim import DDIMSampler
+    import lvdm.models.samplers.ddim as ddim_mod
+
+    # DDIMSampler.register_buffer hard-codes .to("cuda") (ddim.py:18-22): CPU patch, test side only.
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+    DDIMSampler.register_buffer = register_buffer
+
+    params = AttrDict.wrap(tiny_model_params("lvdm.modules.networks.openaimodel3d.UNetModel",
+                                             "lvdm.models.autoencoder.AutoencoderKL"))
+    torch.manual_seed(0)
+    model = VIPLatentDiffusion(**params).eval()
+    shapes = load_synth(model, skip=SCHEDULE_BUFFERS)
+    out["model_keys"] = np.array(sorted(shapes.keys()))
+    out["model_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                 "scale_arr"):
+        out[f"model_{name}"] = getattr(model, name).numpy()
+    cd = TINY_UNET["context_dim"]
+    b, t, h, w = 1, 4, 32, 16
+    cond = {"c_crossattn": [synth_input("ddim_ctx", (b, 77 + 16 * t, cd))], "c_concat": [synth_input("ddim_cat", (b, 4, t, h, w), scale=0.8)]}
+    uc = {"c_crossattn": [synth_input("ddim_uctx", (b, 77 + 16 * t, cd))], "c_concat": cond["c_concat"]}
+    x_T = synth_input("ddim_xT", (b, 4, t, h, w))
+    fs = torch.tensor([10] * b)
+    with torch.no_grad():
+        v = model.apply_model(x_T, torch.tensor([999]), cond, fs=fs)
+        out["apply_model"] = v.numpy()
+        for eta in (0.0, 1.0):
+            counter = [0]
+
+            def fake_noise(shape, device, repeat=False):
+                counter[0] += 1
+                return synth_input(f"ddim_noise_{counter[0]}", shape)
+            ddim_mod.noise_like = fake_noise
+            sampler = DDIMSampler(model)
+            samples, inter = sampler.sample(S=5, conditioning=cond, batch_size=b, shape=[4, t, h, w], verbose=False,
+                                            unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=eta,
+                                            cfg_img=None, mask=None, x0=None, fs=fs, timestep_spacing="uniform_trailing",
+                                            guidance_rescale=0.7, x_T=x_T, log_every_t=1,
+                                            unconditional_conditioning_img_nonetext=None)
+            out[f"ddim_samples_eta{eta}"] = samples.numpy()
+            out[f"ddim_pred_x0_eta{eta}"] = torch.stack(inter["pred_x0"][1:]).numpy()
+            if eta == 0.0:
+                out["ddim_timesteps"] = np.asarray(sampler.ddim_timesteps)
+                out["ddim_scale_arr"] = sampler.ddim_scale_arr.numpy()
+                out["ddim_scale_arr_prev"] = sampler.ddim_scale_arr_prev.numpy()
+                dec = model.decode_first_stage(samples)
+                out["decode_first_stage_sub4"] = dec.numpy()[..., ::4, ::4]  # VAE decode is pinned in full by vae_tiny.npz
+            print("ddim eta", eta, float(samples.abs().mean()))
+
+
+def main():
+    import_reference()
+    torch.set_num_threads(8)
+    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim)):
+        out = {}
+        fn(out)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

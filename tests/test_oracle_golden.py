@@ -1,0 +1,128 @@
+"""Pin the oracle (oracle/lvdm_oracle.py) against golden vectors produced by the reference code itself
+(tests/golden/gen_golden.py, run in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lvdm_oracle as O
+from oracle.weights import synth_input, synth_state_dict
+from tests.tiny_config import TINY_DDCONFIG, TINY_UNET
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def sd_from_fixture(keys, shapes, prefix=""):
+    shp = {str(k): eval(str(s)) for k, s in zip(keys, shapes)}
+    return synth_state_dict({prefix + k: v for k, v in shp.items()}), shp
+
+
+SCHEDULE_BUFFERS = ("betas", "alphas", "sqrt_", "log_one", "posterior", "scale_arr", "lvlb", "logvar")
+
+
+def split_model_state_dict(keys, shapes):
+    """Full-model fixture keys -> (UNet-relative, VAE-relative) synthetic state dicts.  Weights are synthesised from
+    the FULL key ('model.diffusion_model.…'), exactly as gen_golden.py loaded them into the reference model."""
+    shp = {str(k): eval(str(s)) for k, s in zip(keys, shapes)}
+    sd = synth_state_dict(shp, skip=SCHEDULE_BUFFERS)
+    up, vp = "model.diffusion_model.", "first_stage_model."
+    return ({k[len(up):]: v for k, v in sd.items() if k.startswith(up)},
+            {k[len(vp):]: v for k, v in sd.items() if k.startswith(vp)})
+
+
+def max_rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_schedules_match_reference():
+    g = load("schedules")
+    betas = O.make_beta_schedule_linear(1000, 0.00085, 0.012)
+    assert np.array_equal(betas, g["betas_linear"])
+    assert np.allclose(O.rescale_zero_terminal_snr(betas), g["betas_zero_snr"], rtol=0, atol=1e-15)
+    for method, n in (("uniform_trailing", 50), ("uniform_trailing", 5), ("uniform_trailing", 10), ("uniform", 50), ("quad", 20)):
+        assert np.array_equal(O.make_ddim_timesteps(method, n, 1000), g[f"ddim_timesteps_{method}_{n}"]), (method, n)
+    assert list(O.make_ddim_timesteps("uniform_trailing", 5, 1000)) == [199, 399, 599, 799, 999]
+    acp = O.diffusion_tables()["alphas_cumprod"]
+    ts = O.make_ddim_timesteps("uniform_trailing", 50, 1000)
+    for eta in (0.0, 1.0):
+        s, a, ap = O.make_ddim_sampling_parameters(acp, ts, eta)
+        assert np.allclose(np.asarray(s, dtype=np.float64), g[f"ddim_sigmas_eta{eta}"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(np.asarray(a, dtype=np.float64), g[f"ddim_alphas_eta{eta}"], rtol=1e-7)
+        assert np.allclose(np.asarray(ap, dtype=np.float64), g[f"ddim_alphas_prev_eta{eta}"], rtol=1e-7)
+    t = torch.tensor([0, 19, 500, 999])
+    assert np.allclose(O.timestep_embedding(t, 320).numpy(), g["timestep_embedding_320"], atol=1e-6)
+    assert np.allclose(O.timestep_embedding(t, 65).numpy(), g["timestep_embedding_65"], atol=1e-6)
+    a, b = synth_input("cfg_a", (2, 4, 3, 8, 8)), synth_input("cfg_b", (2, 4, 3, 8, 8))
+    assert np.allclose(O.rescale_noise_cfg(a, b, 0.7).numpy(), g["rescale_noise_cfg"], atol=1e-6)
+
+
+def test_diffusion_tables_match_reference_model_buffers():
+    g = load("ddim_tiny")
+    tb = O.diffusion_tables()
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
+        assert np.array_equal(tb[k].numpy(), g["model_" + k]), k
+    assert float(tb["alphas_cumprod"][-1]) == 0.0   # zero terminal SNR
+    assert np.array_equal(O.dynamic_rescale_table(1000, 0.3, 400).numpy(), g["model_scale_arr"])
+
+
+@pytest.mark.parametrize("tag,shape,L", [("perframe", (1, 4, 32, 16), 77 + 64), ("shared", (2, 3, 16, 32), 77 + 40)])
+def test_unet_forward_matches_reference(tag, shape, L):
+    g = load("unet_tiny")
+    sd, _ = sd_from_fixture(g["unet_keys"], g["unet_shapes"])
+    b, t, h, w = shape
+    x = synth_input(f"unet_x_{tag}", (b, 8, t, h, w))
+    ctx = synth_input(f"unet_ctx_{tag}", (b, L, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = O.unet_forward(sd, TINY_UNET, x, torch.tensor([999, 399][:b]), ctx, torch.tensor([10, 3][:b]))
+    assert y.shape == g[f"unet_out_{tag}"].shape
+    assert max_rel(y.numpy(), g[f"unet_out_{tag}"]) < 2e-5
+
+
+def test_vae_matches_reference():
+    g = load("vae_tiny")
+    sd, _ = sd_from_fixture(g["vae_keys"], g["vae_shapes"])
+    with torch.no_grad():
+        dec = O.vae_decode(sd, TINY_DDCONFIG, synth_input("vae_z", (2, 4, 8, 16)))
+        mom = O.vae_encode_moments(sd, TINY_DDCONFIG, synth_input("vae_img", (1, 3, 64, 32), scale=0.5))
+    assert max_rel(dec.numpy(), g["vae_decode"]) < 2e-5
+    assert max_rel(mom.numpy(), g["vae_encode_moments"]) < 2e-5
+    assert max_rel(mom[:, :4].numpy(), g["vae_encode_mode"]) < 2e-5
+
+
+@pytest.mark.parametrize("eta", [0.0, 1.0])
+def test_ddim_trajectory_matches_reference(eta):
+    """5-step DDIM (CFG 7.5, rescale 0.7, uniform_trailing, dynamic rescale, v-pred) + decode_first_stage."""
+    g = load("ddim_tiny")
+    unet_sd, vae_sd = split_model_state_dict(g["model_keys"], g["model_shapes"])
+    b, t, h, w = 1, 4, 32, 16
+    cd = TINY_UNET["context_dim"]
+    ctx, uctx = synth_input("ddim_ctx", (b, 77 + 16 * t, cd)), synth_input("ddim_uctx", (b, 77 + 16 * t, cd))
+    cat = synth_input("ddim_cat", (b, 4, t, h, w), scale=0.8)
+    x_T = synth_input("ddim_xT", (b, 4, t, h, w))
+    fs = torch.tensor([10] * b)
+
+    def apply_model(x, ts, c):   # DiffusionWrapper 'hybrid', ddpm3d.py:1437-1443
+        return O.unet_forward(unet_sd, TINY_UNET, torch.cat([x, cat], 1), ts, c, fs)
+
+    counter = [0]
+
+    def noise_fn(shape):
+        counter[0] += 1
+        return synth_input(f"ddim_noise_{counter[0]}", shape)
+
+    with torch.no_grad():
+        v = apply_model(x_T, torch.tensor([999]), ctx)
+        assert max_rel(v.numpy(), g["apply_model"]) < 2e-5
+        x0, preds = O.ddim_sample(apply_model, O.diffusion_tables(), O.dynamic_rescale_table(1000, 0.3, 400), x_T, ctx, uctx,
+                                  steps=5, eta=eta, cfg_scale=7.5, guidance_rescale=0.7, noise_fn=noise_fn)
+        assert max_rel(torch.stack(preds).numpy(), g[f"ddim_pred_x0_eta{eta}"]) < 2e-4
+        assert max_rel(x0.numpy(), g[f"ddim_samples_eta{eta}"]) < 2e-4
+        if eta == 0.0:
+            dec = O.decode_first_stage(vae_sd, TINY_DDCONFIG, torch.from_numpy(g["ddim_samples_eta0.0"]))
+            assert max_rel(dec.numpy()[..., ::4, ::4], g["decode_first_stage_sub4"]) < 2e-5

@@ -1,0 +1,35 @@
+"""Tiny hyper-parameters shared by the golden generator, the oracle tests and the GPU parity tests.
+
+Same graph as configs/inference_pvd_1024.yaml (all block types, both context branches, init_attn, fs conditioning),
+narrower: model_channels 64 (GroupNorm-32 divisibility holds), head dim 64, context dim 128, VAE ch 32.
+"""
+import copy
+
+TINY_UNET = dict(
+    in_channels=8, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+    channel_mult=[1, 2, 4, 4], dropout=0.1, num_head_channels=64, transformer_depth=1, context_dim=128, use_linear=True,
+    use_checkpoint=False, temporal_conv=True, temporal_attention=True, temporal_selfatt_only=True,
+    use_relative_position=False, use_causal_attention=False, temporal_length=16, addition_attention=True,
+    image_cross_attention=True, default_fs=10, fs_condition=True,
+)
+
+TINY_DDCONFIG = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+                     num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+
+
+def tiny_model_params(unet_target, vae_target, base_scale=0.3):
+    """`params` of the model YAML (configs/inference_pvd_1024.yaml:6-110) with the tiny sub-configs and Identity
+    conditioners (the CLIP encoders run once per video and are out of scope)."""
+    ident = {"target": "torch.nn.Identity"}
+    return copy.deepcopy(dict(
+        rescale_betas_zero_snr=True, parameterization="v", linear_start=0.00085, linear_end=0.012, num_timesteps_cond=1,
+        log_every_t=200, timesteps=1000, first_stage_key="video", cond_stage_key="caption", cond_stage_trainable=False,
+        image_proj_model_trainable=True, conditioning_key="hybrid", image_size=[32, 16], channels=4, scale_by_std=False,
+        scale_factor=0.18215, use_ema=False, uncond_prob=0.05, uncond_type="empty_seq", rand_cond_frame=True,
+        use_dynamic_rescale=True, base_scale=base_scale, fps_condition_type="fps", perframe_ae=True, loop_video="Flase",
+        unet_config={"target": unet_target, "params": TINY_UNET},
+        first_stage_config={"target": vae_target,
+                            "params": {"embed_dim": 4, "monitor": "val/rec_loss", "ddconfig": TINY_DDCONFIG,
+                                       "lossconfig": ident}},
+        cond_stage_config=ident, img_cond_stage_config=ident, image_proj_stage_config=ident,
+    ))
