@@ -1,0 +1,315 @@
+"""Transformer blocks of the lvdm UNet on the gfx950 kernels.
+
+Mirrors the classes of the reference's lvdm/modules/attention.py that the ViewCrafter graph instantiates
+(CrossAttention, FeedForward/GEGLU, BasicTransformerBlock, SpatialTransformer, TemporalTransformer) with identical
+constructor arguments and parameter names/shapes, so reference checkpoints load with strict=True.  The parameters are
+held in stock nn.Linear / nn.LayerNorm / nn.GroupNorm containers; `forward` never calls them — it runs the packed
+fp16 copies through libvcx (no PyTorch fallback).
+
+Activations are channels-last fp16.  A spatial transformer sees tokens [(b t h w), C]; a temporal transformer sees the
+SAME row order (Linear/LayerNorm are row-wise, so no '(b t) c h w <-> (b h w) t c' copies are needed — only the
+temporal attention kernel itself walks frames with a stride of h*w rows).
+"""
+import torch
+from torch import nn
+
+from ... import ops
+from ...packing import pack_geglu
+from ..common import default
+
+
+def _f16(t):
+    return t.detach().to(torch.float16).contiguous()
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class PackedModule(nn.Module):
+    """Base for modules that keep kernel-layout copies of their parameters in `self._pk` (built lazily on the first
+    forward, dropped whenever parameters are moved/cast or a state dict is loaded)."""
+
+    def __init__(self):
+        super().__init__()
+        self._pk = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_packed())
+
+    def _drop_packed(self):
+        self._pk = None
+
+    def _apply(self, fn, recurse=True):
+        self._pk = None
+        return super()._apply(fn, recurse)
+
+    def packed(self):
+        if self._pk is None:
+            with torch.no_grad():
+                self._pk = self._pack()
+        return self._pk
+
+    def _pack(self):
+        raise NotImplementedError
+
+
+class CrossAttention(PackedModule):
+    """Reference attention.py:42-209.  Parameter container + packing; the attention itself is launched by the owning
+    transformer (it needs the token geometry).  Relative position / causal masks are not part of the ViewCrafter
+    graph (use_relative_position=false, use_causal_attention=False) and are rejected."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0., relative_position=False,
+                 temporal_length=None, video_length=None, image_cross_attention=False, image_cross_attention_scale=1.0,
+                 image_cross_attention_scale_learnable=False, text_context_len=77):
+        super().__init__()
+        if relative_position:
+            raise NotImplementedError("relative_position attention is not on the ViewCrafter inference path")
+        if image_cross_attention_scale_learnable:
+            raise NotImplementedError("image_cross_attention_scale_learnable is not used by the ViewCrafter configs")
+        if dim_head != 64:
+            raise NotImplementedError(f"libvcx attention kernels are built for head dim 64 (got {dim_head})")
+        inner_dim = dim_head * heads
+        self.is_self = context_dim is None
+        context_dim = default(context_dim, query_dim)
+        self.scale = dim_head ** -0.5
+        self.heads, self.dim_head, self.inner_dim = heads, dim_head, inner_dim
+        self.to_q = nn.Linear(query_dim, inner_dim, bias=False)
+        self.to_k = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
+        self.video_length = video_length
+        self.image_cross_attention = image_cross_attention
+        self.image_cross_attention_scale = image_cross_attention_scale
+        self.text_context_len = text_context_len
+        if image_cross_attention:
+            self.to_k_ip = nn.Linear(context_dim, inner_dim, bias=False)
+            self.to_v_ip = nn.Linear(context_dim, inner_dim, bias=False)
+
+    def _pack(self):
+        pk = dict(wo=_f16(self.to_out[0].weight), bo=_f32(self.to_out[0].bias), wq=_f16(self.to_q.weight),
+                  wk=_f16(self.to_k.weight), wv=_f16(self.to_v.weight))
+        if self.is_self:
+            pk["wqk"] = _f16(torch.cat([self.to_q.weight, self.to_k.weight], 0))                       # spatial
+            pk["wqkv"] = _f16(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0))    # temporal
+        if self.image_cross_attention:
+            pk["wk_ip"], pk["wv_ip"] = _f16(self.to_k_ip.weight), _f16(self.to_v_ip.weight)
+        return pk
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("CrossAttention is driven by SpatialTransformer/TemporalTransformer in this package")
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(PackedModule):
+    """Reference attention.py:425-442 with glu=True: Linear(C, 8C) -> x * gelu(gate) -> Linear(4C, C).  The GEGLU gate
+    is applied inside the first GEMM's epilogue (weights row-interleaved by pack_geglu)."""
+
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.):
+        super().__init__()
+        if not glu:
+            raise NotImplementedError("only the gated (GEGLU) feed-forward is on the ViewCrafter path")
+        inner_dim = int(dim * mult)
+        dim_out = default(dim_out, dim)
+        self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
+
+    def _pack(self):
+        w1, b1 = pack_geglu(self.net[0].proj.weight.detach(), self.net[0].proj.bias.detach())
+        return dict(w1=_f16(w1), b1=_f32(b1), w2=_f16(self.net[2].weight), b2=_f32(self.net[2].bias))
+
+    def run(self, x_norm, residual):
+        pk = self.packed()
+        g = ops.linear(x_norm, pk["w1"], pk["b1"], geglu=True)
+        return ops.linear(g, pk["w2"], pk["b2"], residual=residual)
+
+
+class BasicTransformerBlock(PackedModule):
+    """Reference attention.py:212-246 (attn1 self, attn2 cross or - in temporal blocks - self again, GEGLU FF)."""
+
+    def __init__(self, dim, n_heads, d_head, dropout=0., context_dim=None, gated_ff=True, checkpoint=True,
+                 disable_self_attn=False, attention_cls=None, video_length=None, image_cross_attention=False,
+                 image_cross_attention_scale=1.0, image_cross_attention_scale_learnable=False, text_context_len=77):
+        super().__init__()
+        if disable_self_attn:
+            raise NotImplementedError("disable_self_attn is not used by the ViewCrafter configs")
+        attn_cls = CrossAttention if attention_cls is None else attention_cls
+        self.attn1 = attn_cls(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout, context_dim=None)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = attn_cls(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout,
+                              video_length=video_length, image_cross_attention=image_cross_attention,
+                              image_cross_attention_scale=image_cross_attention_scale,
+                              image_cross_attention_scale_learnable=image_cross_attention_scale_learnable,
+                              text_context_len=text_context_len)
+        self.image_cross_attention = image_cross_attention
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.checkpoint = checkpoint
+
+    def _pack(self):
+        return [(_f32(n.weight), _f32(n.bias), n.eps) for n in (self.norm1, self.norm2, self.norm3)]
+
+    def ln_params(self):
+        return self.packed()
+
+
+class ContextKV:
+    """Projected cross-attention keys/values of one SpatialTransformer block for one conditioning tensor.  They depend
+    only on the context, i.e. they are constant over all DDIM steps and are cached by UNetModel."""
+    __slots__ = ("k_txt", "vt_txt", "k_img", "vt_img", "n_txt_rows", "n_img", "img_per_frame")
+
+
+def project_context(attn2, ctx):
+    """ctx: dict(txt=[B*80, D] fp16 (rows 77..79 zero), img=[G*Li, D] fp16 or None, n_img=Li, per_frame=bool)."""
+    pk = attn2.packed()
+    kv = ContextKV()
+    txt = ctx["txt"]
+    D = txt.shape[1]
+    C = attn2.inner_dim
+    kv.k_txt = ops.linear(txt, pk["wk"])                                        # [B*80, C]
+    kv.vt_txt = ops.gemm(pk["wv"], txt, M=C, N=txt.shape[0], K=D, lda=D)        # [C, B*80]  (V^T for the flash kernel)
+    kv.n_txt_rows = txt.shape[0]
+    kv.k_img = kv.vt_img = None
+    kv.n_img, kv.img_per_frame = ctx.get("n_img", 0), ctx.get("per_frame", False)
+    if attn2.image_cross_attention and ctx.get("img") is not None:
+        img = ctx["img"]
+        kv.k_img = ops.linear(img, pk["wk_ip"])
+        kv.vt_img = ops.gemm(pk["wv_ip"], img, M=C, N=img.shape[0], K=D, lda=D)
+    return kv
+
+
+class SpatialTransformer(PackedModule):
+    """Reference attention.py:249-310 (use_linear=True): GN(eps 1e-6) -> proj_in -> [LN, self-attn, LN, text (+) image
+    cross-attn, LN, GEGLU-FF] -> proj_out -> + x."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None, use_checkpoint=True,
+                 disable_self_attn=False, use_linear=False, video_length=None, image_cross_attention=False,
+                 image_cross_attention_scale_learnable=False):
+        super().__init__()
+        if not use_linear:
+            raise NotImplementedError("the ViewCrafter configs set use_linear: true (1x1-conv projections unsupported)")
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        self.n_heads = n_heads
+        self.norm = nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Linear(in_channels, inner_dim)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim,
+                                  disable_self_attn=disable_self_attn, checkpoint=use_checkpoint, attention_cls=None,
+                                  video_length=video_length, image_cross_attention=image_cross_attention,
+                                  image_cross_attention_scale_learnable=image_cross_attention_scale_learnable)
+            for _ in range(depth)])
+        self.proj_out = nn.Linear(inner_dim, in_channels)
+        nn.init.zeros_(self.proj_out.weight)
+        nn.init.zeros_(self.proj_out.bias)
+        self.use_linear = use_linear
+
+    def _pack(self):
+        return dict(gn_w=_f32(self.norm.weight), gn_b=_f32(self.norm.bias), win=_f16(self.proj_in.weight),
+                    bin=_f32(self.proj_in.bias), wout=_f16(self.proj_out.weight), bout=_f32(self.proj_out.bias))
+
+    def project_context(self, ctx):
+        return [project_context(blk.attn2, ctx) for blk in self.transformer_blocks]
+
+    def forward(self, x, context_kv=None, frames_per_video=1, **kwargs):
+        """x [n, H, W, C] fp16 channels-last, n = b*t frames; context_kv from project_context()."""
+        n, H, W, C = x.shape
+        N = H * W
+        if N % 8 != 0:
+            raise ValueError(f"spatial attention needs h*w % 8 == 0 (got {H}x{W})")
+        pk = self.packed()
+        tokens = n * N
+        xin = x.reshape(tokens, C)
+        a = ops.group_norm(x.view(n, N, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False)
+        t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
+        D, heads = t.shape[1], self.n_heads
+        for blk, kv in zip(self.transformer_blocks, context_kv):
+            ln = blk.ln_params()
+            a1, a2 = blk.attn1.packed(), blk.attn2.packed()
+            # ---- self-attention over the h*w tokens of each frame
+            h1 = ops.layer_norm(t, *ln[0])
+            qk = ops.linear(h1, a1["wqk"])                                           # [tokens, 2D]
+            vt = ops.gemm(a1["wv"], h1, M=D, N=tokens, K=D, lda=D)                   # [D, tokens]
+            o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
+            ops.flash_attn(qk, qk[:, D:], vt, o, n_groups=n, heads=heads, nq=N, nk=N, kv_rows=N, kv_div=1, ldq=2 * D,
+                           ldk=2 * D, ldvt=tokens, ldo=D, scale=blk.attn1.scale)
+            t = ops.linear(o, a1["wo"], a1["bo"], residual=t)
+            # ---- cross-attention: softmax(Q K_txt) V_txt + softmax(Q K_img) V_img
+            h2 = ops.layer_norm(t, *ln[1])
+            q2 = ops.linear(h2, a2["wq"])
+            o2 = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
+            nb = kv.n_txt_rows // 80
+            ops.flash_attn(q2, kv.k_txt, kv.vt_txt, o2, n_groups=n, heads=heads, nq=N, nk=blk.attn2.text_context_len,
+                           kv_rows=80, kv_div=frames_per_video, ldq=D, ldk=D, ldvt=nb * 80, ldo=D, scale=blk.attn2.scale)
+            if kv.k_img is not None:
+                ops.flash_attn(q2, kv.k_img, kv.vt_img, o2, n_groups=n, heads=heads, nq=N, nk=kv.n_img, kv_rows=kv.n_img,
+                               kv_div=1 if kv.img_per_frame else frames_per_video, ldq=D, ldk=D,
+                               ldvt=kv.vt_img.shape[1], ldo=D, scale=blk.attn2.scale, accumulate=True)
+            t = ops.linear(o2, a2["wo"], a2["bo"], residual=t)
+            # ---- feed-forward
+            t = blk.ff.run(ops.layer_norm(t, *ln[2]), t)
+        out = ops.linear(t, pk["wout"], pk["bout"], residual=xin)
+        return out.view(n, H, W, C)
+
+
+class TemporalTransformer(PackedModule):
+    """Reference attention.py:313-412 with only_self_att=True: GN over (C/32, T, H, W) -> proj_in -> [LN, self-attn
+    over T, LN, self-attn over T again (context None, :389-390), LN, GEGLU-FF] -> proj_out -> + x."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None, use_checkpoint=True,
+                 use_linear=False, only_self_att=True, causal_attention=False, causal_block_size=1,
+                 relative_position=False, temporal_length=None):
+        super().__init__()
+        if not only_self_att or causal_attention or relative_position:
+            raise NotImplementedError("ViewCrafter uses temporal self-attention only, no causal mask / relative position")
+        self.only_self_att = only_self_att
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        self.n_heads = n_heads
+        self.norm = nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+        if not use_linear:   # init_attn: Conv1d k=1 (openaimodel3d.py:389-399); same matmul, weight [inner, C, 1]
+            self.proj_in = nn.Conv1d(in_channels, inner_dim, kernel_size=1, stride=1, padding=0)
+            self.proj_out = nn.Conv1d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0)
+        else:
+            self.proj_in = nn.Linear(in_channels, inner_dim)
+            self.proj_out = nn.Linear(inner_dim, in_channels)
+        nn.init.zeros_(self.proj_out.weight)
+        nn.init.zeros_(self.proj_out.bias)
+
+        def attention_cls(**kw):
+            return CrossAttention(temporal_length=temporal_length, **kw)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=None,
+                                  attention_cls=attention_cls, checkpoint=use_checkpoint) for _ in range(depth)])
+        self.use_linear = use_linear
+
+    def _pack(self):
+        win = self.proj_in.weight.detach().reshape(self.proj_in.weight.shape[0], -1)
+        wout = self.proj_out.weight.detach().reshape(self.proj_out.weight.shape[0], -1)
+        return dict(gn_w=_f32(self.norm.weight), gn_b=_f32(self.norm.bias), win=_f16(win), bin=_f32(self.proj_in.bias),
+                    wout=_f16(wout), bout=_f32(self.proj_out.bias))
+
+    def forward(self, x, context=None):
+        """x [B, T, P, C] fp16 channels-last (P = h*w)."""
+        B, T, P, C = x.shape
+        pk = self.packed()
+        tokens = B * T * P
+        xin = x.reshape(tokens, C)
+        a = ops.group_norm(x.view(B, T * P, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False)
+        t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
+        D, heads = t.shape[1], self.n_heads
+        for blk in self.transformer_blocks:
+            ln = blk.ln_params()
+            for attn, lnp in ((blk.attn1, ln[0]), (blk.attn2, ln[1])):
+                ap = attn.packed()
+                qkv = ops.linear(ops.layer_norm(t, *lnp), ap["wqkv"])                 # [tokens, 3D]
+                o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
+                ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D, ldo=D,
+                                  scale=attn.scale)
+                t = ops.linear(o, ap["wo"], ap["bo"], residual=t)
+            t = blk.ff.run(ops.layer_norm(t, *ln[2]), t)
+        out = ops.linear(t, pk["wout"], pk["bout"], residual=xin)
+        return out.view(B, T, P, C)

@@ -1,0 +1,387 @@
+"""The lvdm 3-D UNet denoiser on the gfx950 kernels.
+
+Drop-in for the reference's lvdm/modules/networks/openaimodel3d.py::UNetModel on the ViewCrafter inference path: same
+constructor keywords (configs/inference_pvd_*.yaml `unet_config.params`), same state-dict names/shapes (strict
+checkpoint load), same call signature `forward(x, timesteps, context, features_adapter=None, fs=None, **ignored)`.
+
+MI355X-first differences from the reference implementation (none changes the result beyond fp16 rounding):
+  * one channels-last fp16 master layout [B, T, H, W, C]: the reference's '(b t) c h w' <-> 'b c t h w' <->
+    '(b h w) t c' copies are views here;
+  * every conv is an implicit GEMM on MFMA (csrc/gemm.hip) with bias / timestep-embedding add / residual / GEGLU fused
+    into the epilogue; nearest-2x upsampling is fused into the following conv's gather;
+  * cross-attention K/V projections depend only on the conditioning and are cached across DDIM steps;
+  * cond/uncond (CFG) run as one B=2 forward, halving weight traffic.
+There is no PyTorch compute fallback: without libvcx.so and a gfx950 device forward() raises.
+"""
+import torch
+from torch import nn
+
+from .... import ops
+from ....packing import pack_conv
+from ..attention import PackedModule, SpatialTransformer, TemporalTransformer, _f16, _f32
+
+
+class TimestepBlock(nn.Module):
+    """Marker: modules whose forward takes the timestep embedding (reference openaimodel3d.py:19-28)."""
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """Reference openaimodel3d.py:30-48: routes (emb | context | 5-D view) to each child by type.
+    x is channels-last [n = b*t, H, W, C]."""
+
+    def forward(self, x, emb, context=None, batch_size=None):
+        for layer in self:
+            if isinstance(layer, ResBlock):
+                x = layer(x, emb, batch_size=batch_size)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer(x, context_kv=context[id(layer)], frames_per_video=x.shape[0] // batch_size)
+            elif isinstance(layer, TemporalTransformer):
+                n, H, W, C = x.shape
+                x = layer(x.view(batch_size, n // batch_size, H * W, C)).view(n, H, W, C)
+            else:
+                x = layer(x)
+        return x
+
+
+class Downsample(PackedModule):
+    """Reference openaimodel3d.py:51-77 (use_conv=True, dims=2): Conv2d 3x3 stride 2 pad 1 stored as `.op`."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        if not use_conv or dims != 2 or padding != 1:
+            raise NotImplementedError("ViewCrafter uses conv_resample=True, dims=2")
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.op = nn.Conv2d(self.channels, self.out_channels, 3, stride=2, padding=padding)
+
+    def _pack(self):
+        return dict(w=_f16(pack_conv(self.op.weight.detach())), b=_f32(self.op.bias))
+
+    def forward(self, x):
+        pk = self.packed()
+        return ops.conv2d(x, pk["w"], pk["b"], kh=3, kw=3, stride=2)
+
+
+class Upsample(PackedModule):
+    """Reference openaimodel3d.py:80-106: nearest 2x then Conv2d 3x3 (`.conv`); the interpolation is folded into the
+    convolution's gather (VCX mode-1 `ups`)."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        if not use_conv or dims != 2 or padding != 1:
+            raise NotImplementedError("ViewCrafter uses conv_resample=True, dims=2")
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.conv = nn.Conv2d(self.channels, self.out_channels, 3, padding=padding)
+
+    def _pack(self):
+        return dict(w=_f16(pack_conv(self.conv.weight.detach())), b=_f32(self.conv.bias))
+
+    def forward(self, x):
+        pk = self.packed()
+        return ops.conv2d(x, pk["w"], pk["b"], kh=3, kw=3, ups=1)
+
+
+class TemporalConvBlock(PackedModule):
+    """Reference openaimodel3d.py:239-279: 4 x [GroupNorm(32) over (C/32, T, H, W) -> SiLU -> Conv3d (3,1,1)] + identity.
+    Module indices follow the reference (conv1: conv at .2; conv2-4: Dropout at .2, conv at .3)."""
+
+    def __init__(self, in_channels, out_channels=None, dropout=0.0, spatial_aware=False):
+        super().__init__()
+        if spatial_aware:
+            raise NotImplementedError("tempspatial_aware is False in the ViewCrafter configs")
+        out_channels = out_channels or in_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        k, p = (3, 1, 1), (1, 0, 0)
+        self.conv1 = nn.Sequential(nn.GroupNorm(32, in_channels), nn.SiLU(), nn.Conv3d(in_channels, out_channels, k, padding=p))
+        self.conv2 = nn.Sequential(nn.GroupNorm(32, out_channels), nn.SiLU(), nn.Dropout(dropout),
+                                   nn.Conv3d(out_channels, in_channels, k, padding=p))
+        self.conv3 = nn.Sequential(nn.GroupNorm(32, out_channels), nn.SiLU(), nn.Dropout(dropout),
+                                   nn.Conv3d(out_channels, in_channels, k, padding=p))
+        self.conv4 = nn.Sequential(nn.GroupNorm(32, out_channels), nn.SiLU(), nn.Dropout(dropout),
+                                   nn.Conv3d(out_channels, in_channels, k, padding=p))
+        nn.init.zeros_(self.conv4[-1].weight)
+        nn.init.zeros_(self.conv4[-1].bias)
+
+    def _pack(self):
+        out = []
+        for seq in (self.conv1, self.conv2, self.conv3, self.conv4):
+            gn, conv = seq[0], seq[-1]
+            out.append((_f32(gn.weight), _f32(gn.bias), gn.eps, _f16(pack_conv(conv.weight.detach())), _f32(conv.bias)))
+        return out
+
+    def forward(self, x):
+        """x [B, T, P, C] fp16."""
+        B, T, P, C = x.shape
+        y = x
+        stages = self.packed()
+        for i, (gw, gb, eps, w, b) in enumerate(stages):
+            a = ops.group_norm(y.reshape(B, T * P, y.shape[-1]), gw, gb, eps, True)
+            last = i == len(stages) - 1
+            y = ops.temporal_conv3(a.view(B, T, P, -1), w, b, residual=x.reshape(B * T * P, C) if last else None)
+        return y
+
+
+class ResBlock(PackedModule, TimestepBlock):
+    """Reference openaimodel3d.py:109-236 (no up/down, no scale-shift norm, 1x1 skip when channels change)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_scale_shift_norm=False, dims=2,
+                 use_checkpoint=False, use_conv=False, up=False, down=False, use_temporal_conv=False,
+                 tempspatial_aware=False):
+        super().__init__()
+        if use_scale_shift_norm or up or down or use_conv or dims != 2:
+            raise NotImplementedError("ResBlock variant not used by the ViewCrafter configs")
+        self.channels, self.emb_channels = channels, emb_channels
+        self.out_channels = out_channels or channels
+        self.use_temporal_conv = use_temporal_conv
+        self.in_layers = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Conv2d(channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(nn.GroupNorm(32, self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1))
+        nn.init.zeros_(self.out_layers[-1].weight)
+        nn.init.zeros_(self.out_layers[-1].bias)
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = nn.Conv2d(channels, self.out_channels, 1)
+        if self.use_temporal_conv:
+            self.temopral_conv = TemporalConvBlock(self.out_channels, self.out_channels, dropout=0.1,
+                                                   spatial_aware=tempspatial_aware)
+
+    def _pack(self):
+        gn1, c1 = self.in_layers[0], self.in_layers[2]
+        gn2, c2 = self.out_layers[0], self.out_layers[3]
+        pk = dict(g1=(_f32(gn1.weight), _f32(gn1.bias), gn1.eps), w1=_f16(pack_conv(c1.weight.detach())), b1=_f32(c1.bias),
+                  g2=(_f32(gn2.weight), _f32(gn2.bias), gn2.eps), w2=_f16(pack_conv(c2.weight.detach())), b2=_f32(c2.bias),
+                  we=_f16(self.emb_layers[1].weight), be=_f32(self.emb_layers[1].bias))
+        if not isinstance(self.skip_connection, nn.Identity):
+            pk["ws"] = _f16(pack_conv(self.skip_connection.weight.detach()))
+            pk["bs"] = _f32(self.skip_connection.bias)
+        return pk
+
+    def forward(self, x, emb, batch_size=None):
+        """x [n, H, W, Cin] fp16; emb = SiLU(time+fs embedding) as fp16 [B, emb_channels] (one row per video: the
+        reference repeats it over the T frames, openaimodel3d.py:563)."""
+        n, H, W, cin = x.shape
+        pk = self.packed()
+        cout = self.out_channels
+        B = emb.shape[0]
+        a = ops.group_norm(x.view(n, H * W, cin), *pk["g1"], True)
+        emb_out = ops.linear(emb, pk["we"], pk["be"], out_f32=True)                           # [B, Cout] fp32
+        h = ops.conv2d(a.view(n, H, W, cin), pk["w1"], pk["b1"], kh=3, kw=3, rowadd=emb_out, rowadd_div=(n // B) * H * W)
+        a = ops.group_norm(h.view(n, H * W, cout), *pk["g2"], True)
+        if "ws" in pk:
+            skip = ops.conv2d(x, pk["ws"], pk["bs"], kh=1, kw=1).view(n * H * W, cout)
+        else:
+            skip = x.reshape(n * H * W, cout)
+        h = ops.conv2d(a.view(n, H, W, cout), pk["w2"], pk["b2"], kh=3, kw=3, residual=skip)
+        if self.use_temporal_conv and batch_size:
+            h = self.temopral_conv(h.view(batch_size, n // batch_size, H * W, cout)).view(n, H, W, cout)
+        return h
+
+
+class UNetModel(PackedModule):
+    """Reference openaimodel3d.py:281-603."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0.0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, context_dim=None, use_scale_shift_norm=False,
+                 resblock_updown=False, num_heads=-1, num_head_channels=-1, transformer_depth=1, use_linear=False,
+                 use_checkpoint=False, temporal_conv=False, tempspatial_aware=False, temporal_attention=True,
+                 use_relative_position=True, use_causal_attention=False, temporal_length=None, use_fp16=False,
+                 addition_attention=False, temporal_selfatt_only=True, image_cross_attention=False,
+                 image_cross_attention_scale_learnable=False, default_fs=4, fs_condition=False):
+        super().__init__()
+        if num_head_channels == -1:
+            raise NotImplementedError("set num_head_channels (the ViewCrafter configs use 64)")
+        if resblock_updown or dims != 2 or not conv_resample:
+            raise NotImplementedError("UNet variant not used by the ViewCrafter configs")
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions = num_res_blocks, attention_resolutions
+        self.dropout, self.channel_mult, self.conv_resample = dropout, channel_mult, conv_resample
+        self.temporal_attention = temporal_attention
+        self.use_checkpoint = use_checkpoint       # accepted and ignored (inference only)
+        self.dtype = torch.float16 if use_fp16 else torch.float32
+        self.addition_attention = addition_attention
+        self.temporal_length = temporal_length
+        self.image_cross_attention = image_cross_attention
+        self.default_fs, self.fs_condition = default_fs, fs_condition
+        self.context_dim = context_dim
+        time_embed_dim = model_channels * 4
+
+        def spatial(ch):
+            return SpatialTransformer(ch, ch // num_head_channels, num_head_channels, depth=transformer_depth,
+                                      context_dim=context_dim, use_linear=use_linear, use_checkpoint=use_checkpoint,
+                                      disable_self_attn=False, video_length=temporal_length,
+                                      image_cross_attention=image_cross_attention,
+                                      image_cross_attention_scale_learnable=image_cross_attention_scale_learnable)
+
+        def temporal(ch, heads=None, linear=use_linear):
+            return TemporalTransformer(ch, heads or ch // num_head_channels, num_head_channels, depth=transformer_depth,
+                                       context_dim=context_dim, use_linear=linear, use_checkpoint=use_checkpoint,
+                                       only_self_att=temporal_selfatt_only, causal_attention=use_causal_attention,
+                                       relative_position=use_relative_position, temporal_length=temporal_length)
+
+        def res(cin, cout):
+            return ResBlock(cin, time_embed_dim, dropout, out_channels=cout, dims=dims, use_checkpoint=use_checkpoint,
+                            use_scale_shift_norm=use_scale_shift_norm, tempspatial_aware=tempspatial_aware,
+                            use_temporal_conv=temporal_conv)
+
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, time_embed_dim), nn.SiLU(),
+                                        nn.Linear(time_embed_dim, time_embed_dim))
+        if fs_condition:
+            self.fps_embedding = nn.Sequential(nn.Linear(model_channels, time_embed_dim), nn.SiLU(),
+                                               nn.Linear(time_embed_dim, time_embed_dim))
+            nn.init.zeros_(self.fps_embedding[-1].weight)
+            nn.init.zeros_(self.fps_embedding[-1].bias)
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        if addition_attention:   # 8 heads, Conv1d projections (use_linear not forwarded), openaimodel3d.py:387-399
+            self.init_attn = TimestepEmbedSequential(temporal(model_channels, heads=8, linear=False))
+        input_block_chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [res(ch, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(spatial(ch))
+                    if temporal_attention:
+                        layers.append(temporal(ch))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                input_block_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims, out_channels=ch)))
+                input_block_chans.append(ch)
+                ds *= 2
+        layers = [res(ch, ch), spatial(ch)]
+        if temporal_attention:
+            layers.append(temporal(ch))
+        layers.append(res(ch, ch))
+        self.middle_block = TimestepEmbedSequential(*layers)
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = input_block_chans.pop()
+                layers = [res(ch + ich, mult * model_channels)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(spatial(ch))
+                    if temporal_attention:
+                        layers.append(temporal(ch))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
+        nn.init.zeros_(self.out[-1].weight)
+        nn.init.zeros_(self.out[-1].bias)
+        self._ctx_cache = {}
+
+    # ------------------------------------------------------------------ packing / caches
+    def _drop_packed(self):
+        super()._drop_packed()
+        self._ctx_cache = {}
+
+    def _apply(self, fn, recurse=True):
+        self._ctx_cache = {}
+        return super()._apply(fn, recurse)
+
+    def _pack(self):
+        c0 = self.input_blocks[0][0]
+        gn, co = self.out[0], self.out[2]
+        pk = dict(w_in=_f16(pack_conv(c0.weight.detach())), b_in=_f32(c0.bias),
+                  g_out=(_f32(gn.weight), _f32(gn.bias), gn.eps), w_out=_f16(pack_conv(co.weight.detach())), b_out=_f32(co.bias),
+                  te=[(_f16(l.weight), _f32(l.bias)) for l in (self.time_embed[0], self.time_embed[2])])
+        if self.fs_condition:
+            pk["fe"] = [(_f16(l.weight), _f32(l.bias)) for l in (self.fps_embedding[0], self.fps_embedding[2])]
+        return pk
+
+    def spatial_transformers(self):
+        return [m for m in self.modules() if isinstance(m, SpatialTransformer)]
+
+    def _context_kv(self, context, t):
+        """Split/pad the conditioning (openaimodel3d.py:553-562) and project it through every SpatialTransformer's
+        to_k/to_v(/_ip) once; cached on the identity of the context tensor (constant over the DDIM loop)."""
+        key = (context.data_ptr(), context._version, tuple(context.shape), t, str(context.device))
+        hit = self._ctx_cache.get(key)
+        if hit is not None:
+            return hit
+        b, L, D = context.shape
+        ctx16 = ops.to_f16(context) if context.dtype != torch.float16 else context.contiguous()
+        txt = torch.zeros((b, 80, D), dtype=torch.float16, device=context.device)
+        ntxt = min(L, 77)
+        txt[:, :ntxt] = ctx16[:, :ntxt]
+        ctx = dict(txt=txt.view(b * 80, D), img=None, n_img=0, per_frame=False)
+        if self.image_cross_attention and L > 77:
+            n_img = L - 77
+            if L == 77 + t * 16:            # per-frame image tokens (the hard-coded branch, openaimodel3d.py:556-560)
+                ctx.update(img=ctx16[:, 77:].reshape(b * t * 16, D).contiguous(), n_img=16, per_frame=True)
+            else:
+                if n_img % 8 != 0:
+                    raise ValueError(f"image context length {n_img} must be a multiple of 8")
+                ctx.update(img=ctx16[:, 77:].reshape(b * n_img, D).contiguous(), n_img=n_img, per_frame=False)
+        kv = {id(st): st.project_context(ctx) for st in self.spatial_transformers()}
+        if len(self._ctx_cache) >= 4:
+            self._ctx_cache.clear()
+        self._ctx_cache[key] = kv
+        kv["_keepalive"] = context   # keep the key's data_ptr from being recycled while cached
+        return kv
+
+    # ------------------------------------------------------------------ forward
+    def _embed(self, pk, timesteps, fs, b, device):
+        mc = self.model_channels
+        t_emb = ops.to_f16(ops.timestep_embedding(timesteps, mc))
+        h = ops.linear(t_emb, *pk["te"][0], out_f32=True)
+        emb = ops.linear(ops.to_f16(ops.silu_f32(h)), *pk["te"][1], out_f32=True)          # [B, 4*mc] fp32
+        if self.fs_condition:
+            if fs is None:
+                fs = torch.full((b,), self.default_fs, dtype=torch.long, device=device)
+            f_emb = ops.to_f16(ops.timestep_embedding(fs, mc))
+            h = ops.linear(f_emb, *pk["fe"][0], out_f32=True)
+            emb = ops.linear(ops.to_f16(ops.silu_f32(h)), *pk["fe"][1], out_f32=True, rowadd=emb, rowadd_div=1)
+        # every ResBlock starts its emb branch with SiLU (emb_layers.0): do it once
+        return ops.to_f16(ops.silu_f32(emb))
+
+    def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
+        """x [B, in_channels, T, h, w] fp32 (or a list of tensors to be concatenated on channels, which is how
+        DiffusionWrapper avoids materialising torch.cat([x] + c_concat)); timesteps [B] int64; context [B, L, D];
+        fs [B] int64.  Extra keywords (cfg_img, unconditional_conditioning_img_nonetext, ...) leak in from the
+        sampler exactly as in the reference and are ignored.  Returns [B, out_channels, T, h, w] fp32."""
+        ops.require_gpu()
+        if features_adapter is not None:
+            raise NotImplementedError("features_adapter is not used on the ViewCrafter path")
+        parts = list(x) if isinstance(x, (list, tuple)) else [x]
+        b, _, t, hh, ww = parts[0].shape
+        device = parts[0].device
+        cin = sum(p.shape[1] for p in parts)
+        if cin != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} input channels, got {cin}")
+        pk = self.packed()
+        emb = self._embed(pk, timesteps, fs, b, device)
+        ckv = self._context_kv(context, t)
+
+        h = torch.empty((b, t, hh, ww, cin), dtype=torch.float16, device=device)
+        off = 0
+        for p in parts:
+            ops.ncthw_to_nthwc(p.float(), h, c_off=off)
+            off += p.shape[1]
+        h = h.view(b * t, hh, ww, cin)
+
+        hs = []
+        for i, module in enumerate(self.input_blocks):
+            if i == 0:
+                h = ops.conv2d(h, pk["w_in"], pk["b_in"], kh=3, kw=3)
+                if self.addition_attention:
+                    h = self.init_attn(h, emb, context=ckv, batch_size=b)
+            else:
+                h = module(h, emb, context=ckv, batch_size=b)
+            hs.append(h)
+        h = self.middle_block(h, emb, context=ckv, batch_size=b)
+        for module in self.output_blocks:
+            skip = hs.pop()
+            n, H, W, c1 = h.shape
+            h = ops.concat_channels(h.view(n * H * W, c1), skip.view(n * H * W, skip.shape[-1])).view(n, H, W, -1)
+            h = module(h, emb, context=ckv, batch_size=b)
+        n, H, W, c = h.shape
+        a = ops.group_norm(h.view(n, H * W, c), *pk["g_out"], True)
+        y = ops.conv2d(a.view(n, H, W, c), pk["w_out"], pk["b_out"], kh=3, kw=3, out_f32=True)   # [n, H, W, out] fp32
+        return ops.nthwc_to_ncthw(y.view(b, t, H, W, self.out_channels))
