@@ -17,16 +17,16 @@ def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
     """Reference utils_diffusion.py:31-53.  torch.linspace in fp64 so the tables are bit-identical."""
     if schedule == "linear":
-        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
+        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64, device="cpu") ** 2
     elif schedule == "cosine":
-        steps = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
+        steps = torch.arange(n_timestep + 1, dtype=torch.float64, device="cpu") / n_timestep + cosine_s
         alphas = torch.cos(steps / (1 + cosine_s) * math.pi / 2).pow(2)
         alphas = alphas / alphas[0]
         betas = (1 - alphas[1:] / alphas[:-1]).clamp(0, 0.999)
     elif schedule == "sqrt_linear":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64, device="cpu")
     elif schedule == "sqrt":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64, device="cpu") ** 0.5
     else:
         raise ValueError(f"schedule '{schedule}' unknown.")
     return betas.numpy()
