@@ -1,0 +1,46 @@
+"""The C-ABI library loads on a GPU-less host and exports every function include/vcx.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from viewcrafter_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "vcx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vcx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_functions_are_exported_and_bound():
+    names = declared_functions()
+    assert len(names) >= 20
+    L = _lib.lib()
+    for n in names:
+        assert getattr(L, n) is not None, n
+    assert sorted(_lib.SYMBOLS) == names, "viewcrafter_amd/_lib.py SYMBOLS must list exactly the header's functions"
+
+
+def test_abi_version_and_error_string():
+    L = _lib.lib()
+    assert L.vcx_abi_version() == 1
+    assert isinstance(L.vcx_last_error(), bytes)
+
+
+def test_gemm_desc_layout_matches_header():
+    """Field order/types of the ctypes mirror follow the C struct (checked by total size: 6 pointers, one int64, 21 int32,
+    one float, padded to 8)."""
+    assert ctypes.sizeof(_lib.GemmDesc) == 6 * 8 + 8 + 21 * 4 + 4
+    fields = [f[0] for f in _lib.GemmDesc._fields_]
+    assert fields[:7] == ["A", "W", "C", "bias", "rowadd", "residual", "lda"] and fields[-1] == "alpha"
+
+
+def test_argument_validation_without_gpu():
+    """Validation happens before any launch, so bad descriptors are rejected even on a GPU-less host."""
+    L = _lib.lib()
+    d = _lib.GemmDesc()
+    assert L.vcx_gemm_f16(ctypes.byref(d), None) == -1
+    assert b"null" in L.vcx_last_error()
+    assert L.vcx_layernorm_f16(None, None, None, None, 4, 64, 1e-5, None) == -1

@@ -1,0 +1,217 @@
+"""CPU tests of the host-side logic: config/plugin mechanism, schedules and sampler tables against the reference's golden
+vectors, state-dict contract, checkpoint loader, weight packing, and the no-fallback rule."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.tiny_config import TINY_DDCONFIG, TINY_UNET, tiny_model_params
+from tests.util import golden
+from viewcrafter_amd.config import Config, load_yaml
+from viewcrafter_amd.utils import diffusion_utils as du
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tiny_model():
+    params = Config.wrap(tiny_model_params("lvdm.modules.networks.openaimodel3d.UNetModel", "lvdm.models.autoencoder.AutoencoderKL"))
+    return du.instantiate_from_config(Config(target="lvdm.models.ddpm3d.VIPLatentDiffusion", params=params)).eval()
+
+
+# ------------------------------------------------------------------ config / plugin mechanism
+def test_config_container_supports_both_access_styles():
+    c = Config.wrap({"a": {"b": [1, {"c": 2}]}, "target": "x"})
+    assert c.a.b[1].c == 2 and c["a"]["b"][0] == 1 and "target" in c and c.get("zzz") is None
+    with pytest.raises(AttributeError):
+        c.missing
+
+
+def test_instantiate_from_config_contract():
+    assert du.instantiate_from_config("__is_first_stage__") is None
+    assert du.instantiate_from_config("__is_unconditional__") is None
+    with pytest.raises(KeyError):
+        du.instantiate_from_config({"params": {}})
+    lin = du.instantiate_from_config({"target": "torch.nn.Linear", "params": {"in_features": 3, "out_features": 2}})
+    assert isinstance(lin, torch.nn.Linear)
+    from viewcrafter_amd.lvdm.models.autoencoder import AutoencoderKL
+    assert du.get_obj_from_str("lvdm.models.autoencoder.AutoencoderKL") is AutoencoderKL      # reference path -> ours
+
+
+@pytest.mark.parametrize("name,size,scale", [("inference_pvd_1024.yaml", [72, 128], 0.3), ("inference_pvd_512.yaml", [40, 64], 0.7)])
+def test_shipped_yaml_graphs(name, size, scale):
+    cfg = load_yaml(os.path.join(ROOT, "configs", name))
+    p = cfg.model.params
+    assert cfg.model.target == "lvdm.models.ddpm3d.VIPLatentDiffusion"
+    assert p.image_size == size and p.base_scale == scale and p.parameterization == "v" and p.rescale_betas_zero_snr
+    u = p.unet_config.params
+    assert (u.in_channels, u.model_channels, u.num_head_channels, u.context_dim, u.temporal_length) == (8, 320, 64, 1024, 16)
+    assert p.first_stage_config.params.ddconfig.ch_mult == [1, 2, 4, 4]
+
+
+# ------------------------------------------------------------------ schedules vs the reference's golden vectors
+def test_schedule_functions_match_reference():
+    from viewcrafter_amd.lvdm.models import utils_diffusion as ud
+    g = golden("schedules")
+    betas = ud.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    assert np.array_equal(betas, g["betas_linear"])
+    assert np.allclose(ud.rescale_zero_terminal_snr(betas), g["betas_zero_snr"], rtol=0, atol=1e-15)
+    for method, n in (("uniform_trailing", 50), ("uniform_trailing", 5), ("uniform_trailing", 10), ("uniform", 50), ("quad", 20)):
+        assert np.array_equal(ud.make_ddim_timesteps(method, n, 1000, verbose=False), g[f"ddim_timesteps_{method}_{n}"])
+    with pytest.raises(NotImplementedError):
+        ud.make_ddim_timesteps("nope", 5, 1000, verbose=False)
+    acp = torch.tensor(np.cumprod(1.0 - g["betas_zero_snr"]), dtype=torch.float32)
+    for eta in (0.0, 1.0):
+        s, a, ap = ud.make_ddim_sampling_parameters(acp, g["ddim_timesteps_uniform_trailing_50"], eta, verbose=False)
+        assert np.allclose(s, g[f"ddim_sigmas_eta{eta}"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(a, g[f"ddim_alphas_eta{eta}"], rtol=1e-7) and np.allclose(ap, g[f"ddim_alphas_prev_eta{eta}"], rtol=1e-7)
+    from oracle.weights import synth_input
+    a, b = synth_input("cfg_a", (2, 4, 3, 8, 8)), synth_input("cfg_b", (2, 4, 3, 8, 8))
+    assert np.allclose(ud.rescale_noise_cfg(a, b, 0.7).numpy(), g["rescale_noise_cfg"], atol=1e-6)
+
+
+def test_model_buffers_and_sampler_tables_match_reference(tiny_model):
+    from viewcrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    g = golden("ddim_tiny")
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "scale_arr"):
+        assert np.array_equal(getattr(tiny_model, k).numpy(), g["model_" + k]), k
+    assert tiny_model.num_timesteps == 1000 and tiny_model.parameterization == "v" and tiny_model.use_dynamic_rescale
+    assert tiny_model.model.conditioning_key == "hybrid" and tiny_model.uncond_type == "empty_seq" and tiny_model.perframe_ae
+    assert tiny_model.model.diffusion_model.out_channels == 4
+    s = DDIMSampler(tiny_model)
+    s.make_schedule(5, ddim_discretize="uniform_trailing", ddim_eta=0.0, verbose=False)
+    assert list(s.ddim_timesteps) == list(g["ddim_timesteps"]) == [199, 399, 599, 799, 999]
+    assert np.allclose(s.ddim_scale_arr.numpy(), g["ddim_scale_arr"]) and np.allclose(s.ddim_scale_arr_prev.numpy(), g["ddim_scale_arr_prev"])
+    # zero terminal SNR: the first step has a_t == 0 exactly and the direction coefficient stays real
+    assert float(s._host["a"][-1]) == 0.0 and float(1.0 - s._host["a_prev"][-1] - s._host["sigma"][-1] ** 2) >= 0.0
+
+
+# ------------------------------------------------------------------ state-dict contract (strict checkpoint loading)
+def test_state_dict_names_and_shapes_equal_the_reference(tiny_model):
+    from viewcrafter_amd.lvdm.models.autoencoder import AutoencoderKL
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    for fixture, keys, shapes, module in (
+            ("unet_tiny", "unet_keys", "unet_shapes", UNetModel(**TINY_UNET)),
+            ("vae_tiny", "vae_keys", "vae_shapes", AutoencoderKL(ddconfig=TINY_DDCONFIG, lossconfig=None, embed_dim=4)),
+            ("ddim_tiny", "model_keys", "model_shapes", tiny_model)):
+        g = golden(fixture)
+        ref = {str(k): eval(str(s)) for k, s in zip(g[keys], g[shapes])}
+        mine = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+        assert mine == ref, (fixture, sorted(set(ref) ^ set(mine))[:5])
+    sd = tiny_model.state_dict()
+    assert sd["model.diffusion_model.init_attn.0.proj_in.weight"].dim() == 3          # Conv1d projection
+    assert "model.diffusion_model.input_blocks.1.0.temopral_conv.conv2.3.weight" in sd  # (sic) + Dropout index shift
+
+
+def test_zero_initialised_layers_like_the_reference():
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    m = UNetModel(**TINY_UNET)
+    sd = m.state_dict()
+    for k in ("out.2.weight", "input_blocks.1.0.out_layers.3.weight", "input_blocks.1.0.temopral_conv.conv4.3.weight",
+              "input_blocks.1.1.proj_out.weight", "input_blocks.1.2.proj_out.weight", "fps_embedding.2.weight"):
+        assert float(sd[k].abs().max()) == 0.0, k
+
+
+def test_load_model_checkpoint_layouts(tmp_path, tiny_model):
+    from viewcrafter_amd.lvdm.models.autoencoder import AutoencoderKL
+    src = AutoencoderKL(ddconfig=TINY_DDCONFIG, lossconfig=None, embed_dim=4)
+    sd = {k: torch.randn_like(v) for k, v in src.state_dict().items()}
+    dst = AutoencoderKL(ddconfig=TINY_DDCONFIG, lossconfig=None, embed_dim=4)
+    p1 = str(tmp_path / "lightning.ckpt")
+    torch.save({"state_dict": sd, "epoch": 3, "hyper": {"x": object}}, p1)
+    du.load_model_checkpoint(dst, p1)
+    assert all(torch.equal(dst.state_dict()[k], v) for k, v in sd.items())
+    p2 = str(tmp_path / "deepspeed.ckpt")
+    torch.save({"module": {"_forward_module." + k: v * 2 for k, v in sd.items()}}, p2)
+    du.load_model_checkpoint(dst, p2)
+    assert all(torch.equal(dst.state_dict()[k], 2 * v) for k, v in sd.items())
+    bad = dict(sd)
+    bad.pop(next(iter(bad)))
+    p3 = str(tmp_path / "bad.ckpt")
+    torch.save({"state_dict": bad}, p3)
+    with pytest.raises(RuntimeError):
+        du.load_model_checkpoint(dst, p3)            # strict: a missing key is an error, as in the reference
+    # 256-model rename retry: framestride_embed -> fps_embedding
+    full = {k.replace("fps_embedding", "framestride_embed"): v for k, v in tiny_model.state_dict().items()}
+    p4 = str(tmp_path / "renamed.ckpt")
+    torch.save({"state_dict": full}, p4)
+    du.load_model_checkpoint(tiny_model, p4)
+
+
+# ------------------------------------------------------------------ weight packing
+def test_pack_conv_is_the_im2col_order_of_the_channels_last_gather():
+    from viewcrafter_amd.packing import pack_conv, pad_cin
+    x = torch.randn(2, 5, 6, 8)                                           # n h w c
+    w = torch.randn(4, 8, 3, 3)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    xp = F.pad(x, (0, 0, 1, 1, 1, 1))
+    cols = torch.stack([xp[:, ky:ky + 5, kx:kx + 6, :] for ky in range(3) for kx in range(3)], dim=3)   # n h w tap c
+    out = cols.reshape(2, 5, 6, 72) @ pack_conv(w).t()
+    assert torch.allclose(out, ref, atol=1e-4)
+    w3 = torch.randn(4, 8, 3, 1, 1)
+    assert torch.equal(pack_conv(w3), w3[:, :, :, 0, 0].permute(0, 2, 1).reshape(4, 24))
+    assert pad_cin(torch.ones(2, 4, 3, 3), 8)[:, 4:].abs().sum() == 0 and pad_cin(w, 8) is w
+
+
+def test_pack_geglu_pairs_x_and_gate_in_blocks_of_32():
+    from viewcrafter_amd.packing import pack_geglu
+    d = 64
+    w = torch.arange(2 * d, dtype=torch.float32)[:, None].repeat(1, 4)
+    b = torch.arange(2 * d, dtype=torch.float32)
+    wp, bp = pack_geglu(w, b)
+    for blk in range(d // 32):
+        assert torch.equal(bp[64 * blk:64 * blk + 32], b[32 * blk:32 * blk + 32])                 # x rows
+        assert torch.equal(bp[64 * blk + 32:64 * blk + 64], b[d + 32 * blk:d + 32 * blk + 32])     # their gates
+    assert torch.equal(wp[:, 0], bp)
+
+
+# ------------------------------------------------------------------ sampler host logic
+def test_cfg_batching_rules():
+    from viewcrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    c = {"c_crossattn": [torch.zeros(1, 5, 4)], "c_concat": [torch.zeros(1, 4, 2, 2, 2)]}
+    uc = {"c_crossattn": [torch.ones(1, 5, 4)], "c_concat": [torch.zeros(1, 4, 2, 2, 2)]}
+    assert DDIMSampler._batchable(c, uc)
+    assert not DDIMSampler._batchable(c, {"c_crossattn": [torch.ones(1, 6, 4)], "c_concat": c["c_concat"]})
+    assert not DDIMSampler._batchable(c, torch.zeros(1))
+    s = DDIMSampler.__new__(DDIMSampler)
+    s._cfg_cache = None
+    both = s._cfg_cond(c, uc)
+    assert both["c_crossattn"][0].shape == (2, 5, 4) and float(both["c_crossattn"][0][1].min()) == 1.0
+    assert s._cfg_cond(c, uc) is both                                   # built once per sample() call
+
+
+# ------------------------------------------------------------------ the product has no CPU / oracle fallback
+def test_forward_fails_loudly_without_gpu(tiny_model):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from viewcrafter_amd._lib import VcxError
+    x = torch.zeros(1, 4, 2, 8, 8)
+    cond = {"c_crossattn": [torch.zeros(1, 77, TINY_UNET["context_dim"])], "c_concat": [torch.zeros(1, 4, 2, 8, 8)]}
+    with pytest.raises(VcxError):
+        tiny_model.apply_model(x, torch.tensor([10]), cond)
+    with pytest.raises(VcxError):
+        tiny_model.decode_first_stage(torch.zeros(1, 4, 2, 8, 8))
+
+
+def test_product_never_imports_the_oracle():
+    offenders = []
+    for base in ("viewcrafter_amd", "configs"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h")):
+                    src = open(os.path.join(dp, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                        offenders.append(os.path.join(dp, f))
+    for f in ("viewcrafter.py", "inference.py"):
+        if re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(ROOT, f)).read(), flags=re.M):
+            offenders.append(f)
+    assert not offenders, offenders
+
+
+def test_multicond_sampler_is_declared_unbuilt():
+    from viewcrafter_amd.lvdm.models.samplers.ddim_multiplecond import DDIMSampler
+    with pytest.raises(NotImplementedError):
+        DDIMSampler(None)
