@@ -1,0 +1,115 @@
+"""Where does the GEMM/conv time of one B=2 UNet forward go?  Records every vcx_gemm_f16 descriptor of a full-size
+forward, then re-times each unique problem in isolation (random operands) and prints a table sorted by total time.
+
+    python tools/gemm_shapes.py [--workload ViewCrafter_25_576x1024x25] [--json out.json]
+"""
+import argparse
+import collections
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from viewcrafter_amd import _lib, ops  # noqa: E402
+
+FIELDS = ["M", "N", "K", "lda", "ldw", "ldc", "ldr", "mode", "in_h", "in_w", "out_h", "out_w", "cin", "kh", "kw", "stride",
+          "pad_h", "pad_w", "ups", "rowadd_div", "flags"]
+
+
+def record_forward(workload):
+    from bench import WORKLOADS, synth_conditioning
+    from viewcrafter_amd.builder import build_diffusion_model, randomize_parameters
+    cfg, T, h, w = WORKLOADS[workload]
+    model = build_diffusion_model(os.path.join(ROOT, "configs", cfg), device="cuda", conditioners="identity")
+    randomize_parameters(model)
+    x, cond, uc = synth_conditioning(T, h, w, "cuda")
+    both = {k: [torch.cat([a, b], 0) for a, b in zip(cond[k], uc[k])] for k in cond}
+    ts = torch.full((2,), 499, device="cuda", dtype=torch.long)
+    fs = torch.tensor([10, 10], device="cuda")
+    seen = collections.Counter()
+    L = _lib.lib()
+    real = L.vcx_gemm_f16
+
+    class Spy:
+        def __call__(self, dref, stream):
+            d = dref._obj
+            seen[tuple(int(getattr(d, f)) for f in FIELDS)] += 1
+            return real(dref, stream)
+    with torch.no_grad():
+        model.apply_model(torch.cat([x, x]), ts, both, fs=fs)      # warm (packs weights, caches context K/V)
+        L.vcx_gemm_f16 = Spy()
+        try:
+            model.apply_model(torch.cat([x, x]), ts, both, fs=fs)
+        finally:
+            L.vcx_gemm_f16 = real
+    torch.cuda.synchronize()
+    del model
+    torch.cuda.empty_cache()
+    return seen
+
+
+def time_shape(key, iters=5):
+    d = dict(zip(FIELDS, key))
+    M, N, K = d["M"], d["N"], d["K"]
+    conv = d["mode"] == 1
+    flags = d["flags"]
+    if conv:
+        n_img = M // (d["out_h"] * d["out_w"])
+        a = torch.randn(n_img * d["in_h"] * d["in_w"], d["lda"], device="cuda").half()
+    else:
+        a = torch.randn(M, d["lda"], device="cuda").half()
+    w = (torch.randn(N, d["ldw"], device="cuda") / K ** 0.5).half()
+    n_out = N // 2 if flags & 16 else N
+    out = torch.empty(M, max(d["ldc"], n_out), device="cuda", dtype=torch.float32 if flags & 32 else torch.float16)
+    bias = torch.randn(max(M, N) if flags & 2 else N, device="cuda") if flags & 3 else None
+    res = torch.randn(M, d["ldr"], device="cuda").half() if flags & 8 else None
+    ra = torch.randn((M + d["rowadd_div"] - 1) // max(d["rowadd_div"], 1), N, device="cuda") if flags & 4 else None
+    geom = {k: d[k] for k in ("in_h", "in_w", "out_h", "out_w", "cin", "kh", "kw", "stride", "pad_h", "pad_w", "ups")} if conv else None
+
+    def run():
+        ops.gemm(a, w, M=M, N=N, K=K, lda=d["lda"], ldw=d["ldw"], out=out, ldc=d["ldc"], bias=bias, bias_m=bool(flags & 2),
+                 residual=res, ldr=d["ldr"] if res is not None else None, rowadd=ra, rowadd_div=d["rowadd_div"],
+                 geglu=bool(flags & 16), out_f32=bool(flags & 32), conv=geom)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="ViewCrafter_25_576x1024x25")
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    seen = record_forward(args.workload)
+    rows = []
+    for key, cnt in seen.items():
+        d = dict(zip(FIELDS, key))
+        ms = time_shape(key)
+        fl = 2.0 * d["M"] * d["N"] * d["K"]
+        rows.append(dict(d, count=cnt, ms=ms, total_ms=ms * cnt, tflops=fl / ms / 1e9))
+    rows.sort(key=lambda r: -r["total_ms"])
+    tot = sum(r["total_ms"] for r in rows)
+    tfl = sum(2.0 * r["M"] * r["N"] * r["K"] * r["count"] for r in rows)
+    print(f"# {len(rows)} unique GEMM problems, {sum(r['count'] for r in rows)} launches, {tot:.1f} ms, {tfl/1e12:.1f} TFLOP, {tfl/tot/1e9:.0f} TF/s")
+    print(f"{'cnt':>4} {'M':>8} {'N':>6} {'K':>6} {'kind':>10} {'flags':>5} {'ms':>8} {'total':>8} {'TF/s':>7} {'cum%':>6}")
+    cum = 0.0
+    for r in rows:
+        cum += r["total_ms"]
+        kind = f"conv{r['kh']}x{r['kw']}" + ("s2" if r["stride"] == 2 else "") + ("u" if r["ups"] else "") if r["mode"] else "linear"
+        print(f"{r['count']:4d} {r['M']:8d} {r['N']:6d} {r['K']:6d} {kind:>10} {r['flags']:5d} {r['ms']:8.3f} {r['total_ms']:8.2f} {r['tflops']:7.0f} {100*cum/tot:6.1f}")
+    if args.json:
+        json.dump(rows, open(args.json, "w"))
+
+
+if __name__ == "__main__":
+    main()

@@ -48,7 +48,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (F.gelu default) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the fp16 output
+// rounding): ~14 VALU ops instead of libm erff's ~40 — the GEGLU epilogue otherwise costs as much as a K=320 main loop.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
 
 template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
@@ -58,60 +66,66 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
     half_t* sX = reinterpret_cast<half_t*>(smem_raw);              // [2][BM*BK]
     half_t* sW = sX + 2 * BM * BK;                                  // [2][BN*BK]
 
-    // ---- XCD-aware tile mapping: XCD x (= blockIdx % 8) walks a contiguous band of tiles so
-    // that the tiles sharing an activation panel hit the same L2.
-    const int nb = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int q8 = nb >> 3, r8 = nb & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int tile_n = vid % p.tiles_n;
-    const int tile_m = vid / p.tiles_n;
+    // ---- persistent blocks: block b walks tiles b, b+G, b+2G, ... (G = gridDim.x, a multiple of 8 whenever a block
+    // owns more than one tile).  Tile ids are mapped XCD-aware: ids congruent mod 8 (= the XCD the dispatcher puts this
+    // block on) form a contiguous band of (tile_m, tile_n), so tiles sharing an activation panel hit the same L2.
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x;
+    auto tile_coords = [&](int t, int& tm, int& tn) {
+        const int q8 = ntiles >> 3, r8 = ntiles & 7;
+        const int xcd = t & 7, idx = t >> 3;
+        const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        tn = vid % p.tiles_n;
+        tm = vid / p.tiles_n;
+    };
 
     const int tid = threadIdx.x;
     const int chunk = tid & 7;   // 16-byte chunk inside the BK=64 slice
     const int r0 = tid >> 3;     // 0..31
 
-    // ---- per-thread gather state for the 4 activation rows this thread stages
+    // ---- per-thread gather state of the tile being LOADED (4 activation rows, WROWS weight rows)
     int64_t xbase[4];  // linear: element offset of the row; conv: image base pixel index
     int xoy[4], xox[4];
     bool xvalid[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = tile_m * BM + r0 + 32 * i;
-        xvalid[i] = m < p.M;
-        if (CONV) {
-            const int hw = p.out_h * p.out_w;
-            const int mm = xvalid[i] ? m : 0;
-            const int img = mm / hw;
-            const int rem = mm - img * hw;
-            const int oy = rem / p.out_w;
-            const int ox = rem - oy * p.out_w;
-            xbase[i] = (int64_t)img * p.in_h * p.in_w;
-            xoy[i] = oy * p.stride - p.pad_h;
-            xox[i] = ox * p.stride - p.pad_w;
-        } else {
-            xbase[i] = (int64_t)m * p.lda;
-            xoy[i] = xox[i] = 0;
-        }
-    }
-    // conv tap walker: k = (ky*kw + kx)*cin + ci, advanced by BK per K-step
-    int ci = chunk * 8, ky = 0, kx = 0;
-    if (CONV) {
-        while (ci >= p.cin) {
-            ci -= p.cin;
-            if (++kx == p.kw) { kx = 0; ++ky; }
-        }
-    }
-    // weight rows
+    int ci = 0, ky = 0, kx = 0;   // conv tap walker: k = (ky*kw + kx)*cin + ci, advanced by BK per K-step
     const half_t* wptr[WROWS];
     bool wvalid[WROWS];
+    auto init_load = [&](int t) {
+        int tile_m, tile_n;
+        tile_coords(t, tile_m, tile_n);
 #pragma unroll
-    for (int i = 0; i < WROWS; ++i) {
-        const int n = tile_n * BN + r0 + 32 * i;
-        wvalid[i] = n < p.N;
-        wptr[i] = p.W + (int64_t)(wvalid[i] ? n : 0) * p.ldw + chunk * 8;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int m = tile_m * BM + r0 + 32 * i;
+            xvalid[i] = m < p.M;
+            if (CONV) {
+                const int hw = p.out_h * p.out_w;
+                const int mm = xvalid[i] ? m : 0;
+                const int img = mm / hw;
+                const int rem = mm - img * hw;
+                const int oy = rem / p.out_w;
+                const int ox = rem - oy * p.out_w;
+                xbase[i] = (int64_t)img * p.in_h * p.in_w;
+                xoy[i] = oy * p.stride - p.pad_h;
+                xox[i] = ox * p.stride - p.pad_w;
+            } else {
+                xbase[i] = (int64_t)m * p.lda;
+                xoy[i] = xox[i] = 0;
+            }
+        }
+        ci = chunk * 8; ky = 0; kx = 0;
+        if (CONV) {
+            while (ci >= p.cin) {
+                ci -= p.cin;
+                if (++kx == p.kw) { kx = 0; ++ky; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            const int n = tile_n * BN + r0 + 32 * i;
+            wvalid[i] = n < p.N;
+            wptr[i] = p.W + (int64_t)(wvalid[i] ? n : 0) * p.ldw + chunk * 8;
+        }
+    };
 
     h8 xreg[4];
     h8 wreg[WROWS];
@@ -169,14 +183,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- software pipeline over the flattened (tile, k-step) sequence of this block: the loads of step s+1 are in
+    // flight during the MFMAs (and, at a tile boundary, the epilogue) of step s, so neither the first-load latency nor
+    // the epilogue of a tile is exposed after the block's first tile.
     const int nk = (p.K + BK - 1) / BK;
+    int ltile = blockIdx.x, lkt = 0;     // load cursor
+    int ctile = blockIdx.x, ckt = 0;     // compute cursor
+    int tile_m, tile_n;
+    tile_coords(ctile, tile_m, tile_n);
+    init_load(ltile);
     load_tile(0);
     store_tile(0);
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) load_tile(kt + 1);
+    const int flags = p.flags;
+    for (;;) {
+        if (++lkt == nk) {
+            lkt = 0;
+            ltile += G;
+            if (ltile < ntiles) init_load(ltile);
+        }
+        const bool more = ltile < ntiles;
+        if (more) load_tile(lkt);
         const half_t* cx = sX + cur * BM * BK;
         const half_t* cw = sW + cur * BN * BK;
 #pragma unroll
@@ -194,19 +222,73 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
                 for (int b = 0; b < 4; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
         }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-
+        if (ckt == nk - 1) {
     // ---- epilogue.  acc[a][b][r] = out[m][n], m = tile_m*BM + wm*64 + b*16 + lr,
     //      n = tile_n*BN + wn*(BN/2) + a*16 + lg*4 + r.
-    const int flags = p.flags;
+    // Fast path (N % 4 == 0, no GEGLU): all residual / bias loads are issued together, waited for once, then the
+    // math and the 8-byte stores follow; addresses of out-of-range rows/columns are clamped so the loads need no branch.
+            if (!GEGLU && (p.N & 3) == 0) {
+                const int mbase = tile_m * BM + wm * 64 + lr;
+                const int nbase = tile_n * BN + wn * (BN / 2) + lg * 4;
+                h4 rr[NFRAG][4];
+                f4 bv[NFRAG];
+                if (flags & VCX_GEMM_RESIDUAL) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int mc = min(mbase + b * 16, p.M - 1);
+#pragma unroll
+                        for (int a = 0; a < NFRAG; ++a) {
+                            const int nc = min(nbase + a * 16, p.N - 4);
+                            rr[a][b] = *reinterpret_cast<const h4*>(p.R + (int64_t)mc * p.ldr + nc);
+                        }
+                    }
+                }
+                if (flags & VCX_GEMM_BIAS_N) {
+#pragma unroll
+                    for (int a = 0; a < NFRAG; ++a) bv[a] = *reinterpret_cast<const f4*>(p.bias + min(nbase + a * 16, p.N - 4));
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int m = mbase + b * 16;
+                    const int mc = min(m, p.M - 1);
+                    const float bm = (flags & VCX_GEMM_BIAS_M) ? p.bias[mc] : 0.f;
+                    const float* radd = (flags & VCX_GEMM_ROWADD) ? p.rowadd + (int64_t)(mc / p.rowadd_div) * p.N : nullptr;
+#pragma unroll
+                    for (int a = 0; a < NFRAG; ++a) {
+                        const int n0 = nbase + a * 16;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + bm;
+                        if (flags & VCX_GEMM_BIAS_N) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += bv[a][r];
+                        }
+                        if (radd) {
+                            const f4 rv = *reinterpret_cast<const f4*>(radd + min(n0, p.N - 4));
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                        }
+                        if (flags & VCX_GEMM_RESIDUAL) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[a][b][r];
+                        }
+                        if (m < p.M && n0 < p.N) {
+                            if (OUT_F32) {
+                                float* dst = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n0;
+                                *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]};
+                            } else {
+                                half_t* dst = reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n0;
+                                *reinterpret_cast<h4*>(dst) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                            }
+                        }
+                    }
+                }
+            } else {
+    // generic path (GEGLU, or N not a multiple of 4): per-fragment guards, scalar tail
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int m = tile_m * BM + wm * 64 + b * 16 + lr;
         if (m >= p.M) continue;
-        const float bias_m = (flags & VCX_GEMM_BIAS_M) ? p.bias[m] : 0.f;
         const float* radd = (flags & VCX_GEMM_ROWADD) ? p.rowadd + (int64_t)(m / p.rowadd_div) * p.N : nullptr;
         if (GEGLU) {
 #pragma unroll
@@ -232,7 +314,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
                 if (n0 >= p.N) continue;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + bias_m;
+                for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha;
+                if (flags & VCX_GEMM_BIAS_M) {   // loaded where it is consumed: a load left pending on a skipped path
+                    const float bm = p.bias[m];  // would make the compiler drain vmcnt(0) in front of the next MFMAs
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bm;
+                }
                 const bool full = (n0 + 4 <= p.N);
                 if (full) {
                     if (flags & VCX_GEMM_BIAS_N) {
@@ -272,6 +359,38 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
             }
         }
     }
+            }
+#pragma unroll
+            for (int a = 0; a < NFRAG; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+        }   // end of the tile's epilogue
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        if (++ckt == nk) {
+            ckt = 0;
+            ctile += G;
+            if (ctile >= ntiles) break;
+            tile_coords(ctile, tile_m, tile_n);
+        }
+    }
+}
+
+int persistent_grid(int ntiles) {
+    static int slots = 0;   // resident blocks chip-wide at 2 blocks/CU (LDS- and VGPR-limited)
+    if (slots == 0) {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        slots = 2 * cus;
+    }
+    if (ntiles <= slots) return ntiles;
+    const int rounds = (ntiles + slots - 1) / slots;          // balance: every block gets rounds or rounds-1 tiles
+    int g = (ntiles + rounds - 1) / rounds;
+    g = (g + 7) & ~7;                                         // multiple of 8 keeps a block's tiles on one XCD band
+    return g < slots ? g : slots;
 }
 
 template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
@@ -287,7 +406,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
         }
         attr_set = true;
     }
-    const int nb = a.tiles_m * a.tiles_n;
+    const int nb = persistent_grid(a.tiles_m * a.tiles_n);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(NTHREADS), smem, s, a);
     return vcx_check_launch("vcx_gemm_f16");
 }
