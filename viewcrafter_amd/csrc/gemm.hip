@@ -20,43 +20,12 @@
 // zero fill outside the image.
 #include "vcx_common.h"
 
+#include "gemm_args.h"
+#include <stdlib.h>
+
+using namespace vcxgemm;
+
 namespace {
-
-constexpr int BM = 128;
-constexpr int BK = 64;
-constexpr int NTHREADS = 256;
-
-struct GemmArgs {
-    const half_t* A;
-    const half_t* W;
-    void* C;
-    const float* bias;
-    const float* rowadd;
-    const half_t* R;
-    int64_t lda;
-    int M, N, K;
-    int ldw, ldc, ldr;
-    int in_h, in_w, out_h, out_w, cin, kw, stride, pad_h, pad_w, ups;
-    int rowadd_div;
-    int flags;
-    float alpha;
-    int tiles_m, tiles_n;
-};
-
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-    // element offset of a 16-byte chunk inside a [rows][64] fp16 tile
-    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
-}
-
-// exact-erf GELU (F.gelu default) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the fp16 output
-// rounding): ~14 VALU ops instead of libm erff's ~40 — the GEGLU epilogue otherwise costs as much as a K=320 main loop.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
-}
 
 template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
@@ -377,7 +346,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
     }
 }
 
-int persistent_grid(int ntiles) {
+}  // namespace
+int vcxgemm::persistent_grid(int ntiles) {
     static int slots = 0;   // resident blocks chip-wide at 2 blocks/CU (LDS- and VGPR-limited)
     if (slots == 0) {
         int dev = 0, cus = 256;
@@ -392,6 +362,7 @@ int persistent_grid(int ntiles) {
     g = (g + 7) & ~7;                                         // multiple of 8 keeps a block's tiles on one XCD band
     return g < slots ? g : slots;
 }
+namespace {
 
 template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
 int launch(const GemmArgs& a, hipStream_t s) {
@@ -469,7 +440,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.ldw = d->ldw; a.ldc = d->ldc; a.ldr = d->ldr;
     a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w;
-    a.cin = d->cin; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.ups = d->ups;
+    a.cin = d->cin; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.ups = d->ups;
     a.rowadd_div = d->rowadd_div > 0 ? d->rowadd_div : 1;
     a.flags = flags;
     a.alpha = d->alpha;
@@ -481,5 +452,14 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const double flops = 2.0 * d->M * (double)d->N * d->K;
     const double bytes = 2.0 * ((double)d->M * d->K / (conv ? d->kh * d->kw : 1) + (double)d->N * d->K + (double)d->M * d->N);
     VcxProfScope prof(VCX_FAM_GEMM, s, flops, bytes);
+    // DMA kernel (gemm_dma.hip) whenever its addressing assumptions hold; the register-staged kernel otherwise.
+    static const bool dma_enabled = []() { const char* e = getenv("VCX_GEMM_DMA"); return !(e && e[0] == '0'); }();
+    const unsigned long long lim = 0xFFFF0000ull;
+    const unsigned long long a_ext = conv ? 2ull * (unsigned long long)(d->M / (d->out_h * d->out_w)) * d->in_h * d->in_w * d->lda
+                                          : 2ull * ((unsigned long long)(d->M - 1) * d->lda + d->K);
+    const unsigned long long w_ext = 2ull * ((unsigned long long)(d->N - 1) * d->ldw + d->K);
+    const bool dma_ok = dma_enabled && d->K % 64 == 0 && d->N % 4 == 0 && (!conv || (d->cin % 64 == 0 && d->ups == 0)) &&
+                        a_ext < lim && w_ext < lim && (!geglu || d->N >= 64);
+    if (dma_ok) return launch_dma(a, bn, conv, geglu, f32, s);
     return use160 ? dispatch<160>(a, conv, geglu, f32, s) : dispatch<128>(a, conv, geglu, f32, s);
 }

@@ -1,0 +1,56 @@
+// Shared between the generic (register-staged) and the DMA (buffer_load ... lds) GEMM kernels.
+#pragma once
+#include "vcx_common.h"
+
+namespace vcxgemm {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr int NTHREADS = 256;
+
+struct GemmArgs {
+    const half_t* A;
+    const half_t* W;
+    void* C;
+    const float* bias;
+    const float* rowadd;
+    const half_t* R;
+    int64_t lda;
+    int M, N, K;
+    int ldw, ldc, ldr;
+    int in_h, in_w, out_h, out_w, cin, kh, kw, stride, pad_h, pad_w, ups;
+    int rowadd_div;
+    int flags;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    // element offset of a 16-byte chunk inside a [rows][64] fp16 tile
+    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+// exact-erf GELU (F.gelu default) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the fp16 output
+// rounding): ~14 VALU ops instead of libm erff's ~40 — the GEGLU epilogue otherwise costs as much as a K=320 main loop.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+
+// XCD-aware persistent tile walk: tile ids congruent mod 8 form a contiguous band of (tile_m, tile_n).
+__device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int& tm, int& tn) {
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int xcd = t & 7, idx = t >> 3;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    tn = vid % tiles_n;
+    tm = vid / tiles_n;
+}
+
+int persistent_grid(int ntiles);
+int launch_dma(const GemmArgs& a, int bn, bool conv, bool geglu, bool f32, hipStream_t s);
+
+}  // namespace vcxgemm

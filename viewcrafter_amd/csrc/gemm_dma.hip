@@ -1,0 +1,304 @@
+// GEMM / implicit-GEMM convolution, DMA variant: operand tiles go HBM -> LDS with `buffer_load_dwordx4 ... lds`
+// (no VGPR staging, no ds_write), addressed through buffer descriptors whose hardware range check supplies the zero
+// fill: padded taps, rows beyond M and weight rows beyond N simply use an out-of-range offset.
+//
+// Why a second kernel: PMC on the register-staged kernel (profiles/r01_pmc_gemm.txt) shows ~5 VALU + 2 SALU
+// instructions per MFMA — 64-bit address arithmetic, bounds predicates and exec-mask branches around every 16-byte
+// load — and MFMA-busy of only ~28 %.  Here a K-step costs, per thread, 4 x (v_add + bit-extract + select) for the
+// activation rows of a convolution (nothing at all for a linear layer: the K offset rides in the scalar soffset) and
+// zero instructions for the weight rows.
+//
+// Same tiling as gemm.hip (128 x {128,160} x 64, 4 waves 2x2, weight = MFMA A operand, activation = B operand,
+// XOR-swizzled LDS, persistent XCD-aware tile walk, cross-tile software pipeline); the LDS image is lane-linear per
+// DMA instruction, so the swizzle is applied to the SOURCE chunk each lane fetches (both-sides rule).
+//
+// Eligibility (checked by vcx_gemm_f16, which falls back to gemm.hip otherwise): K % 64 == 0, N % 4 == 0, operand
+// extents < 4 GiB (32-bit buffer offsets), convolutions with cin % 64 == 0 (a K-step then lies inside one tap, so
+// the tap is block-uniform) and no fused upsampling.
+#include "gemm_args.h"
+
+using namespace vcxgemm;
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB = 0xFFFFFFFFu;   // voffset beyond any descriptor's num_records -> the load returns zeros
+
+template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsigned a_bytes, unsigned w_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the body uses device-only types)
+    constexpr int NFRAG = BN / 32;
+    constexpr int WROWS = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    half_t* sX = reinterpret_cast<half_t*>(smem_raw);              // [2][BM*BK]
+    half_t* sW = sX + 2 * BM * BK;                                  // [2][BN*BK]
+
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.W), 0, (int)w_bytes, 0x00020000);
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int chunk = tid & 7;   // LDS chunk position inside the 128-byte row
+    const int r0 = tid >> 3;     // tile row of this thread's first DMA instruction
+
+    // ---- per-thread source offsets (bytes) of the tile being loaded
+    unsigned xoff[4];            // activation rows; OOB when the row is beyond M (linear mode)
+    unsigned xmask[4];           // conv: bit t set <=> tap t of this row is inside the image
+    unsigned woff[WROWS];        // weight rows; OOB when beyond N
+    int tap = 0, ci0 = 0;        // conv K walker (block-uniform): k = tap*cin + ci0
+    unsigned tap_off = 0;        // conv: byte offset of (tap, ci0) relative to the row's (ky=0, kx=0, c=0) pixel
+    int tky = 0, tkx = 0;
+    auto init_load = [&](int t) {
+        int tile_m, tile_n;
+        tile_coords(t, ntiles, p.tiles_n, tile_m, tile_n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 32 * i;
+            const int m = tile_m * BM + r;
+            const unsigned csrc = (unsigned)(chunk ^ ((r >> 1) & 7)) * 16u;   // source chunk that lands at position `chunk`
+            if (CONV) {
+                const int hw = p.out_h * p.out_w;
+                const int mm = m < p.M ? m : 0;
+                const int img = mm / hw;
+                const int rem = mm - img * hw;
+                const int oy = rem / p.out_w;
+                const int ox = rem - oy * p.out_w;
+                const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
+                const long long pix0 = ((long long)img * p.in_h + iy0) * p.in_w + ix0;   // may be negative at the border
+                xoff[i] = (unsigned)(pix0 * p.lda * 2) + csrc;                            // wraps; valid taps un-wrap it
+                unsigned mask = 0;
+                if (m < p.M) {
+                    for (int ky = 0; ky < p.kh; ++ky)
+                        for (int kx = 0; kx < p.kw; ++kx) {
+                            const int iy = iy0 + ky, ix = ix0 + kx;
+                            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) mask |= 1u << (ky * p.kw + kx);
+                        }
+                }
+                xmask[i] = mask;
+            } else {
+                xoff[i] = m < p.M ? (unsigned)((long long)m * p.lda * 2) + csrc : OOB;
+                xmask[i] = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            const int r = r0 + 32 * i;
+            const int n = tile_n * BN + r;
+            const unsigned csrc = (unsigned)(chunk ^ ((r >> 1) & 7)) * 16u;
+            woff[i] = n < p.N ? (unsigned)((long long)n * p.ldw * 2) + csrc : OOB;
+        }
+        tap = 0; ci0 = 0; tap_off = 0; tky = 0; tkx = 0;
+    };
+
+    // issue the DMA of K-step kt of the load tile into LDS buffer `buf`
+    auto load_tile = [&](int kt, int buf) {
+        half_t* dx = sX + buf * BM * BK + wave * 8 * BK;
+        half_t* dw = sW + buf * BN * BK + wave * 8 * BK;
+        if (CONV) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ok = (xmask[i] >> tap) & 1u;
+                const unsigned v = ok ? xoff[i] + tap_off : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + 32 * i * BK), 16, v, 0, 0, 0);
+            }
+            ci0 += BK;                                   // advance the (block-uniform) K walker
+            tap_off += BK * 2;
+            if (ci0 == p.cin) {
+                ci0 = 0;
+                ++tap;
+                if (++tkx == p.kw) { tkx = 0; ++tky; }
+                tap_off = (unsigned)((tky * p.in_w + tkx) * (int)p.lda * 2);
+            }
+        } else {
+            const unsigned soff = (unsigned)kt * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + 32 * i * BK), 16, xoff[i], soff, 0, 0);
+        }
+        const unsigned soffw = (unsigned)kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(dw + 32 * i * BK), 16, woff[i], soffw, 0, 0);
+    };
+
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    f4 acc[NFRAG][4];
+#pragma unroll
+    for (int a = 0; a < NFRAG; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    int ltile = blockIdx.x, lkt = 0;
+    int ctile = blockIdx.x, ckt = 0;
+    int tile_m, tile_n;
+    tile_coords(ctile, ntiles, p.tiles_n, tile_m, tile_n);
+    init_load(ltile);
+    load_tile(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70 | 0);   // vmcnt(0) (lgkmcnt/expcnt untouched): first tile landed in LDS
+    __syncthreads();
+    int cur = 0;
+    const int flags = p.flags;
+    for (;;) {
+        if (++lkt == nk) {
+            lkt = 0;
+            ltile += G;
+            if (ltile < ntiles) init_load(ltile);
+        }
+        const bool more = ltile < ntiles;
+        if (more) load_tile(lkt, cur ^ 1);        // async: lands in the other buffer while this one is consumed
+        const half_t* cx = sX + cur * BM * BK;
+        const half_t* cw = sW + cur * BN * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 wf[NFRAG], xf[4];
+#pragma unroll
+            for (int a = 0; a < NFRAG; ++a)
+                wf[a] = *reinterpret_cast<const h8*>(cw + lds_off(wn * (BN / 2) + a * 16 + lr, kk * 4 + lg));
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(wm * 64 + b * 16 + lr, kk * 4 + lg));
+#pragma unroll
+            for (int a = 0; a < NFRAG; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+        if (ckt == nk - 1) {
+            // ---- epilogue: acc[a][b][r] = out[m][n], m = tile_m*BM + wm*64 + b*16 + lr, n = tile_n*BN + wn*(BN/2) + a*16 + lg*4 + r
+            const int mbase = tile_m * BM + wm * 64 + lr;
+            const int nbase = tile_n * BN + wn * (BN / 2) + lg * 4;
+            if (GEGLU) {
+                f4 bx[NFRAG / 2 + 1], bg[NFRAG / 2 + 1];
+#pragma unroll
+                for (int a = 0; a < NFRAG / 2; ++a) {
+                    const int nx = min(nbase + a * 16, p.N - 36);
+                    bx[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nx) : f4{0.f, 0.f, 0.f, 0.f};
+                    bg[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nx + 32) : f4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int m = mbase + b * 16;
+#pragma unroll
+                    for (int a = 0; a < NFRAG / 2; ++a) {
+                        const int nx = nbase + a * 16;                                          // packed-space column of x
+                        const int j = tile_n * (BN / 2) + wn * (BN / 4) + a * 16 + lg * 4;      // output column
+                        half_t o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xv = acc[a][b][r] * p.alpha + bx[a][r];
+                            const float gv = acc[a + NFRAG / 2][b][r] * p.alpha + bg[a][r];
+                            o[r] = (half_t)(xv * gelu_erf(gv));
+                        }
+                        if (m < p.M && nx + 36 <= p.N)
+                            *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + j) = h4{o[0], o[1], o[2], o[3]};
+                    }
+                }
+            } else {
+                h4 rr[NFRAG][4];
+                f4 bv[NFRAG];
+                if (flags & VCX_GEMM_RESIDUAL) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int mc = min(mbase + b * 16, p.M - 1);
+#pragma unroll
+                        for (int a = 0; a < NFRAG; ++a)
+                            rr[a][b] = *reinterpret_cast<const h4*>(p.R + (int64_t)mc * p.ldr + min(nbase + a * 16, p.N - 4));
+                    }
+                }
+                if (flags & VCX_GEMM_BIAS_N) {
+#pragma unroll
+                    for (int a = 0; a < NFRAG; ++a) bv[a] = *reinterpret_cast<const f4*>(p.bias + min(nbase + a * 16, p.N - 4));
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int m = mbase + b * 16;
+                    const int mc = min(m, p.M - 1);
+                    const float bm = (flags & VCX_GEMM_BIAS_M) ? p.bias[mc] : 0.f;
+                    const float* radd = (flags & VCX_GEMM_ROWADD) ? p.rowadd + (int64_t)(mc / p.rowadd_div) * p.N : nullptr;
+#pragma unroll
+                    for (int a = 0; a < NFRAG; ++a) {
+                        const int n0 = nbase + a * 16;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + bm;
+                        if (flags & VCX_GEMM_BIAS_N) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += bv[a][r];
+                        }
+                        if (radd) {
+                            const f4 rv = *reinterpret_cast<const f4*>(radd + min(n0, p.N - 4));
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                        }
+                        if (flags & VCX_GEMM_RESIDUAL) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[a][b][r];
+                        }
+                        if (m < p.M && n0 < p.N) {
+                            if (OUT_F32)
+                                *reinterpret_cast<f4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n0) = f4{v[0], v[1], v[2], v[3]};
+                            else
+                                *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n0) =
+                                    h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < NFRAG; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        // the DMA of the next K-step must have landed, and every wave must be done reading `cur`, before the roles swap
+        __builtin_amdgcn_s_waitcnt(0x0f70 | 0);
+        __syncthreads();
+        cur ^= 1;
+        if (++ckt == nk) {
+            ckt = 0;
+            ctile += G;
+            if (ctile >= ntiles) break;
+            tile_coords(ctile, ntiles, p.tiles_n, tile_m, tile_n);
+        }
+    }
+#endif
+}
+
+template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
+int launch(const GemmArgs& a, hipStream_t s) {
+    constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+    static bool attr_set = false;
+    auto kern = gemm_dma_kernel<BN, CONV, GEGLU, OUT_F32>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+            vcx_set_error("vcx_gemm_f16(dma): cannot reserve %zu bytes of LDS", smem);
+            return VCX_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const bool conv = CONV;
+    const unsigned long long a_ext = conv ? 2ull * (unsigned long long)(a.M / (a.out_h * a.out_w)) * a.in_h * a.in_w * a.lda
+                                          : 2ull * ((unsigned long long)(a.M - 1) * a.lda + a.K);
+    const unsigned long long w_ext = 2ull * ((unsigned long long)(a.N - 1) * a.ldw + a.K);
+    const int nb = persistent_grid(a.tiles_m * a.tiles_n);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(NTHREADS), smem, s, a, (unsigned)a_ext, (unsigned)w_ext);
+    return vcx_check_launch("vcx_gemm_f16(dma)");
+}
+
+template <int BN>
+int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) {
+    if (geglu) return conv ? launch<BN, true, true, false>(a, s) : launch<BN, false, true, false>(a, s);
+    if (f32) return conv ? launch<BN, true, false, true>(a, s) : launch<BN, false, false, true>(a, s);
+    return conv ? launch<BN, true, false, false>(a, s) : launch<BN, false, false, false>(a, s);
+}
+
+}  // namespace
+
+int vcxgemm::launch_dma(const GemmArgs& a, int bn, bool conv, bool geglu, bool f32, hipStream_t s) {
+    return bn == 160 ? dispatch<160>(a, conv, geglu, f32, s) : dispatch<128>(a, conv, geglu, f32, s);
+}
