@@ -1,0 +1,42 @@
+"""Quick A/B of the GEMM engine on representative problems of one UNet forward (prints ms and TF/s)."""
+import math, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from viewcrafter_amd import ops
+from viewcrafter_amd.packing import pack_conv, pack_geglu
+dev = "cuda"
+
+def timeit(fn, iters=8):
+    fn(); fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+def rh(*s, sc=1.0): return (torch.randn(*s, device=dev) * sc).half()
+
+cases = []
+def conv(C, h, w, n=50, ups=0, name=None):
+    x = rh(n, h, w, C); wt = pack_conv(rh(C, C, 3, 3, sc=1 / math.sqrt(9 * C))); b = torch.randn(C, device=dev)
+    fl = 2 * n * (h << ups) * (w << ups) * C * C * 9
+    cases.append((name or f"conv3x3 C={C} {h}x{w}{' ups' if ups else ''}", lambda: ops.conv2d(x, wt, b, kh=3, kw=3, ups=ups), fl))
+def lin(M, N, K, res=False, name=None):
+    x = rh(M, K); wt = rh(N, K, sc=1 / math.sqrt(K)); b = torch.randn(N, device=dev); r = rh(M, N) if res else None
+    cases.append((name or f"linear {M}x{N}x{K}{' +res' if res else ''}", lambda: ops.linear(x, wt, b, residual=r), 2 * M * N * K))
+def geglu(M, C):
+    x = rh(M, C); wp, bp = pack_geglu(torch.randn(8 * C, C, device=dev) / math.sqrt(C), torch.randn(8 * C, device=dev)); wp = wp.half()
+    cases.append((f"geglu {M}x{8*C}x{C}", lambda: ops.linear(x, wp, bp, geglu=True), 2 * M * 8 * C * C))
+def tconv(C, P, T=25, B=2):
+    x = rh(B, T, P, C); wt = pack_conv(rh(C, C, 3, 1, 1, sc=1 / math.sqrt(3 * C))); b = torch.randn(C, device=dev)
+    cases.append((f"tconv C={C} P={P}", lambda: ops.temporal_conv3(x, wt, b), 2 * B * T * P * C * C * 3))
+
+conv(320, 72, 128); conv(640, 36, 64); conv(1280, 18, 32); conv(640, 36, 64, ups=1)
+tconv(320, 9216); tconv(1280, 576)
+lin(460800, 320, 320, res=True); lin(460800, 960, 320); lin(460800, 320, 1280, res=True)
+lin(115200, 640, 640, res=True); lin(28800, 1280, 5120, res=True); lin(28800, 3840, 1280)
+geglu(460800, 320); geglu(115200, 640); geglu(28800, 1280)
+tot = 0
+for name, fn, fl in cases:
+    ms = timeit(fn); tot += ms
+    print(f"{name:34s} {ms:8.3f} ms {fl/ms/1e9:8.0f} TF/s")
+print(f"sum {tot:.3f} ms")

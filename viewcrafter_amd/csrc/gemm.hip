@@ -448,6 +448,8 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const int bn = use160 ? 160 : 128;
     a.tiles_m = (d->M + BM - 1) / BM;
     a.tiles_n = (d->N + bn - 1) / bn;
+    static const int tune = []() { const char* e = getenv("VCX_GEMM_TUNE"); return e ? atoi(e) : 0; }();
+    a.tune = tune;
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * (double)d->N * d->K;
     const double bytes = 2.0 * ((double)d->M * d->K / (conv ? d->kh * d->kw : 1) + (double)d->N * d->K + (double)d->M * d->N);

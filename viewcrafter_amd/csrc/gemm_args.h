@@ -23,6 +23,7 @@ struct GemmArgs {
     int flags;
     float alpha;
     int tiles_m, tiles_n;
+    int tune;   // experiment bits from $VCX_GEMM_TUNE (0 in production)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {

@@ -3,15 +3,16 @@
 
 namespace {
 
-constexpr int MAXC = 4096;  // LDS table limit for groupnorm_apply
+constexpr int MAXC = 4096;  // C/8 * pixel lanes must fit one block (<= 512 threads)
 
 // ---------------------------------------------------------------------------------------
-// GroupNorm statistics: x [n_outer][pixels][C].  grid = (chunks, n_outer); a block reduces a
-// contiguous pixel range.  Thread t owns channel chunk (t % CW) (8 channels = one 16-byte
-// load) and pixel lane (t / CW), so a wave reads whole pixel rows back to back.
+// GroupNorm.  x [n_outer][pixels][C].  grid = (chunks, n_outer); a block owns a contiguous pixel range.  Both kernels use
+// the same thread map: thread t owns the 16-byte channel chunk (t % CW) and pixel lane (t / CW) with CW = C/8 and
+// blockDim = CW * PL, so a wave reads whole pixel rows back to back, the per-channel constants (8 partial sums /
+// 8 scale+shift pairs) live in registers, and the pixel loop is 4-way unrolled to keep four 16-byte loads in flight.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ stats,
-                                                       int64_t pixels, int C, int groups, int64_t pix_per_block) {
+__global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int64_t pixels, int C, int groups,
+                                int64_t pix_per_block, int cw, int pl) {
     __shared__ float gsum[64], gsq[64];
     const int tid = threadIdx.x;
     if (tid < 64) { gsum[tid] = 0.f; gsq[tid] = 0.f; }
@@ -19,45 +20,53 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const half_t* __restrict_
     const int n = blockIdx.y;
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = (p0 + pix_per_block < pixels) ? p0 + pix_per_block : pixels;
-    const int nc8 = C >> 3;
-    const int cw = nc8 < 256 ? nc8 : 256;
-    const int pl = 256 / cw;
     const int cpg = C / groups;
-    const half_t* xn = x + (int64_t)n * pixels * C;
-    if (tid < cw * pl) {
-        const int plane = tid / cw;
-        for (int c8 = tid % cw; c8 < nc8; c8 += cw) {
-            float s[8], ss[8];
+    const int c8 = tid % cw, plane = tid / cw;
+    const half_t* xp = x + ((int64_t)n * pixels) * C + c8 * 8;
+    float s[8], ss[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-            for (int64_t pix = p0 + plane; pix < p1; pix += pl) {
-                const h8 v = *reinterpret_cast<const h8*>(xn + pix * C + c8 * 8);
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    int64_t pix = p0 + plane;
+    const int64_t step = pl;
+    for (; pix + 3 * step < p1; pix += 4 * step) {
+        h8 v[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v[e];
-                    s[e] += f;
-                    ss[e] += f * f;
-                }
-            }
-            // fold the 8 channels into their groups (consecutive channels mostly share one)
-            int gcur = (c8 * 8) / cpg;
-            float as = 0.f, aq = 0.f;
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8*>(xp + (pix + u * step) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int ge = (c8 * 8 + e) / cpg;
-                if (ge != gcur) {
-                    atomicAdd(&gsum[gcur], as);
-                    atomicAdd(&gsq[gcur], aq);
-                    as = aq = 0.f;
-                    gcur = ge;
-                }
-                as += s[e];
-                aq += ss[e];
+                const float f = (float)v[u][e];
+                s[e] += f;
+                ss[e] += f * f;
             }
-            atomicAdd(&gsum[gcur], as);
-            atomicAdd(&gsq[gcur], aq);
+    }
+    for (; pix < p1; pix += step) {
+        const h8 v = *reinterpret_cast<const h8*>(xp + pix * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            s[e] += f;
+            ss[e] += f * f;
         }
     }
+    // fold the 8 channels into their groups (consecutive channels mostly share one)
+    int gcur = (c8 * 8) / cpg;
+    float as = 0.f, aq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ge = (c8 * 8 + e) / cpg;
+        if (ge != gcur) {
+            atomicAdd(&gsum[gcur], as);
+            atomicAdd(&gsq[gcur], aq);
+            as = aq = 0.f;
+            gcur = ge;
+        }
+        as += s[e];
+        aq += ss[e];
+    }
+    atomicAdd(&gsum[gcur], as);
+    atomicAdd(&gsq[gcur], aq);
     __syncthreads();
     if (tid < groups) {
         atomicAdd(&stats[((int64_t)n * groups + tid) * 2 + 0], gsum[tid]);
@@ -65,88 +74,134 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const half_t* __restrict_
     }
 }
 
-__global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
-                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int64_t pixels, int C, int groups,
-                                                       float eps, int silu, int64_t pix_per_block) {
-    __shared__ float sc[MAXC], sh[MAXC];
+__global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int64_t pixels, int C,
+                                int groups, float eps, int silu, int64_t pix_per_block, int cw, int pl) {
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int cpg = C / groups;
     const float cnt = (float)((double)pixels * cpg);
-    for (int c = tid; c < C; c += 256) {
+    const int c8 = tid % cw, plane = tid / cw;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c8 * 8 + e;
         const int g = c / cpg;
         const float su = stats[((int64_t)n * groups + g) * 2 + 0];
         const float sq = stats[((int64_t)n * groups + g) * 2 + 1];
         const float mean = su / cnt;
         float var = sq / cnt - mean * mean;
         var = var > 0.f ? var : 0.f;
-        const float rstd = rsqrtf(var + eps);
-        const float a = rstd * gamma[c];
-        sc[c] = a;
-        sh[c] = beta[c] - mean * a;
+        const float a = rsqrtf(var + eps) * gamma[c];
+        sc[e] = a;
+        sh[e] = beta[c] - mean * a;
     }
-    __syncthreads();
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = (p0 + pix_per_block < pixels) ? p0 + pix_per_block : pixels;
-    const int nc8 = C >> 3;
-    const int64_t total = (p1 - p0) * nc8;
-    const half_t* xn = x + ((int64_t)n * pixels + p0) * C;
-    half_t* yn = y + ((int64_t)n * pixels + p0) * C;
-    for (int64_t i = tid; i < total; i += 256) {
-        const int c0 = (int)(i % nc8) * 8;
-        h8 v = *reinterpret_cast<const h8*>(xn + i * 8);
+    const half_t* xp = x + ((int64_t)n * pixels) * C + c8 * 8;
+    half_t* yp = y + ((int64_t)n * pixels) * C + c8 * 8;
+    const int64_t step = pl;
+    int64_t pix = p0 + plane;
+    for (; pix + 3 * step < p1; pix += 4 * step) {
+        h8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8*>(xp + (pix + u * step) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[u][e] * sc[e] + sh[e];
+                if (silu) f = vcx_silu(f);
+                v[u][e] = (half_t)f;
+            }
+            *reinterpret_cast<h8*>(yp + (pix + u * step) * C) = v[u];
+        }
+    }
+    for (; pix < p1; pix += step) {
+        h8 v = *reinterpret_cast<const h8*>(xp + pix * C);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = (float)v[e] * sc[c0 + e] + sh[c0 + e];
+            float f = (float)v[e] * sc[e] + sh[e];
             if (silu) f = vcx_silu(f);
             v[e] = (half_t)f;
         }
-        *reinterpret_cast<h8*>(yn + i * 8) = v;
+        *reinterpret_cast<h8*>(yp + pix * C) = v;
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, two-pass statistics (mean, then centred variance) as torch
-// computes them; the row is re-read from L1/L2 rather than held in registers.
+// LayerNorm: LPR lanes per row (8..64, chosen so a lane holds <= 4 chunks of 8 channels), the row stays in registers:
+// one HBM read, mean then centred variance from the registers (as torch computes them), one HBM write.
 // ---------------------------------------------------------------------------------------
+template <int LPR, int CPL>
 __global__ void __launch_bounds__(256) layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int64_t rows, int C, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const half_t* xr = x + row * C;
-    half_t* yr = y + row * C;
+    constexpr int RPB = 256 / LPR;                 // rows per block
+    const int sub = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool rvalid = row < rows;
     const int nc8 = C >> 3;
+    const half_t* xr = x + (rvalid ? row : 0) * C;
+    h8 v[CPL];
     float s = 0.f;
-    for (int c = lane; c < nc8; c += 64) {
-        const h8 v = *reinterpret_cast<const h8*>(xr + c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += (float)v[e];
+    for (int j = 0; j < CPL; ++j) {
+        const int c = sub + j * LPR;
+        if (c < nc8) {
+            v[j] = *reinterpret_cast<const h8*>(xr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[j][e];
+        }
     }
-    const float mean = vcx_wave_sum(s) / (float)C;
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
     float q = 0.f;
-    for (int c = lane; c < nc8; c += 64) {
-        const h8 v = *reinterpret_cast<const h8*>(xr + c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float d = (float)v[e] - mean;
-            q += d * d;
+    for (int j = 0; j < CPL; ++j) {
+        if (sub + j * LPR < nc8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)v[j][e] - mean;
+                q += d * d;
+            }
         }
     }
-    const float rstd = rsqrtf(vcx_wave_sum(q) / (float)C + eps);
-    for (int c = lane; c < nc8; c += 64) {
-        h8 v = *reinterpret_cast<const h8*>(xr + c * 8);
-        const f4 g0 = *reinterpret_cast<const f4*>(gamma + c * 8), g1 = *reinterpret_cast<const f4*>(gamma + c * 8 + 4);
-        const f4 b0 = *reinterpret_cast<const f4*>(beta + c * 8), b1 = *reinterpret_cast<const f4*>(beta + c * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = (half_t)(((float)v[e] - mean) * rstd * g0[e] + b0[e]);
-            v[e + 4] = (half_t)(((float)v[e + 4] - mean) * rstd * g1[e] + b1[e]);
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!rvalid) return;
+    half_t* yr = y + row * C;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int c = sub + j * LPR;
+        if (c < nc8) {
+            const f4 g0 = *reinterpret_cast<const f4*>(gamma + c * 8), g1 = *reinterpret_cast<const f4*>(gamma + c * 8 + 4);
+            const f4 b0 = *reinterpret_cast<const f4*>(beta + c * 8), b1 = *reinterpret_cast<const f4*>(beta + c * 8 + 4);
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (half_t)(((float)v[j][e] - mean) * rstd * g0[e] + b0[e]);
+                o[e + 4] = (half_t)(((float)v[j][e + 4] - mean) * rstd * g1[e] + b1[e]);
+            }
+            *reinterpret_cast<h8*>(yr + c * 8) = o;
         }
-        *reinterpret_cast<h8*>(yr + c * 8) = v;
     }
+}
+
+template <int LPR, int CPL>
+void launch_ln(const half_t* x, half_t* y, const float* g, const float* b, int64_t rows, int C, float eps, hipStream_t s) {
+    constexpr int RPB = 256 / LPR;
+    hipLaunchKernelGGL((layernorm_kernel<LPR, CPL>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, x, y, g, b, rows, C, eps);
+}
+
+// thread geometry shared by the two GroupNorm kernels: cw channel chunks x pl pixel lanes, ~320 threads
+void gn_geometry(int C, int& cw, int& pl) {
+    cw = C >> 3;
+    pl = 320 / cw;
+    if (pl < 1) pl = 1;
+    while (cw * pl > 512) --pl;
 }
 
 int64_t pick_pix_per_block(int n_outer, int64_t pixels) {
@@ -175,7 +230,9 @@ extern "C" int vcx_groupnorm_stats_f16(const void* x, float* stats, int n_outer,
     }
     const int64_t ppb = pick_pix_per_block(n_outer, pixels);
     dim3 grid((unsigned)((pixels + ppb - 1) / ppb), n_outer);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, (const half_t*)x, stats, pixels, C, groups, ppb);
+    int cw, pl;
+    gn_geometry(C, cw, pl);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(cw * pl), 0, s, (const half_t*)x, stats, pixels, C, groups, ppb, cw, pl);
     return vcx_check_launch("vcx_groupnorm_stats_f16");
 }
 
@@ -190,8 +247,10 @@ extern "C" int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stat
     VcxProfScope prof(VCX_FAM_GN, s, 0.0, 4.0 * n_outer * (double)pixels * C);
     const int64_t ppb = pick_pix_per_block(n_outer, pixels);
     dim3 grid((unsigned)((pixels + ppb - 1) / ppb), n_outer);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, s, (const half_t*)x, (half_t*)y, stats, gamma, beta, pixels, C,
-                       groups, eps, silu, ppb);
+    int cw, pl;
+    gn_geometry(C, cw, pl);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(cw * pl), 0, s, (const half_t*)x, (half_t*)y, stats, gamma, beta, pixels, C,
+                       groups, eps, silu, ppb, cw, pl);
     return vcx_check_launch("vcx_groupnorm_apply_f16");
 }
 
@@ -201,11 +260,22 @@ extern "C" int vcx_layernorm_f16(const void* x, void* y, const float* gamma, con
     VCX_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "vcx_layernorm_f16: need C %% 8 == 0 (C=%d)", C);
     VCX_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
                 "vcx_layernorm_f16: pointers must be 16-byte aligned");
-    const int64_t nblk = (rows + 3) / 4;
-    VCX_REQUIRE(nblk < (1ll << 31), "vcx_layernorm_f16: too many rows");
+    VCX_REQUIRE(rows < (1ll << 31) && C <= 8192, "vcx_layernorm_f16: too many rows or C > 8192");
     hipStream_t s = (hipStream_t)stream;
     VcxProfScope prof(VCX_FAM_LN, s, 0.0, 4.0 * rows * (double)C);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const half_t*)x, (half_t*)y, gamma, beta,
-                       rows, C, eps);
+    const half_t* xp = (const half_t*)x;
+    half_t* yp = (half_t*)y;
+    const int nc8 = C >> 3;
+    if (nc8 <= 8) launch_ln<8, 1>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 16) launch_ln<8, 2>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 32) launch_ln<16, 2>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 48) launch_ln<16, 3>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 64) launch_ln<16, 4>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 96) launch_ln<32, 3>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 128) launch_ln<32, 4>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 192) launch_ln<64, 3>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 256) launch_ln<64, 4>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 512) launch_ln<64, 8>(xp, yp, gamma, beta, rows, C, eps, s);
+    else launch_ln<64, 16>(xp, yp, gamma, beta, rows, C, eps, s);
     return vcx_check_launch("vcx_layernorm_f16");
 }
