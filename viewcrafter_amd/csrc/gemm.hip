@@ -347,15 +347,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
 }
 
 }  // namespace
-int vcxgemm::persistent_grid(int ntiles) {
-    static int slots = 0;   // resident blocks chip-wide at 2 blocks/CU (LDS- and VGPR-limited)
-    if (slots == 0) {
-        int dev = 0, cus = 256;
+int vcxgemm::persistent_grid(int ntiles, int blocks_per_cu) {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
         hipDeviceProp_t prop;
+        ncu = 256;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-        slots = 2 * cus;
+            ncu = prop.multiProcessorCount;
     }
+    const int slots = blocks_per_cu * ncu;   // resident blocks chip-wide (LDS- and VGPR-limited)
     if (ntiles <= slots) return ntiles;
     const int rounds = (ntiles + slots - 1) / slots;          // balance: every block gets rounds or rounds-1 tiles
     int g = (ntiles + rounds - 1) / rounds;
@@ -450,6 +451,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.tiles_n = (d->N + bn - 1) / bn;
     static const int tune = []() { const char* e = getenv("VCX_GEMM_TUNE"); return e ? atoi(e) : 0; }();
     a.tune = tune;
+    a.m_begin = 0;
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * (double)d->N * d->K;
     const double bytes = 2.0 * ((double)d->M * d->K / (conv ? d->kh * d->kw : 1) + (double)d->N * d->K + (double)d->M * d->N);
@@ -460,8 +462,47 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const unsigned long long a_ext = conv ? 2ull * (unsigned long long)(d->M / (d->out_h * d->out_w)) * d->in_h * d->in_w * d->lda
                                           : 2ull * ((unsigned long long)(d->M - 1) * d->lda + d->K);
     const unsigned long long w_ext = 2ull * ((unsigned long long)(d->N - 1) * d->ldw + d->K);
-    const bool dma_ok = dma_enabled && d->K % 64 == 0 && d->N % 4 == 0 && (!conv || (d->cin % 64 == 0 && d->ups == 0)) &&
+    const bool dma_ok = dma_enabled && d->K % 64 == 0 && d->N % 4 == 0 && (!conv || d->cin % 64 == 0) &&
                         a_ext < lim && w_ext < lim && (!geglu || d->N >= 64);
-    if (dma_ok) return launch_dma(a, bn, conv, geglu, f32, s);
+    if (dma_ok) {
+        // tile choice: the large (256-row, 8-wave) tiles halve the LDS traffic per MFMA but need >= ~1.5 waves of 256 tiles
+        static const int force = []() { const char* e = getenv("VCX_GEMM_CFG"); return e ? atoi(e) : -1; }();
+        int cfg = use160 ? 1 : 0;
+        const int big_bn = (d->N % 320 == 0 && !geglu) ? 320 : ((d->N % 256 == 0 || d->N >= 1024) ? 256 : 0);
+        if (big_bn) {
+            const long long tiles = (long long)((d->M + 255) / 256) * ((d->N + big_bn - 1) / big_bn);
+            if (tiles >= 384) cfg = big_bn == 320 ? 3 : 2;
+        }
+        if (force >= 0 && !(geglu && (force == 1 || force == 3))) cfg = force;
+        const int tbm = cfg >= 2 ? 256 : 128, tbn = cfg == 0 ? 128 : cfg == 1 ? 160 : cfg == 2 ? 256 : 320;
+        a.tiles_m = (d->M + tbm - 1) / tbm;
+        a.tiles_n = (d->N + tbn - 1) / tbn;
+        if (cfg >= 2) {
+            // Large tiles run one block per CU: a partial last round of 256-row tiles costs a full tile time.  When the
+            // remainder is small, finish the full rounds with large tiles and hand the tail rows to the small-tile config.
+            const int slots = persistent_grid(1 << 30, 1);
+            const long long tiles = (long long)a.tiles_m * a.tiles_n;
+            const long long full = tiles / slots, rem = tiles % slots;
+            if (full >= 1 && rem > 0 && rem * 10 < slots * 7) {
+                const int tm1 = (int)(full * slots / a.tiles_n);
+                const int m1 = tm1 * 256;
+                if (m1 > 0 && m1 < d->M) {
+                    GemmArgs b = a;
+                    b.M = m1;
+                    b.tiles_m = tm1;
+                    int rc = launch_dma(b, cfg, conv, geglu, f32, s);
+                    if (rc) return rc;
+                    GemmArgs c = a;
+                    const int scfg = (geglu || d->N % 160 != 0) ? 0 : 1;
+                    const int sbn = scfg ? 160 : 128;
+                    c.m_begin = m1;
+                    c.tiles_m = (d->M - m1 + 127) / 128;
+                    c.tiles_n = (d->N + sbn - 1) / sbn;
+                    return launch_dma(c, scfg, conv, geglu, f32, s);
+                }
+            }
+        }
+        return launch_dma(a, cfg, conv, geglu, f32, s);
+    }
     return use160 ? dispatch<160>(a, conv, geglu, f32, s) : dispatch<128>(a, conv, geglu, f32, s);
 }

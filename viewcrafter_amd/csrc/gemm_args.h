@@ -23,6 +23,7 @@ struct GemmArgs {
     int flags;
     float alpha;
     int tiles_m, tiles_n;
+    int m_begin;   // first output row of this launch (tail split of large-tile launches); rows are < M
     int tune;   // experiment bits from $VCX_GEMM_TUNE (0 in production)
 };
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
     tm = vid / tiles_n;
 }
 
-int persistent_grid(int ntiles);
-int launch_dma(const GemmArgs& a, int bn, bool conv, bool geglu, bool f32, hipStream_t s);
+int persistent_grid(int ntiles, int blocks_per_cu = 2);
+int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);
 
 }  // namespace vcxgemm

@@ -24,14 +24,32 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned OOB = 0xFFFFFFFFu;   // voffset beyond any descriptor's num_records -> the load returns zeros
 
-template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsigned a_bytes, unsigned w_bytes) {
+// Tile configuration: block tile TBM x TBN, NWM x NWN waves, each wave owns (TBM/NWM) x (TBN/NWN) outputs.
+//   small : 128 x {128,160}, 2x2 waves (64 x {64,80} per wave), 2 blocks/CU      - few tiles / small M
+//   large : 256 x {256,320}, 2x4 waves (128 x {64,80} per wave), 1 block/CU      - LDS bytes per MFMA drop from ~690 to
+//           ~450 (DMA writes 230 -> 115-128, fragment reads 461 -> 333-384): the small tile is LDS-bandwidth bound
+//           (profiles/r01_gemm_experiments.md: removing the DMA gives +25 %, removing barriers or DMA waits nothing).
+template <int TBM_, int TBN_, int NWM_, int NWN_>
+struct TileCfg {
+    static constexpr int TBM = TBM_, TBN = TBN_, NWM = NWM_, NWN = NWN_;
+    static constexpr int THREADS = 64 * NWM * NWN;
+    static constexpr int MF = TBM / NWM / 16;      // 16-row activation fragments per wave
+    static constexpr int NF = TBN / NWN / 16;      // 16-col weight fragments per wave
+    static constexpr int XROWS = TBM * 8 / THREADS;   // DMA instructions per thread for the activation tile
+    static constexpr int WROWS = TBN * 8 / THREADS;
+    static constexpr int RSTEP = THREADS / 8;         // tile rows covered by one DMA instruction of the block
+    static constexpr size_t SMEM = (size_t)2 * (TBM + TBN) * BK * sizeof(half_t);
+};
+
+template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32>
+__global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the body uses device-only types)
-    constexpr int NFRAG = BN / 32;
-    constexpr int WROWS = BN / 32;
+    constexpr int TBM = Cfg::TBM, BN = Cfg::TBN;
+    constexpr int NFRAG = Cfg::NF, MFRAG = Cfg::MF;
+    constexpr int WROWS = Cfg::WROWS, XROWS = Cfg::XROWS, RSTEP = Cfg::RSTEP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    half_t* sX = reinterpret_cast<half_t*>(smem_raw);              // [2][BM*BK]
-    half_t* sW = sX + 2 * BM * BK;                                  // [2][BN*BK]
+    half_t* sX = reinterpret_cast<half_t*>(smem_raw);              // [2][TBM*BK]
+    half_t* sW = sX + 2 * TBM * BK;                                 // [2][BN*BK]
 
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.W), 0, (int)w_bytes, 0x00020000);
@@ -45,8 +63,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
     const int r0 = tid >> 3;     // tile row of this thread's first DMA instruction
 
     // ---- per-thread source offsets (bytes) of the tile being loaded
-    unsigned xoff[4];            // activation rows; OOB when the row is beyond M (linear mode)
-    unsigned xmask[4];           // conv: bit t set <=> tap t of this row is inside the image
+    unsigned xoff[XROWS];        // activation rows; OOB when the row is beyond M (linear mode)
+    unsigned xmask[XROWS];       // conv: bit t set <=> tap t of this row is inside the image
     unsigned woff[WROWS];        // weight rows; OOB when beyond N
     int tap = 0, ci0 = 0;        // conv K walker (block-uniform): k = tap*cin + ci0
     unsigned tap_off = 0;        // conv: byte offset of (tap, ci0) relative to the row's (ky=0, kx=0, c=0) pixel
@@ -55,9 +73,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
         int tile_m, tile_n;
         tile_coords(t, ntiles, p.tiles_n, tile_m, tile_n);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + 32 * i;
-            const int m = tile_m * BM + r;
+        for (int i = 0; i < XROWS; ++i) {
+            const int r = r0 + RSTEP * i;
+            const int m = p.m_begin + tile_m * TBM + r;
             const unsigned csrc = (unsigned)(chunk ^ ((r >> 1) & 7)) * 16u;   // source chunk that lands at position `chunk`
             if (CONV) {
                 const int hw = p.out_h * p.out_w;
@@ -66,18 +84,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
                 const int rem = mm - img * hw;
                 const int oy = rem / p.out_w;
                 const int ox = rem - oy * p.out_w;
+                // (iy0, ix0): tap (0,0) in the (possibly 2x nearest-upsampled) input grid; its source pixel is (iy0>>ups, ix0>>ups)
                 const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
-                const long long pix0 = ((long long)img * p.in_h + iy0) * p.in_w + ix0;   // may be negative at the border
+                const long long pix0 = ((long long)img * p.in_h + (iy0 >> p.ups)) * p.in_w + (ix0 >> p.ups);   // may be negative at the border
                 xoff[i] = (unsigned)(pix0 * p.lda * 2) + csrc;                            // wraps; valid taps un-wrap it
                 unsigned mask = 0;
                 if (m < p.M) {
+                    const int lim_h = p.in_h << p.ups, lim_w = p.in_w << p.ups;
                     for (int ky = 0; ky < p.kh; ++ky)
                         for (int kx = 0; kx < p.kw; ++kx) {
                             const int iy = iy0 + ky, ix = ix0 + kx;
-                            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) mask |= 1u << (ky * p.kw + kx);
+                            if (iy >= 0 && iy < lim_h && ix >= 0 && ix < lim_w) mask |= 1u << (ky * p.kw + kx);
                         }
                 }
-                xmask[i] = mask;
+                // bits 30/31: parity of (iy0, ix0) - with fused upsampling the source step of a tap depends on it
+                xmask[i] = mask | ((unsigned)(iy0 & 1) << 31) | ((unsigned)(ix0 & 1) << 30);
             } else {
                 xoff[i] = m < p.M ? (unsigned)((long long)m * p.lda * 2) + csrc : OOB;
                 xmask[i] = 0;
@@ -85,7 +106,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
         }
 #pragma unroll
         for (int i = 0; i < WROWS; ++i) {
-            const int r = r0 + 32 * i;
+            const int r = r0 + RSTEP * i;
             const int n = tile_n * BN + r;
             const unsigned csrc = (unsigned)(chunk ^ ((r >> 1) & 7)) * 16u;
             woff[i] = n < p.N ? (unsigned)((long long)n * p.ldw * 2) + csrc : OOB;
@@ -95,14 +116,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
 
     // issue the DMA of K-step kt of the load tile into LDS buffer `buf`
     auto load_tile = [&](int kt, int buf) {
-        half_t* dx = sX + buf * BM * BK + wave * 8 * BK;
+        half_t* dx = sX + buf * TBM * BK + wave * 8 * BK;
         half_t* dw = sW + buf * BN * BK + wave * 8 * BK;
         if (CONV) {
+            if (p.ups) {
+                // source offset of tap (ky,kx) relative to tap (0,0): ((by+ky)>>1, (bx+kx)>>1) pixels, by/bx = parity of iy0/ix0
+                const unsigned cb = (unsigned)ci0 * 2u, rowb = (unsigned)(p.in_w * (int)p.lda * 2), pixb = (unsigned)((int)p.lda * 2);
+                const unsigned y0 = (unsigned)(tky >> 1) * rowb, y1 = (unsigned)((tky + 1) >> 1) * rowb;
+                const unsigned x0 = (unsigned)(tkx >> 1) * pixb, x1 = (unsigned)((tkx + 1) >> 1) * pixb;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned ok = (xmask[i] >> tap) & 1u;
-                const unsigned v = ok ? xoff[i] + tap_off : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + 32 * i * BK), 16, v, 0, 0, 0);
+                for (int i = 0; i < XROWS; ++i) {
+                    const unsigned ok = (xmask[i] >> tap) & 1u;
+                    const unsigned oy_ = (xmask[i] >> 31) ? y1 : y0, ox_ = ((xmask[i] >> 30) & 1u) ? x1 : x0;
+                    const unsigned v = ok ? xoff[i] + oy_ + ox_ + cb : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + RSTEP * i * BK), 16, v, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < XROWS; ++i) {
+                    const unsigned ok = (xmask[i] >> tap) & 1u;
+                    const unsigned v = ok ? xoff[i] + tap_off : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + RSTEP * i * BK), 16, v, 0, 0, 0);
+                }
             }
             ci0 += BK;                                   // advance the (block-uniform) K walker
             tap_off += BK * 2;
@@ -115,23 +150,24 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
         } else {
             const unsigned soff = (unsigned)kt * (BK * 2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + 32 * i * BK), 16, xoff[i], soff, 0, 0);
+            for (int i = 0; i < XROWS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + RSTEP * i * BK), 16, xoff[i], soff, 0, 0);
         }
         const unsigned soffw = (unsigned)kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < WROWS; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(dw + 32 * i * BK), 16, woff[i], soffw, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(dw + RSTEP * i * BK), 16, woff[i], soffw, 0, 0);
     };
 
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % Cfg::NWM, wn = wave / Cfg::NWM;
     const int lr = lane & 15, lg = lane >> 4;
+    constexpr int WM = TBM / Cfg::NWM, WN = BN / Cfg::NWN;   // wave tile
 
-    f4 acc[NFRAG][4];
+    f4 acc[NFRAG][MFRAG];
 #pragma unroll
     for (int a = 0; a < NFRAG; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MFRAG; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
     int ltile = blockIdx.x, lkt = 0;
@@ -152,27 +188,27 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
         }
         const bool more = ltile < ntiles;
         if (more) load_tile(lkt, cur ^ 1);        // async: lands in the other buffer while this one is consumed
-        const half_t* cx = sX + cur * BM * BK;
+        const half_t* cx = sX + cur * TBM * BK;
         const half_t* cw = sW + cur * BN * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            h8 wf[NFRAG], xf[4];
+            h8 wf[NFRAG], xf[MFRAG];
 #pragma unroll
             for (int a = 0; a < NFRAG; ++a)
-                wf[a] = *reinterpret_cast<const h8*>(cw + lds_off(wn * (BN / 2) + a * 16 + lr, kk * 4 + lg));
+                wf[a] = *reinterpret_cast<const h8*>(cw + lds_off(wn * WN + a * 16 + lr, kk * 4 + lg));
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(wm * 64 + b * 16 + lr, kk * 4 + lg));
+            for (int b = 0; b < MFRAG; ++b)
+                xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(wm * WM + b * 16 + lr, kk * 4 + lg));
 #pragma unroll
             for (int a = 0; a < NFRAG; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < MFRAG; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
         }
         if (ckt == nk - 1) {
             // ---- epilogue: acc[a][b][r] = out[m][n], m = tile_m*BM + wm*64 + b*16 + lr, n = tile_n*BN + wn*(BN/2) + a*16 + lg*4 + r
-            const int mbase = tile_m * BM + wm * 64 + lr;
-            const int nbase = tile_n * BN + wn * (BN / 2) + lg * 4;
+            const int mbase = p.m_begin + tile_m * TBM + wm * WM + lr;
+            const int nbase = tile_n * BN + wn * WN + lg * 4;
             if (GEGLU) {
                 f4 bx[NFRAG / 2 + 1], bg[NFRAG / 2 + 1];
 #pragma unroll
@@ -182,12 +218,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
                     bg[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nx + 32) : f4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < MFRAG; ++b) {
                     const int m = mbase + b * 16;
 #pragma unroll
                     for (int a = 0; a < NFRAG / 2; ++a) {
                         const int nx = nbase + a * 16;                                          // packed-space column of x
-                        const int j = tile_n * (BN / 2) + wn * (BN / 4) + a * 16 + lg * 4;      // output column
+                        const int j = tile_n * (BN / 2) + wn * (WN / 2) + a * 16 + lg * 4;      // output column
                         half_t o[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -200,25 +236,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
                     }
                 }
             } else {
-                h4 rr[NFRAG][4];
                 f4 bv[NFRAG];
-                if (flags & VCX_GEMM_RESIDUAL) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int mc = min(mbase + b * 16, p.M - 1);
-#pragma unroll
-                        for (int a = 0; a < NFRAG; ++a)
-                            rr[a][b] = *reinterpret_cast<const h4*>(p.R + (int64_t)mc * p.ldr + min(nbase + a * 16, p.N - 4));
-                    }
-                }
                 if (flags & VCX_GEMM_BIAS_N) {
 #pragma unroll
                     for (int a = 0; a < NFRAG; ++a) bv[a] = *reinterpret_cast<const f4*>(p.bias + min(nbase + a * 16, p.N - 4));
                 }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < MFRAG; ++b) {
                     const int m = mbase + b * 16;
                     const int mc = min(m, p.M - 1);
+                    h4 rr[NFRAG];           // one 16-row group's residual loads are issued together
+                    if (flags & VCX_GEMM_RESIDUAL) {
+#pragma unroll
+                        for (int a = 0; a < NFRAG; ++a)
+                            rr[a] = *reinterpret_cast<const h4*>(p.R + (int64_t)mc * p.ldr + min(nbase + a * 16, p.N - 4));
+                    }
                     const float bm = (flags & VCX_GEMM_BIAS_M) ? p.bias[mc] : 0.f;
                     const float* radd = (flags & VCX_GEMM_ROWADD) ? p.rowadd + (int64_t)(mc / p.rowadd_div) * p.N : nullptr;
 #pragma unroll
@@ -238,7 +270,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
                         }
                         if (flags & VCX_GEMM_RESIDUAL) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[a][b][r];
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[a][r];
                         }
                         if (m < p.M && n0 < p.N) {
                             if (OUT_F32)
@@ -253,7 +285,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
 #pragma unroll
             for (int a = 0; a < NFRAG; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < MFRAG; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
         }
         // the DMA of the next K-step must have landed, and every wave must be done reading `cur`, before the roles swap
         __builtin_amdgcn_s_waitcnt(0x0f70 | 0);
@@ -269,14 +301,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(GemmArgs p, unsig
 #endif
 }
 
-template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
+template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32>
 int launch(const GemmArgs& a, hipStream_t s) {
-    constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
     static bool attr_set = false;
-    auto kern = gemm_dma_kernel<BN, CONV, GEGLU, OUT_F32>;
+    auto kern = gemm_dma_kernel<Cfg, CONV, GEGLU, OUT_F32>;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
-            vcx_set_error("vcx_gemm_f16(dma): cannot reserve %zu bytes of LDS", smem);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::SMEM) != hipSuccess) {
+            vcx_set_error("vcx_gemm_f16(dma): cannot reserve %zu bytes of LDS", Cfg::SMEM);
             return VCX_ELAUNCH;
         }
         attr_set = true;
@@ -285,20 +316,32 @@ int launch(const GemmArgs& a, hipStream_t s) {
     const unsigned long long a_ext = conv ? 2ull * (unsigned long long)(a.M / (a.out_h * a.out_w)) * a.in_h * a.in_w * a.lda
                                           : 2ull * ((unsigned long long)(a.M - 1) * a.lda + a.K);
     const unsigned long long w_ext = 2ull * ((unsigned long long)(a.N - 1) * a.ldw + a.K);
-    const int nb = persistent_grid(a.tiles_m * a.tiles_n);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(NTHREADS), smem, s, a, (unsigned)a_ext, (unsigned)w_ext);
+    const int blocks_per_cu = Cfg::SMEM > 80 * 1024 ? 1 : 2;
+    const int nb = persistent_grid(a.tiles_m * a.tiles_n, blocks_per_cu);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(Cfg::THREADS), Cfg::SMEM, s, a, (unsigned)a_ext, (unsigned)w_ext);
     return vcx_check_launch("vcx_gemm_f16(dma)");
 }
 
-template <int BN>
+template <class Cfg>
 int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) {
-    if (geglu) return conv ? launch<BN, true, true, false>(a, s) : launch<BN, false, true, false>(a, s);
-    if (f32) return conv ? launch<BN, true, false, true>(a, s) : launch<BN, false, false, true>(a, s);
-    return conv ? launch<BN, true, false, false>(a, s) : launch<BN, false, false, false>(a, s);
+    if (geglu) {
+        if constexpr (Cfg::NF % 2 == 0) return conv ? launch<Cfg, true, true, false>(a, s) : launch<Cfg, false, true, false>(a, s);
+        vcx_set_error("vcx_gemm_f16(dma): GEGLU needs an even fragment count");
+        return VCX_EINVAL;
+    }
+    if (f32) return conv ? launch<Cfg, true, false, true>(a, s) : launch<Cfg, false, false, true>(a, s);
+    return conv ? launch<Cfg, true, false, false>(a, s) : launch<Cfg, false, false, false>(a, s);
 }
 
 }  // namespace
 
-int vcxgemm::launch_dma(const GemmArgs& a, int bn, bool conv, bool geglu, bool f32, hipStream_t s) {
-    return bn == 160 ? dispatch<160>(a, conv, geglu, f32, s) : dispatch<128>(a, conv, geglu, f32, s);
+int vcxgemm::launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s) {
+    switch (cfg) {
+        case 0: return dispatch<TileCfg<128, 128, 2, 2>>(a, conv, geglu, f32, s);
+        case 1: return dispatch<TileCfg<128, 160, 2, 2>>(a, conv, geglu, f32, s);
+        case 2: return dispatch<TileCfg<256, 256, 2, 4>>(a, conv, geglu, f32, s);
+        case 3: return dispatch<TileCfg<256, 320, 2, 4>>(a, conv, geglu, f32, s);
+    }
+    vcx_set_error("vcx_gemm_f16(dma): unknown tile configuration %d", cfg);
+    return VCX_EINVAL;
 }
