@@ -1,6 +1,7 @@
 // Attention kernels for gfx950: flash attention (head dim 64) on MFMA 32x32x16 f16, temporal
 // attention over T <= 32 frames on the VALU, and an in-place row softmax.
 #include "vcx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -20,7 +21,6 @@ namespace {
 // WITHOUT any cross-lane movement by reading the V^T fragment with the same key permutation
 // (a sum over keys does not care about the order as long as P and V agree on it).
 // =======================================================================================
-constexpr int FQ = 128;  // query rows per block
 constexpr int FK = 64;   // keys per tile
 
 struct FlashArgs {
@@ -36,121 +36,154 @@ struct FlashArgs {
 
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// QB = 32-row query blocks per wave (1 or 2).  With QB = 2 every K / V^T fragment read from LDS feeds two MFMAs, which
+// halves the LDS bytes per MFMA - like the GEMM, the QB = 1 kernel is bound by LDS traffic, not by the matrix pipe.
+// K / V^T tiles go HBM -> LDS by DMA (buffer_load ... lds); rows / key columns beyond nk use an out-of-range offset and
+// arrive as zeros (masked to -inf before the softmax anyway).
+template <int QB>
 __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) half_t sK[2][64 * 64];
     __shared__ __attribute__((aligned(16))) half_t sV[2][64 * 64];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     const int lq = lane & 31, hi = lane >> 5;
     const int g = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
-    const int q0 = blockIdx.x * FQ + wave * 32;
+    const int q0 = (blockIdx.x * 4 + wave) * (32 * QB);
 
     const half_t* qbase = p.q + ((int64_t)g * p.nq) * p.ldq + h * 64;
     const int64_t kvrow0 = (int64_t)(g / p.kv_div) * p.kv_rows;
     const half_t* kbase = p.k + kvrow0 * p.ldk + h * 64;
     const half_t* vbase = p.vt + (int64_t)(h * 64) * p.ldvt + kvrow0;
+    const unsigned k_bytes = (unsigned)(((int64_t)(p.nk - 1) * p.ldk + 64) * 2);
+    const unsigned v_bytes = (unsigned)((63ll * p.ldvt + ((p.nk + 7) & ~7)) * 2);
+    const __amdgpu_buffer_rsrc_t srd_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kbase), 0, (int)k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vbase), 0, (int)v_bytes, 0x00020000);
 
     // Q fragments (B operand): lane (q = lq, hi) holds Q[q][s*16 + hi*8 .. +7]
     const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    h8 qf[4];
-    const int qrow = q0 + lq;
-    const bool qvalid = qrow < p.nq;
+    h8 qf[QB][4];
+    bool qvalid[QB];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        qf[s] = qvalid ? *reinterpret_cast<const h8*>(qbase + (int64_t)qrow * p.ldq + s * 16 + hi * 8) : zero8;
+    for (int b = 0; b < QB; ++b) {
+        const int qrow = q0 + b * 32 + lq;
+        qvalid[b] = qrow < p.nq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[b][s] = qvalid[b] ? *reinterpret_cast<const h8*>(qbase + (int64_t)qrow * p.ldq + s * 16 + hi * 8) : zero8;
+    }
 
-    // staging map: 512 chunks per tile, 2 per thread
-    const int srow = tid >> 3, schunk = tid & 7;
-    h8 kreg[2], vreg[2];
-    auto load_tile = [&](int kt) {
+    // DMA map: 512 16-byte chunks per tile and operand, 2 per thread; source chunk swizzled, LDS image lane-linear
+    const int srow = tid >> 3, spos = tid & 7;
+    unsigned koff[2], voff[2];
+    int vkey[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = srow + 32 * i;
+        const int csrc = spos ^ ((r >> 1) & 7);
+        koff[i] = (unsigned)((int64_t)r * p.ldk * 2) + csrc * 16;       // + kt*64 rows per tile
+        voff[i] = (unsigned)((int64_t)r * p.ldvt * 2) + csrc * 16;      // + kt*128 bytes per tile
+        vkey[i] = csrc * 8;                                             // first key of this V^T chunk inside the tile
+    }
+    const unsigned krow_bytes = (unsigned)(p.ldk * 2);
+    auto load_tile = [&](int kt, int buf) {
+        half_t* dk = &sK[buf][wave * 8 * 64];
+        half_t* dv = &sV[buf][wave * 8 * 64];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = srow + 32 * i;
-            const int key = kt * FK + r;
-            kreg[i] = (key < p.nk) ? *reinterpret_cast<const h8*>(kbase + (int64_t)key * p.ldk + schunk * 8) : zero8;
-            const int kc = kt * FK + schunk * 8;  // first key of this V^T chunk
-            vreg[i] = (kc < p.nk) ? *reinterpret_cast<const h8*>(vbase + (int64_t)r * p.ldvt + kc) : zero8;
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = srow + 32 * i;
-            *reinterpret_cast<h8*>(&sK[buf][tile_off(r, schunk)]) = kreg[i];
-            *reinterpret_cast<h8*>(&sV[buf][tile_off(r, schunk)]) = vreg[i];
+            const int key = kt * FK + srow + 32 * i;
+            const unsigned kv = key < p.nk ? koff[i] + (unsigned)(kt * FK) * krow_bytes : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_k, (lds_ptr_t)(dk + 32 * i * 64), 16, kv, 0, 0, 0);
+            const unsigned vv = (kt * FK + vkey[i] < p.nk) ? voff[i] + (unsigned)(kt * FK * 2) : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_v, (lds_ptr_t)(dv + 32 * i * 64), 16, vv, 0, 0, 0);
         }
     };
 
-    f16v oacc[2];
+    f16v oacc[QB][2];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
-    float m_run = -1e30f, l_run = 0.f;
+    for (int b = 0; b < QB; ++b) {
+        m_run[b] = -1e30f;
+        l_run[b] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[b][0][i] = 0.f; oacc[b][1][i] = 0.f; }
+    }
 
     const int ntiles = (p.nk + FK - 1) / FK;
-    load_tile(0);
-    store_tile(0);
+    load_tile(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < ntiles; ++kt) {
-        const bool more = kt + 1 < ntiles;
-        if (more) load_tile(kt + 1);
+        if (kt + 1 < ntiles) load_tile(kt + 1, cur ^ 1);
         const half_t* cK = sK[cur];
         const half_t* cV = sV[cur];
 
-        // ---- S^T = K Q^T for the two 32-key halves of the tile
-        f16v sacc[2];
+        // ---- S^T = K Q^T for the two 32-key halves of the tile; each K fragment feeds QB MFMAs.  The first MFMA of an
+        // accumulator takes a literal zero C operand (no per-tile v_mov zeroing of 64 registers).
+        f16v sacc[QB][2];
+        const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const h8 kf = *reinterpret_cast<const h8*>(cK + tile_off(kb * 32 + lq, s * 2 + hi));
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < QB; ++b)
+                    sacc[b][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[b][s], s == 0 ? zero16 : sacc[b][kb], 0, 0, 0);
             }
-        }
-        // ---- scale, mask the tail keys, online softmax
+        // ---- online softmax per query block in the log2 domain: p = 2^(s*c - m), one fma + one v_exp per score.
+        // Key masking exists only in the code path of a partial last tile (block-uniform branch).
         const int key_base = kt * FK;
-        const bool tail = key_base + FK > p.nk;
-        float mx = -1e30f;
+        if (key_base + FK > p.nk) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int b = 0; b < QB; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = sacc[kb][r] * p.scale_log2;
-                if (tail) {
-                    const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= p.nk) v = -1e30f;
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (key >= p.nk) sacc[b][kb][r] = -1e30f;
+                    }
+        }
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[b], mx * p.scale_log2);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+            m_run[b] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][kb][r], p.scale_log2, -m_new));
+                    sacc[b][kb][r] = pv;
+                    psum += pv;
                 }
-                sacc[kb][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
+            l_run[b] = l_run[b] * alpha + psum;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new);
-                sacc[kb][r] = pv;
-                psum += pv;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
-
-        // ---- O^T += V^T P^T
+            for (int i = 0; i < 16; ++i) { oacc[b][0][i] *= alpha; oacc[b][1][i] *= alpha; }
+        }
+        // ---- O^T += V^T P^T; each V^T fragment feeds QB MFMAs
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                h8 pf;
+                h8 pf[QB];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[kb][8 * s + j];
+                for (int b = 0; b < QB; ++b)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[b][j] = (half_t)sacc[b][kb][8 * s + j];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const int row = db * 32 + lq;
@@ -158,35 +191,40 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
                     const h4 lo = *reinterpret_cast<const h4*>(cV + tile_off(row, c0) + 4 * hi);
                     const h4 hi4 = *reinterpret_cast<const h4*>(cV + tile_off(row, c0 + 1) + 4 * hi);
                     const h8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[db], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) oacc[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[b], oacc[b][db], 0, 0, 0);
                 }
             }
-        if (more) store_tile(cur ^ 1);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
         cur ^= 1;
     }
 
     // ---- epilogue: O[q][d] = O^T[d][q] / l
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    if (qvalid) {
-        half_t* orow = p.o + ((int64_t)g * p.nq + qrow) * p.ldo + h * 64;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int b = 0; b < QB; ++b) {
+        const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32);
+        const float inv = 1.0f / l_tot;
+        if (qvalid[b]) {
+            half_t* orow = p.o + ((int64_t)g * p.nq + q0 + b * 32 + lq) * p.ldo + h * 64;
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int d0 = db * 32 + 8 * gq + 4 * hi;
-                float v[4];
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = oacc[db][gq * 4 + r] * inv;
-                if (p.accumulate) {
-                    const h4 old = *reinterpret_cast<const h4*>(orow + d0);
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int d0 = db * 32 + 8 * gq + 4 * hi;
+                    float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                    for (int r = 0; r < 4; ++r) v[r] = oacc[b][db][gq * 4 + r] * inv;
+                    if (p.accumulate) {
+                        const h4 old = *reinterpret_cast<const h4*>(orow + d0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                    }
+                    *reinterpret_cast<h4*>(orow + d0) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 }
-                *reinterpret_cast<h4*>(orow + d0) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            }
+        }
     }
+#endif
 }
 
 // =======================================================================================
@@ -350,8 +388,21 @@ extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* 
     hipStream_t s = (hipStream_t)stream;
     const double nprob = (double)n_groups * heads;
     VcxProfScope prof(VCX_FAM_FLASH, s, 4.0 * nprob * nq * (double)nk * 64, 2.0 * nprob * 64 * (2.0 * nq + 2.0 * nk));
-    dim3 grid((nq + FQ - 1) / FQ, n_groups * heads);
-    hipLaunchKernelGGL(flash_d64_kernel, grid, dim3(256), 0, s, a);
+    VCX_REQUIRE(((int64_t)(nk - 1) * ldk + 64) * 2 < 0xFFFF0000ll && (63ll * ldvt + nk + 8) * 2 < 0xFFFF0000ll,
+                "vcx_attn_flash_d64_f16: K / V^T extents per (group, head) must stay below 4 GiB");
+    // two 32-row query blocks per wave (256 rows per block) unless the row count would waste > 20 % of such blocks
+    static const int force_qb = []() { const char* e = getenv("VCX_FLASH_QB"); return e ? atoi(e) : 0; }();
+    const int blocks2 = (nq + 255) / 256;
+    bool qb2 = (double)nq / (blocks2 * 256.0) >= 0.8;
+    if (force_qb == 1) qb2 = false;
+    if (force_qb == 2) qb2 = true;
+    if (qb2) {
+        dim3 grid(blocks2, n_groups * heads);
+        hipLaunchKernelGGL(flash_d64_kernel<2>, grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((nq + 127) / 128, n_groups * heads);
+        hipLaunchKernelGGL(flash_d64_kernel<1>, grid, dim3(256), 0, s, a);
+    }
     return vcx_check_launch("vcx_attn_flash_d64_f16");
 }
 
