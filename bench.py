@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--workload", default="ViewCrafter_25_576x1024x25", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the UNet forward as a hipGraph in the timed region "
+                    "(HIP-event profiling cannot run inside a graph: the roofline is then measured on extra eager steps)")
+    ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the timed region")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,17 +139,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    unet = model.model.diffusion_model
+    unet.use_hip_graph = bool(args.graph)
+    profile_in_region = not (args.graph or args.no_profile)
     with torch.no_grad():
         for i in range(args.warmup):
             x = one_step(x, i)
         sync()
-        ops.profile_begin(1 << 16)
+        if profile_in_region:
+            ops.profile_begin(1 << 16)
         t0 = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
             x = one_step(x, i)
         sync()
         elapsed = time.perf_counter() - t0
-        prof = ops.profile_end()
+        if profile_in_region:
+            prof = ops.profile_end()
+        else:   # per-family HIP-event timing on extra eager steps of the same loop (not part of `value`)
+            unet.use_hip_graph = False
+            n_extra = min(2, n_sched - args.warmup - args.steps)
+            ops.profile_begin(1 << 16)
+            xe = x
+            for i in range(args.warmup + args.steps, args.warmup + args.steps + n_extra):
+                xe = one_step(xe, i)
+            torch.cuda.synchronize()
+            prof = ops.profile_end()
+            for v in prof.values():      # normalise to the timed region's step count
+                for k in ("launches", "ms", "flops", "bytes"):
+                    v[k] = v[k] * args.steps / max(n_extra, 1)
     assert torch.isfinite(x).all(), "non-finite latent after the timed steps"
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -159,7 +179,8 @@ def main():
         else f"DDIM steps/sec ({args.workload})",
         "value": steps_per_s, "unit": "DDIM steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16", "data": "synthetic",
+        "dtype": "f16", "data": "synthetic", "launch_mode": "hipGraph replay" if args.graph else "eager",
+        "roofline_measured_on": "the timed region" if profile_in_region else "extra eager steps after the timed region",
         "config": {"workload": args.workload, "trajectories_per_gpu": 1, "frames": T, "latent": [T, h, w],
                    "guidance": "CFG 7.5 + rescale 0.7, cond/uncond batched as B=2", "eta": 1.0,
                    "parallelism": f"trajectory-sharded x{world} (no in-step collective)"},

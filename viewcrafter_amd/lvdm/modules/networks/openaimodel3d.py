@@ -275,14 +275,19 @@ class UNetModel(PackedModule):
         nn.init.zeros_(self.out[-1].weight)
         nn.init.zeros_(self.out[-1].bias)
         self._ctx_cache = {}
+        # hipGraph replay of the whole forward (launch-bound at the small UNet levels): opt-in, see forward_graphed()
+        self.use_hip_graph = False
+        self._graphs = {}
 
     # ------------------------------------------------------------------ packing / caches
     def _drop_packed(self):
         super()._drop_packed()
         self._ctx_cache = {}
+        self._graphs = {}
 
     def _apply(self, fn, recurse=True):
         self._ctx_cache = {}
+        self._graphs = {}
         return super()._apply(fn, recurse)
 
     def _pack(self):
@@ -342,6 +347,41 @@ class UNetModel(PackedModule):
         return ops.to_f16(ops.silu_f32(emb))
 
     def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
+        if self.use_hip_graph and features_adapter is None and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            return self.forward_graphed(x, timesteps, context, fs)
+        return self._forward(x, timesteps, context=context, features_adapter=features_adapter, fs=fs, **kwargs)
+
+    def forward_graphed(self, x, timesteps, context, fs):
+        """Replay the forward as one hipGraph (captured through torch.cuda.CUDAGraph: every libvcx call is stream-ordered,
+        allocation-free and sync-free, so the ctypes launches are captured like any other kernel).  One graph per
+        (shapes, conditioning tensor); inputs are copied into static buffers, the output buffer is reused by the next
+        replay (the DDIM update consumes it first)."""
+        parts = list(x) if isinstance(x, (list, tuple)) else [x]
+        key = (tuple(tuple(p.shape) for p in parts), context.data_ptr(), context._version, tuple(context.shape),
+               None if fs is None else tuple(fs.shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            static = dict(parts=[p.detach().clone().float() for p in parts], t=timesteps.detach().clone(),
+                          fs=None if fs is None else fs.detach().clone())
+            with torch.no_grad():
+                self._forward(static["parts"], static["t"], context=context, fs=static["fs"])   # warm-up: packs, caches K/V
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self._forward(static["parts"], static["t"], context=context, fs=static["fs"])
+            if len(self._graphs) >= 4:
+                self._graphs.clear()
+            ent = self._graphs[key] = (graph, static, out, context)
+        graph, static, out, _ = ent
+        for dst, src in zip(static["parts"], parts):
+            dst.copy_(src)
+        static["t"].copy_(timesteps)
+        if fs is not None:
+            static["fs"].copy_(fs)
+        graph.replay()
+        return out
+
+    def _forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
         """x [B, in_channels, T, h, w] fp32 (or a list of tensors to be concatenated on channels, which is how
         DiffusionWrapper avoids materialising torch.cat([x] + c_concat)); timesteps [B] int64; context [B, L, D];
         fs [B] int64.  Extra keywords (cfg_img, unconditional_conditioning_img_nonetext, ...) leak in from the
