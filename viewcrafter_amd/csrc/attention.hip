@@ -228,9 +228,7 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
 }
 
 // =======================================================================================
-// Temporal attention: T <= 32 frames, d = 64.  One half-wave (32 lanes) per (pixel, head);
-// lane i is query frame i.  K and V of the pair sit in LDS ([T][64] fp16 each) and are read
-// as broadcasts; scores and the output row are kept in registers.
+// Temporal attention: T <= 32 frames, d = 64.
 // =======================================================================================
 struct TAttnArgs {
     const half_t* qkv;
@@ -242,90 +240,95 @@ struct TAttnArgs {
     int64_t npairs;
 };
 
+// One wave per (pixel, head): S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x16_f16 (T <= 32 keys = one MFMA
+// tile), the same swapped formulation as the flash kernel, so softmax statistics are per-lane and P needs no
+// cross-lane movement.  Q and K fragments are read straight from global memory (a frame row of one head is one
+// 128-byte line); V goes through a wave-private LDS patch [32][72] from which the V^T fragments are gathered with
+// 16-bit reads (rows >= T zero-filled).  Traffic is the algorithmic minimum (q, k, v read once, o written once).
 __global__ void __launch_bounds__(256) tattn_d64_kernel(TAttnArgs p) {
-    __shared__ __attribute__((aligned(16))) half_t sKV[8][2][32 * 64];  // [half-wave][K|V][t][d]
+    constexpr int VLD = 72;                                           // LDS row pitch (halfs): 144 B keeps 16-B alignment
+    __shared__ __attribute__((aligned(16))) half_t sVt[4][32 * VLD];
     const int tid = threadIdx.x;
-    const int hw = tid >> 5;        // half-wave id in block, 0..7
-    const int i = tid & 31;         // query frame
-    const int64_t pair = (int64_t)blockIdx.x * 8 + hw;
-    const bool pvalid = pair < p.npairs;
-    const int64_t pr = pvalid ? pair : 0;
-    const int h = (int)(pr % p.heads);
-    const int64_t pix = (pr / p.heads) % p.P;
-    const int b = (int)(pr / (p.heads * p.P));
-    const half_t* base = p.qkv + ((int64_t)b * p.T * p.P + pix) * p.ld + h * 64;  // frame 0 row
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
+    if (pair >= p.npairs) return;                                     // wave-uniform; no block-level sync below
+    const int h = (int)(pair % p.heads);
+    const int64_t pix = (pair / p.heads) % p.P;
+    const int b = (int)(pair / (p.heads * p.P));
+    const half_t* base = p.qkv + ((int64_t)b * p.T * p.P + pix) * p.ld + h * 64;   // frame-0 row of this (pixel, head)
     const int64_t fstride = p.P * p.ld;
-
-    // stage K, V rows of this pair: T rows x 8 chunks each
-    half_t* sk = sKV[hw][0];
-    half_t* sv = sKV[hw][1];
-    for (int c = i; c < p.T * 8; c += 32) {
-        const int t = c >> 3, ch = c & 7;
-        const half_t* src = base + (int64_t)t * fstride + ch * 8;
-        *reinterpret_cast<h8*>(sk + t * 64 + ch * 8) = *reinterpret_cast<const h8*>(src + p.k_off);
-        *reinterpret_cast<h8*>(sv + t * 64 + ch * 8) = *reinterpret_cast<const h8*>(src + p.v_off);
-    }
-    const bool active = pvalid && i < p.T;
-    h8 qv[8];
     const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        qv[c] = active ? *reinterpret_cast<const h8*>(base + (int64_t)i * fstride + c * 8) : zero8;
-    __syncthreads();
+    const bool rvalid = lq < p.T;
 
-    float s[32];
+    h8 qf[4], kf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const half_t* src = base + (int64_t)lq * fstride + s * 16 + hi * 8;
+        qf[s] = rvalid ? *reinterpret_cast<const h8*>(src) : zero8;
+        kf[s] = rvalid ? *reinterpret_cast<const h8*>(src + p.k_off) : zero8;
+    }
+    half_t* sv = sVt[wave];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = (lane >> 3) + 8 * it, ch = lane & 7;
+        const h8 v = row < p.T ? *reinterpret_cast<const h8*>(base + (int64_t)row * fstride + p.v_off + ch * 8) : zero8;
+        *reinterpret_cast<h8*>(sv + row * VLD + ch * 8) = v;
+    }
+
+    // S^T[key, q]: lane (q = lq, hi) holds keys (r&3) + 8*(r>>2) + 4*hi
+    const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16v sacc = zero16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[s], s == 0 ? zero16 : sacc, 0, 0, 0);
+    const float c = p.scale * 1.4426950408889634f;
     float mx = -1e30f;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        float acc = 0.f;
-        if (j < p.T) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const h8 kv = *reinterpret_cast<const h8*>(sk + j * 64 + c * 8);
-#pragma unroll
-                for (int e = 0; e < 8; e += 2)
-                    acc = __builtin_amdgcn_fdot2(h2{qv[c][e], qv[c][e + 1]}, h2{kv[e], kv[e + 1]}, acc, false);
-            }
-            acc *= p.scale;
-            mx = fmaxf(mx, acc);
-        } else {
-            acc = -1e30f;
-        }
-        s[j] = acc;
+    for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key >= p.T) sacc[r] = -1e30f;
+        mx = fmaxf(mx, sacc[r]);
     }
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * c;
     float l = 0.f;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const float e = (j < p.T) ? __expf(s[j] - mx) : 0.f;
-        s[j] = e;
+    for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c, -mx));
+        sacc[r] = e;
         l += e;
     }
+    l += __shfl_xor(l, 32);
     const float inv = 1.0f / l;
-    float oacc[64];
+    h8 pf[2];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) oacc[d] = 0.f;
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        if (j < p.T) {
-            // reference multiplies the fp16-rounded probabilities (autocast einsum)
-            const float pj = (float)(half_t)(s[j] * inv);
+        for (int j = 0; j < 8; ++j) pf[s][j] = (half_t)(sacc[8 * s + j] * inv);   // normalised P, fp16 like the reference's einsum input
+
+    // O^T[d, q] = sum_key V^T[d, key] P^T[key, q]; V^T fragment slot j <-> key 16s + (j&3) + 8*(j>>2) + 4*hi
+    __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): this wave's V rows are in LDS (wave-private patch: no barrier)
+    f16v oacc[2];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const h8 vv = *reinterpret_cast<const h8*>(sv + j * 64 + c * 8);
+    for (int db = 0; db < 2; ++db) {
+        const int d = db * 32 + lq;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) oacc[c * 8 + e] += pj * (float)vv[e];
-            }
+        for (int s = 0; s < 2; ++s) {
+            h8 vf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vf[j] = sv[(16 * s + (j & 3) + 8 * (j >> 2) + 4 * hi) * VLD + d];
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], s == 0 ? zero16 : oacc[db], 0, 0, 0);
         }
     }
-    if (active) {
-        half_t* dst = p.o + (((int64_t)b * p.T + i) * p.P + pix) * p.ldo + h * 64;
+    if (rvalid) {
+        half_t* dst = p.o + (((int64_t)b * p.T + lq) * p.P + pix) * p.ldo + h * 64;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            h8 ov;
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = (half_t)oacc[c * 8 + e];
-            *reinterpret_cast<h8*>(dst + c * 8) = ov;
-        }
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d0 = db * 32 + 8 * gq + 4 * hi;
+                *reinterpret_cast<h4*>(dst + d0) = h4{(half_t)oacc[db][gq * 4 + 0], (half_t)oacc[db][gq * 4 + 1],
+                                                      (half_t)oacc[db][gq * 4 + 2], (half_t)oacc[db][gq * 4 + 3]};
+            }
     }
 }
 
@@ -420,7 +423,7 @@ extern "C" int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T,
     a.npairs = (int64_t)B * P * heads;
     hipStream_t s = (hipStream_t)stream;
     VcxProfScope prof(VCX_FAM_TATTN, s, 4.0 * a.npairs * (double)T * T * 64, 2.0 * a.npairs * T * 64 * 4.0);
-    const int64_t nblk = (a.npairs + 7) / 8;
+    const int64_t nblk = (a.npairs + 3) / 4;
     VCX_REQUIRE(nblk < (1ll << 31), "vcx_attn_temporal_d64_f16: grid too large");
     hipLaunchKernelGGL(tattn_d64_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a);
     return vcx_check_launch("vcx_attn_temporal_d64_f16");

@@ -205,9 +205,11 @@ void gn_geometry(int C, int& cw, int& pl) {
 }
 
 int64_t pick_pix_per_block(int n_outer, int64_t pixels) {
-    // aim for >= ~2048 blocks chip-wide but keep at least 64 pixels per block
+    // aim for ~2048 blocks chip-wide, at least 64 pixels per block, and at most 256 blocks per n: every block ends
+    // with one fp32 atomic per group on the same n's statistics, and > 256 blocks per address start to serialise in L2
     int64_t chunks = (2048 + n_outer - 1) / n_outer;
     if (chunks < 1) chunks = 1;
+    if (chunks > 256) chunks = 256;
     int64_t ppb = (pixels + chunks - 1) / chunks;
     if (ppb < 64) ppb = 64;
     return ppb;
