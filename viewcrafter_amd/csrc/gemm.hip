@@ -464,6 +464,8 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const unsigned long long w_ext = 2ull * ((unsigned long long)(d->N - 1) * d->ldw + d->K);
     const bool dma_ok = dma_enabled && d->K % 64 == 0 && d->N % 4 == 0 && (!conv || d->cin % 64 == 0) &&
                         a_ext < lim && w_ext < lim && (!geglu || d->N >= 64);
+    a.a_bytes = (unsigned)a_ext;
+    a.w_bytes = (unsigned)w_ext;
     if (dma_ok) {
         // tile choice: the large (256-row, 8-wave) tiles halve the LDS traffic per MFMA but need >= ~1.5 waves of 256 tiles
         static const int force = []() { const char* e = getenv("VCX_GEMM_CFG"); return e ? atoi(e) : -1; }();

@@ -23,6 +23,7 @@ struct GemmArgs {
     int flags;
     float alpha;
     int tiles_m, tiles_n;
+    unsigned a_bytes, w_bytes;   // operand extents for the DMA kernel's buffer descriptors (whole problem, not the launch's rows)
     int m_begin;   // first output row of this launch (tail split of large-tile launches); rows are < M
     int tune;   // experiment bits from $VCX_GEMM_TUNE (0 in production)
 };

@@ -312,13 +312,9 @@ int launch(const GemmArgs& a, hipStream_t s) {
         }
         attr_set = true;
     }
-    const bool conv = CONV;
-    const unsigned long long a_ext = conv ? 2ull * (unsigned long long)(a.M / (a.out_h * a.out_w)) * a.in_h * a.in_w * a.lda
-                                          : 2ull * ((unsigned long long)(a.M - 1) * a.lda + a.K);
-    const unsigned long long w_ext = 2ull * ((unsigned long long)(a.N - 1) * a.ldw + a.K);
     const int blocks_per_cu = Cfg::SMEM > 80 * 1024 ? 1 : 2;
     const int nb = persistent_grid(a.tiles_m * a.tiles_n, blocks_per_cu);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(Cfg::THREADS), Cfg::SMEM, s, a, (unsigned)a_ext, (unsigned)w_ext);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(Cfg::THREADS), Cfg::SMEM, s, a, a.a_bytes, a.w_bytes);
     return vcx_check_launch("vcx_gemm_f16(dma)");
 }
 
