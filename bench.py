@@ -195,6 +195,12 @@ def main():
                            "launches_per_step": gemm["launches"] / args.steps,
                            "avg_launch_ms": gemm["ms"] / max(gemm["launches"], 1),
                            "algorithmic_tflop_per_launch_avg": gemm["flops"] / max(gemm["launches"], 1) / 1e12}
+        try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (bench.py cannot run rocprofv3 itself)
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr["source"]
+        except Exception:
+            pass
         out["kernel_families"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
                                       "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None,
                                       "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
