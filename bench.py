@@ -97,15 +97,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs an MI355X GPU (torch.cuda.device_count() == 0)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        if ndev >= world:
+            dist.init_process_group("nccl", device_id=device)       # RCCL over xGMI, one rank per GPU
+        else:
+            # fewer GPUs than ranks (only happens when the launch line is smoke-tested on a 1-GPU box): RCCL cannot
+            # put two ranks on one device, so the control-plane collectives fall back to gloo; the numbers are meaningless
+            print(f"[bench] {world} ranks on {ndev} GPU(s): sharing devices, gloo control plane (smoke test only)", file=sys.stderr)
+            dist.init_process_group("gloo")
     if args.gpus != world:
         if rank == 0:
             print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; running with {world} rank(s)", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
 
     from viewcrafter_amd import ops
     from viewcrafter_amd.builder import build_diffusion_model, randomize_parameters
@@ -169,7 +179,7 @@ def main():
                     v[k] = v[k] * args.steps / max(n_extra, 1)
     assert torch.isfinite(x).all(), "non-finite latent after the timed steps"
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
