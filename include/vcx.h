@@ -177,6 +177,12 @@ int vcx_nthwc_to_ncthw_f32(const void* src, float* dst, int B, int C, int T, int
 int vcx_ddim_step_f32(const float* x, const float* v_cond, const float* v_uncond,
                       const float* noise, float* x_prev, float* pred_x0, void* ws, int B,
                       int64_t n, const float* coef_host, void* stream);
+/* Multi-condition guidance (lvdm/models/samplers/ddim_multiplecond.py:220-236, `--multiple_cond_cfg`): v_img is the
+ * prediction under (empty text, image) conditioning and coef_host[8] = cfg_img:
+ *   v = v_uncond + cfg_img (v_img - v_uncond) + cfg (v_cond - v_img).  v_img == NULL reduces to vcx_ddim_step_f32. */
+int vcx_ddim_step3_f32(const float* x, const float* v_cond, const float* v_uncond,
+                       const float* v_img, const float* noise, float* x_prev, float* pred_x0,
+                       void* ws, int B, int64_t n, const float* coef_host, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Lightweight per-kernel-family profiling with HIP events (used by bench.py to fill

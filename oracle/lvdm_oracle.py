@@ -396,18 +396,20 @@ def decode_first_stage(sd, dd, z, scale_factor=0.18215):
 # DDIM sampler  (lvdm/models/samplers/ddim.py)
 # =============================================================================================
 def ddim_sample(apply_model, tables, scale_arr, x_T, cond, uncond, steps, eta=0.0, cfg_scale=7.5, guidance_rescale=0.7,
-                spacing="uniform_trailing", parameterization="v", noise_fn=None):
+                spacing="uniform_trailing", parameterization="v", noise_fn=None, uncond_img=None, cfg_img=None):
     """DDIMSampler.sample/ddim_sampling/p_sample_ddim, ddim.py:62-281, for the ViewCrafter call
     (diffusion_utils.py:179-194): CFG (:223-231), v-parameterisation (:233-236, 262), dynamic rescale (:264-268),
     update (:273-279).  apply_model(x, t, c) is the denoiser; `tables` from diffusion_tables(); scale_arr may be None.
-    noise_fn(shape) supplies N(0,1) when eta > 0.  Returns (x_0 latent, list of pred_x0)."""
+    noise_fn(shape) supplies N(0,1) when eta > 0.  Returns (x_0 latent, list of pred_x0).
+    uncond_img != None selects the multi-condition variant (ddim_multiplecond.py): a third evaluation under ("", image)
+    with v = v_u + cfg_img (v_img - v_u) + s (v_c - v_img) (:229-234) and the un-fixed ddim_scale_arr_prev (:33)."""
     acp = tables["alphas_cumprod"]
     ts = make_ddim_timesteps(spacing, steps, acp.shape[0])
     sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(acp, ts, eta)
     sqrt_1m = np.sqrt(1.0 - alphas)
     if scale_arr is not None:   # ddim.py:31-35
         s_arr = scale_arr[ts]
-        s_prev = torch.cat([scale_arr[0:1], s_arr[:-1]])
+        s_prev = torch.cat([(s_arr if uncond_img is not None else scale_arr)[0:1], s_arr[:-1]])
     x = x_T
     b = x.shape[0]
     preds = []
@@ -419,7 +421,11 @@ def ddim_sample(apply_model, tables, scale_arr, x_T, cond, uncond, steps, eta=0.
             out = v_c
         else:
             v_u = apply_model(x, t, uncond)
-            out = v_u + cfg_scale * (v_c - v_u)
+            if uncond_img is not None:
+                v_i = apply_model(x, t, uncond_img)
+                out = v_u + (cfg_scale if cfg_img is None else cfg_img) * (v_i - v_u) + cfg_scale * (v_c - v_i)
+            else:
+                out = v_u + cfg_scale * (v_c - v_u)
             if guidance_rescale > 0.0:
                 out = rescale_noise_cfg(out, v_c, guidance_rescale)
         sa = tables["sqrt_alphas_cumprod"][t].view(b, *([1] * (x.ndim - 1)))

@@ -193,6 +193,20 @@ def gen_ddim(out):
                 dec = model.decode_first_stage(samples)
                 out["decode_first_stage_sub4"] = dec.numpy()[..., ::4, ::4]  # VAE decode is pinned in full by vae_tiny.npz
             print("ddim eta", eta, float(samples.abs().mean()))
+        # multi-condition CFG sampler (--multiple_cond_cfg): third conditioning = ("" text, real image tokens)
+        from lvdm.models.samplers.ddim_multiplecond import DDIMSampler as DDIMSamplerMulti
+        DDIMSamplerMulti.register_buffer = register_buffer
+        uc2 = {"c_crossattn": [torch.cat([uc["c_crossattn"][0][:, :77], cond["c_crossattn"][0][:, 77:]], 1)], "c_concat": cond["c_concat"]}
+        sampler = DDIMSamplerMulti(model)
+        samples, inter = sampler.sample(S=5, conditioning=cond, batch_size=b, shape=[4, t, h, w], verbose=False,
+                                        unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0,
+                                        cfg_img=3.0, mask=None, x0=None, fs=fs, timestep_spacing="uniform_trailing",
+                                        guidance_rescale=0.7, x_T=x_T, log_every_t=1,
+                                        unconditional_conditioning_img_nonetext=uc2)
+        out["multicond_samples"] = samples.numpy()
+        out["multicond_pred_x0"] = torch.stack(inter["pred_x0"][1:]).numpy()
+        out["multicond_scale_arr_prev"] = sampler.ddim_scale_arr_prev.numpy()
+        print("multicond", float(samples.abs().mean()))
 
 
 def main():

@@ -181,6 +181,7 @@ def test_cfg_batching_rules():
     both = s._cfg_cond(c, uc)
     assert both["c_crossattn"][0].shape == (2, 5, 4) and float(both["c_crossattn"][0][1].min()) == 1.0
     assert s._cfg_cond(c, uc) is both                                   # built once per sample() call
+    assert DDIMSampler._batchable(c, uc, uc) and s._cfg_cond(c, uc, uc)["c_crossattn"][0].shape == (3, 5, 4)
 
 
 # ------------------------------------------------------------------ the product has no CPU / oracle fallback
@@ -211,7 +212,13 @@ def test_product_never_imports_the_oracle():
     assert not offenders, offenders
 
 
-def test_multicond_sampler_is_declared_unbuilt():
-    from viewcrafter_amd.lvdm.models.samplers.ddim_multiplecond import DDIMSampler
-    with pytest.raises(NotImplementedError):
-        DDIMSampler(None)
+def test_multicond_sampler_schedule_uses_the_unfixed_scale_arr_prev(tiny_model):
+    from viewcrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    from viewcrafter_amd.lvdm.models.samplers.ddim_multiplecond import DDIMSampler as Multi
+    g = golden("ddim_tiny")
+    a, m = DDIMSampler(tiny_model), Multi(tiny_model)
+    a.make_schedule(5, ddim_discretize="uniform_trailing", ddim_eta=0.0, verbose=False)
+    m.make_schedule(5, ddim_discretize="uniform_trailing", ddim_eta=0.0, verbose=False)
+    assert np.allclose(m.ddim_scale_arr_prev.numpy(), g["multicond_scale_arr_prev"])
+    assert float(a.ddim_scale_arr_prev[0]) == 1.0 and float(m.ddim_scale_arr_prev[0]) == float(m.ddim_scale_arr[0])
+    assert np.allclose(m._host["ratio"], (m.ddim_scale_arr_prev / m.ddim_scale_arr).numpy())

@@ -143,3 +143,28 @@ def test_ddim_trajectory_vs_reference_golden(model, eta):
         p = psnr(dec[..., ::4, ::4], g["decode_first_stage_sub4"])
         print(f"decoded frames PSNR vs reference = {p:.1f} dB")
         assert p >= 30.0
+
+
+def test_multicond_ddim_trajectory_vs_reference_golden(model):
+    """DDIMSampler of ddim_multiplecond.py (3 conditionings run as one B=3 forward, vcx_ddim_step3_f32)."""
+    from viewcrafter_amd.lvdm.models.samplers.ddim_multiplecond import DDIMSampler as DDIMSamplerMulti
+    g = golden("ddim_tiny")
+    cd = TINY_UNET["context_dim"]
+    b, t, h, w = 1, 4, 32, 16
+    cat = synth_input("ddim_cat", (b, 4, t, h, w), scale=0.8).to(DEV)
+    ctx, uctx = synth_input("ddim_ctx", (b, 77 + 16 * t, cd)).to(DEV), synth_input("ddim_uctx", (b, 77 + 16 * t, cd)).to(DEV)
+    cond = {"c_crossattn": [ctx], "c_concat": [cat]}
+    uc = {"c_crossattn": [uctx], "c_concat": [cat]}
+    uc2 = {"c_crossattn": [torch.cat([uctx[:, :77], ctx[:, 77:]], 1)], "c_concat": [cat]}
+    x_T = synth_input("ddim_xT", (b, 4, t, h, w)).to(DEV)
+    fs = torch.tensor([10] * b, device=DEV)
+    sampler = DDIMSamplerMulti(model)
+    with torch.no_grad():
+        samples, inter = sampler.sample(S=5, conditioning=cond, batch_size=b, shape=[4, t, h, w], verbose=False,
+                                        unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, cfg_img=3.0,
+                                        mask=None, x0=None, fs=fs, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                                        x_T=x_T, log_every_t=1, unconditional_conditioning_img_nonetext=uc2)
+    assert np.allclose(sampler.ddim_scale_arr_prev.numpy(), g["multicond_scale_arr_prev"])
+    e = rel_l2(samples, g["multicond_samples"])
+    print(f"multi-cond ddim: final latent rel-L2 {e:.3e}")
+    assert e <= DDIM_TOL

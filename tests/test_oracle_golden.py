@@ -126,3 +126,24 @@ def test_ddim_trajectory_matches_reference(eta):
         if eta == 0.0:
             dec = O.decode_first_stage(vae_sd, TINY_DDCONFIG, torch.from_numpy(g["ddim_samples_eta0.0"]))
             assert max_rel(dec.numpy()[..., ::4, ::4], g["decode_first_stage_sub4"]) < 2e-5
+
+
+def test_multicond_ddim_trajectory_matches_reference():
+    """`--multiple_cond_cfg`: 3-way guidance (cfg 7.5, cfg_img 3.0) and the un-fixed ddim_scale_arr_prev of ddim_multiplecond.py."""
+    g = load("ddim_tiny")
+    unet_sd, _ = split_model_state_dict(g["model_keys"], g["model_shapes"])
+    b, t, h, w = 1, 4, 32, 16
+    cd = TINY_UNET["context_dim"]
+    ctx, uctx = synth_input("ddim_ctx", (b, 77 + 16 * t, cd)), synth_input("ddim_uctx", (b, 77 + 16 * t, cd))
+    uctx2 = torch.cat([uctx[:, :77], ctx[:, 77:]], 1)
+    cat = synth_input("ddim_cat", (b, 4, t, h, w), scale=0.8)
+    x_T = synth_input("ddim_xT", (b, 4, t, h, w))
+    fs = torch.tensor([10] * b)
+
+    def apply_model(x, ts, c):
+        return O.unet_forward(unet_sd, TINY_UNET, torch.cat([x, cat], 1), ts, c, fs)
+    with torch.no_grad():
+        x0, preds = O.ddim_sample(apply_model, O.diffusion_tables(), O.dynamic_rescale_table(1000, 0.3, 400), x_T, ctx, uctx,
+                                  steps=5, eta=0.0, cfg_scale=7.5, guidance_rescale=0.7, uncond_img=uctx2, cfg_img=3.0)
+    assert max_rel(torch.stack(preds).numpy(), g["multicond_pred_x0"]) < 2e-4
+    assert max_rel(x0.numpy(), g["multicond_samples"]) < 2e-4

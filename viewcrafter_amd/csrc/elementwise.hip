@@ -72,19 +72,27 @@ __global__ void nthwc_to_ncthw_kernel(const void* src, float* dst, int B, int C,
 // and of the guided v).  Pass 2: the update.
 // ---------------------------------------------------------------------------------------
 struct DdimCoef {
-    float sqrt_acp, sqrt_1m_acp, sqrt_a_prev, dir_coef, sigma, scale_ratio, cfg, rescale;
-    int is_v, has_uncond, has_noise;
+    float sqrt_acp, sqrt_1m_acp, sqrt_a_prev, dir_coef, sigma, scale_ratio, cfg, rescale, cfg_img;
+    int is_v, has_uncond, has_noise, has_img;
 };
 
-__global__ void __launch_bounds__(256) ddim_reduce_kernel(const float* vc, const float* vu, double* ws, int64_t n, float cfg) {
+// guided prediction: u + s (c - u), or with an image-only branch i (multi-condition CFG,
+// ddim_multiplecond.py:229-234): u + s_img (i - u) + s (c - i)
+__device__ __forceinline__ float ddim_guided(float c, float u, float i, const DdimCoef& k) {
+    return k.has_img ? u + k.cfg_img * (i - u) + k.cfg * (c - i) : u + k.cfg * (c - u);
+}
+
+__global__ void __launch_bounds__(256) ddim_reduce_kernel(const float* vc, const float* vu, const float* vi, double* ws, int64_t n,
+                                                          DdimCoef k) {
     __shared__ double red[4][4];
     const int b = blockIdx.y;
     const float* c = vc + (int64_t)b * n;
     const float* u = vu + (int64_t)b * n;
+    const float* im = k.has_img ? vi + (int64_t)b * n : u;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float a = c[i];
-        const float g = u[i] + cfg * (a - u[i]);
+        const float g = ddim_guided(a, u[i], im[i], k);
         s0 += a; s1 += a * a; s2 += g; s3 += g * g;
     }
     s0 = vcx_wave_sum(s0); s1 = vcx_wave_sum(s1); s2 = vcx_wave_sum(s2); s3 = vcx_wave_sum(s3);
@@ -97,9 +105,9 @@ __global__ void __launch_bounds__(256) ddim_reduce_kernel(const float* vc, const
     }
 }
 
-__global__ void __launch_bounds__(256) ddim_update_kernel(const float* x, const float* vc, const float* vu, const float* noise,
-                                                          float* x_prev, float* pred_x0, const double* ws, int64_t n,
-                                                          DdimCoef k) {
+__global__ void __launch_bounds__(256) ddim_update_kernel(const float* x, const float* vc, const float* vu, const float* vi,
+                                                          const float* noise, float* x_prev, float* pred_x0, const double* ws,
+                                                          int64_t n, DdimCoef k) {
     const int b = blockIdx.y;
     float mix = 1.0f;  // v = v_guided * mix
     if (k.has_uncond && k.rescale > 0.f) {
@@ -115,7 +123,7 @@ __global__ void __launch_bounds__(256) ddim_update_kernel(const float* x, const 
         float v = vc[off + i];
         if (k.has_uncond) {
             const float u = vu[off + i];
-            v = (u + k.cfg * (v - u)) * mix;
+            v = ddim_guided(v, u, k.has_img ? vi[off + i] : u, k) * mix;
         }
         float e_t, x0;
         if (k.is_v) {
@@ -215,7 +223,21 @@ extern "C" int vcx_nthwc_to_ncthw_f32(const void* src, float* dst, int B, int C,
 extern "C" int vcx_ddim_step_f32(const float* x, const float* v_cond, const float* v_uncond, const float* noise,
                                  float* x_prev, float* pred_x0, void* ws, int B, int64_t n, const float* coef_host,
                                  void* stream) {
+    float c9[9];
+    if (!coef_host) {
+        vcx_set_error("vcx_ddim_step_f32: null pointer");
+        return VCX_EINVAL;
+    }
+    for (int i = 0; i < 8; ++i) c9[i] = coef_host[i];
+    c9[8] = 0.f;
+    return vcx_ddim_step3_f32(x, v_cond, v_uncond, nullptr, noise, x_prev, pred_x0, ws, B, n, c9, stream);
+}
+
+extern "C" int vcx_ddim_step3_f32(const float* x, const float* v_cond, const float* v_uncond, const float* v_img,
+                                  const float* noise, float* x_prev, float* pred_x0, void* ws, int B, int64_t n,
+                                  const float* coef_host, void* stream) {
     VCX_REQUIRE(x && v_cond && x_prev && pred_x0 && ws && coef_host, "vcx_ddim_step_f32: null pointer");
+    VCX_REQUIRE(!v_img || v_uncond, "vcx_ddim_step3_f32: v_img needs v_uncond");
     VCX_REQUIRE(B > 0 && B <= 65535 && n > 1, "vcx_ddim_step_f32: bad sizes");
     VCX_REQUIRE(((uintptr_t)ws & 7) == 0, "vcx_ddim_step_f32: ws must be 8-byte aligned");
     DdimCoef k;
@@ -231,6 +253,8 @@ extern "C" int vcx_ddim_step_f32(const float* x, const float* v_cond, const floa
     k.rescale = coef_host[6];
     k.is_v = coef_host[7] != 0.f;
     k.has_uncond = v_uncond != nullptr;
+    k.has_img = v_img != nullptr;
+    k.cfg_img = coef_host[8];
     k.has_noise = (noise != nullptr) && sigma != 0.f;
     hipStream_t s = (hipStream_t)stream;
     VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 4.0 * B * (double)n * 8);
@@ -240,11 +264,11 @@ extern "C" int vcx_ddim_step_f32(const float* x, const float* v_cond, const floa
             vcx_set_error("vcx_ddim_step_f32: memset failed");
             return VCX_ELAUNCH;
         }
-        hipLaunchKernelGGL(ddim_reduce_kernel, dim3(gx, B), dim3(256), 0, s, v_cond, v_uncond, (double*)ws, n, k.cfg);
+        hipLaunchKernelGGL(ddim_reduce_kernel, dim3(gx, B), dim3(256), 0, s, v_cond, v_uncond, v_img, (double*)ws, n, k);
         int rc = vcx_check_launch("vcx_ddim_step_f32(reduce)");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(ddim_update_kernel, dim3(gx, B), dim3(256), 0, s, x, v_cond, v_uncond, noise, x_prev, pred_x0,
+    hipLaunchKernelGGL(ddim_update_kernel, dim3(gx, B), dim3(256), 0, s, x, v_cond, v_uncond, v_img, noise, x_prev, pred_x0,
                        (const double*)ws, n, k);
     return vcx_check_launch("vcx_ddim_step_f32");
 }

@@ -127,24 +127,51 @@ class DDIMSampler(object):
 
     # ------------------------------------------------------------------ CFG batching
     @staticmethod
-    def _batchable(c, uc):
-        if not (isinstance(c, dict) and isinstance(uc, dict)) or set(c.keys()) != set(uc.keys()):
+    def _batchable(c, *others):
+        """True if all conditionings are dicts of equally shaped tensor lists, i.e. can be stacked on the batch axis."""
+        if not isinstance(c, dict):
             return False
-        for k in c:
-            if not (isinstance(c[k], (list, tuple)) and isinstance(uc[k], (list, tuple)) and len(c[k]) == len(uc[k])):
+        for uc in others:
+            if not isinstance(uc, dict) or set(c.keys()) != set(uc.keys()):
                 return False
-            if not all(torch.is_tensor(a) and torch.is_tensor(u) and a.shape == u.shape for a, u in zip(c[k], uc[k])):
-                return False
+            for k in c:
+                if not (isinstance(c[k], (list, tuple)) and isinstance(uc[k], (list, tuple)) and len(c[k]) == len(uc[k])):
+                    return False
+                if not all(torch.is_tensor(a) and torch.is_tensor(u) and a.shape == u.shape for a, u in zip(c[k], uc[k])):
+                    return False
         return True
 
-    def _cfg_cond(self, c, uc):
-        """[cond ; uncond] stacked on the batch axis, built once per sample() call (so that the UNet's context-K/V
-        cache, keyed on tensor identity, hits on every later step)."""
-        key = (id(c), id(uc))
+    def _cfg_cond(self, *conds):
+        """[cond ; uncond (; uncond_img)] stacked on the batch axis, built once per sample() call (so that the UNet's
+        context-K/V cache, keyed on tensor identity, hits on every later step)."""
+        key = tuple(id(c) for c in conds)
         if self._cfg_cache is None or self._cfg_cache[0] != key:
-            both = {k: [torch.cat([a, u], dim=0) for a, u in zip(c[k], uc[k])] for k in c}
-            self._cfg_cache = (key, both, c, uc)
+            both = {k: [torch.cat(parts, dim=0) for parts in zip(*[c[k] for c in conds])] for k in conds[0]}
+            self._cfg_cache = (key, both, conds)
         return self._cfg_cache[1]
+
+    def _apply_batched(self, x, t, conds, kwargs):
+        """One UNet forward over len(conds) stacked conditionings; returns the per-conditioning outputs."""
+        n, b = len(conds), x.shape[0]
+        kw = dict(kwargs)
+        if torch.is_tensor(kw.get("fs")):
+            kw["fs"] = torch.cat([kw["fs"]] * n, 0)
+        out = self.model.apply_model(torch.cat([x] * n, 0), torch.cat([t] * n, 0), self._cfg_cond(*conds), **kw)
+        return [out[i * b:(i + 1) * b] for i in range(n)]
+
+    def _model_outputs(self, x, t, c, unconditional_conditioning, unconditional_guidance_scale, kwargs):
+        """Denoiser evaluations of one step (reference ddim.py:218-231).  Returns (v_cond, v_uncond | None, v_img | None,
+        cfg_img)."""
+        if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
+            return self.model.apply_model(x, t, c, **kwargs), None, None, 0.0
+        if self._batchable(c, unconditional_conditioning):
+            v_c, v_u = self._apply_batched(x, t, (c, unconditional_conditioning), kwargs)
+        elif isinstance(c, (torch.Tensor, dict)):
+            v_c = self.model.apply_model(x, t, c, **kwargs)
+            v_u = self.model.apply_model(x, t, unconditional_conditioning, **kwargs)
+        else:
+            raise NotImplementedError
+        return v_c, v_u, None, 0.0
 
     @torch.no_grad()
     def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
@@ -156,21 +183,8 @@ class DDIMSampler(object):
             raise NotImplementedError("not on the ViewCrafter path")
         b, device = x.shape[0], x.device
         x = x.float().contiguous()
-        guided = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
-        if not guided:
-            v_c, v_u = self.model.apply_model(x, t, c, **kwargs), None
-        elif self._batchable(c, unconditional_conditioning):
-            kw = dict(kwargs)
-            if torch.is_tensor(kw.get("fs")):
-                kw["fs"] = torch.cat([kw["fs"], kw["fs"]], 0)
-            both = self.model.apply_model(torch.cat([x, x], 0), torch.cat([t, t], 0),
-                                          self._cfg_cond(c, unconditional_conditioning), **kw)
-            v_c, v_u = both[:b], both[b:]
-        elif isinstance(c, (torch.Tensor, dict)):
-            v_c = self.model.apply_model(x, t, c, **kwargs)
-            v_u = self.model.apply_model(x, t, unconditional_conditioning, **kwargs)
-        else:
-            raise NotImplementedError
+        v_c, v_u, v_i, cfg_img = self._model_outputs(x, t, c, unconditional_conditioning, unconditional_guidance_scale, kwargs)
+        guided = v_u is not None
         h = self._host
         step_t = int(self.ddim_timesteps[index])   # == t[i] for all i, by construction of ddim_sampling
         sigma = float(h["sigma"][index])
@@ -183,7 +197,8 @@ class DDIMSampler(object):
         noise = None
         if sigma != 0.0:
             noise = noise_like(x.shape, device, repeat_noise) * temperature
-        x_prev, pred_x0 = ops.ddim_step(x, v_c.contiguous(), v_u.contiguous() if v_u is not None else None, noise, coef)
+        x_prev, pred_x0 = ops.ddim_step(x, v_c.contiguous(), v_u.contiguous() if v_u is not None else None, noise, coef,
+                                        v_img=v_i.contiguous() if v_i is not None else None, cfg_img=cfg_img)
         return x_prev, pred_x0
 
     @torch.no_grad()

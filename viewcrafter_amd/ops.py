@@ -219,17 +219,18 @@ def nthwc_to_ncthw(src, C=None):
     return out
 
 
-def ddim_step(x, v_cond, v_uncond, noise, coef, ws=None):
-    """One DDIM update on fp32 [B, ...] tensors; coef = 8 host floats (see include/vcx.h)."""
+def ddim_step(x, v_cond, v_uncond, noise, coef, ws=None, v_img=None, cfg_img=0.0):
+    """One DDIM update on fp32 [B, ...] tensors; coef = 8 host floats (see include/vcx.h); v_img/cfg_img select the
+    multi-condition guidance of vcx_ddim_step3_f32."""
     B = x.shape[0]
     n = x.numel() // B
     x_prev = torch.empty_like(x)
     pred_x0 = torch.empty_like(x)
     if ws is None:
         ws = torch.empty((4 * B,), dtype=torch.float64, device=x.device)
-    c = (ctypes.c_float * 8)(*[float(v) for v in coef])
-    check(lib().vcx_ddim_step_f32(x.data_ptr(), v_cond.data_ptr(), _ptr(v_uncond), _ptr(noise), x_prev.data_ptr(),
-                                  pred_x0.data_ptr(), ws.data_ptr(), B, n, c, _stream()), "ddim_step")
+    c = (ctypes.c_float * 9)(*([float(v) for v in coef[:8]] + [float(cfg_img)]))
+    check(lib().vcx_ddim_step3_f32(x.data_ptr(), v_cond.data_ptr(), _ptr(v_uncond), _ptr(v_img), _ptr(noise),
+                                   x_prev.data_ptr(), pred_x0.data_ptr(), ws.data_ptr(), B, n, c, _stream()), "ddim_step")
     return x_prev, pred_x0
 
 
