@@ -95,12 +95,14 @@ int vcx_gemm_f16(const vcx_gemm_desc* desc_host, void* stream);
  *   per-video   TemporalConvBlock GN openaimodel3d.py:256-266, TemporalTransformer.norm
  *               attention.py:331   (statistics span T*H*W)
  * x is [n_outer][pixels][C]; statistics are taken over (pixels, C/groups) per (n, group).
- * stats: fp32 [n_outer][groups][2] = (sum, sum of squares); written by _stats (it clears
- * the buffer first), consumed by _apply which computes
+ * stats: fp32 [n_outer][groups][2] = (sum, sum of squares); written by _stats, which reduces
+ * deterministically (fixed summation order, no atomics) through the caller's workspace `ws` of
+ * vcx_groupnorm_ws_bytes() bytes; consumed by _apply which computes
  *   y = (x - mean) * rsqrt(var + eps) * gamma[c] + beta[c], then x*sigmoid(x) if silu.
  * ---------------------------------------------------------------------------------- */
-int vcx_groupnorm_stats_f16(const void* x, float* stats, int n_outer, int64_t pixels, int C,
-                            int groups, void* stream);
+size_t vcx_groupnorm_ws_bytes(int n_outer, int64_t pixels, int groups);
+int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, int n_outer, int64_t pixels,
+                            int C, int groups, void* stream);
 int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stats, const float* gamma,
                             const float* beta, int n_outer, int64_t pixels, int C, int groups,
                             float eps, int silu, void* stream);
@@ -172,7 +174,7 @@ int vcx_nthwc_to_ncthw_f32(const void* src, float* dst, int B, int C, int T, int
  *   { sqrt_acp_t, sqrt_1m_acp_t, a_prev, sigma_t, scale_ratio(prev/t), cfg_scale,
  *     guidance_rescale, parameterization_is_v }.
  * v_uncond may be NULL (no guidance).  noise may be NULL when sigma_t == 0.
- * ws: device workspace of 32*B bytes (4 fp64 sums per sample), 8-byte aligned.
+ * ws: device workspace of 8192*B bytes (per-block fp64 partial sums, reduced in fixed order), 8-byte aligned.
  * ---------------------------------------------------------------------------------- */
 int vcx_ddim_step_f32(const float* x, const float* v_cond, const float* v_uncond,
                       const float* noise, float* x_prev, float* pred_x0, void* ws, int B,

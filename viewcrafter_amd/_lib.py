@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libvcx.so")
 # every symbol include/vcx.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
     "vcx_abi_version", "vcx_last_error", "vcx_device_arch", "vcx_gemm_f16",
-    "vcx_groupnorm_stats_f16", "vcx_groupnorm_apply_f16", "vcx_layernorm_f16",
+    "vcx_groupnorm_ws_bytes", "vcx_groupnorm_stats_f16", "vcx_groupnorm_apply_f16", "vcx_layernorm_f16",
     "vcx_attn_flash_d64_f16", "vcx_attn_temporal_d64_f16", "vcx_softmax_rows_f16",
     "vcx_silu_f32", "vcx_timestep_embedding_f32", "vcx_cast_f32_to_f16", "vcx_cast_f16_to_f32",
     "vcx_copy2d_f16", "vcx_ncthw_f32_to_nthwc_f16", "vcx_nthwc_to_ncthw_f32", "vcx_ddim_step_f32", "vcx_ddim_step3_f32",
@@ -57,7 +57,8 @@ def lib():
     L.vcx_last_error.restype = c_char_p
     L.vcx_device_arch.argtypes = [c_char_p, c_int]
     L.vcx_gemm_f16.argtypes = [POINTER(GemmDesc), c_void_p]
-    L.vcx_groupnorm_stats_f16.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]
+    L.vcx_groupnorm_ws_bytes.argtypes = [c_int, c_int64, c_int]
+    L.vcx_groupnorm_stats_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]
     L.vcx_groupnorm_apply_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
                                           c_int, c_float, c_int, c_void_p]
     L.vcx_layernorm_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]
@@ -82,7 +83,9 @@ def lib():
     L.vcx_profile_end.argtypes = [POINTER(c_double)]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name != "vcx_last_error":
+        if name == "vcx_groupnorm_ws_bytes":
+            fn.restype = ctypes.c_size_t
+        elif name != "vcx_last_error":
             fn.restype = c_int
     if L.vcx_abi_version() != 1:
         raise VcxError(f"libvcx ABI version {L.vcx_abi_version()} != 1; rebuild the library")

@@ -99,20 +99,24 @@ __global__ void __launch_bounds__(256) ddim_reduce_kernel(const float* vc, const
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[w][0] = s0; red[w][1] = s1; red[w][2] = s2; red[w][3] = s3; }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < 4) {   // per-block partial, no atomics: ddim_update_kernel adds the blocks in order
         const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(&ws[b * 4 + threadIdx.x], t);
+        ws[((int64_t)b * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = t;
     }
 }
 
 __global__ void __launch_bounds__(256) ddim_update_kernel(const float* x, const float* vc, const float* vu, const float* vi,
                                                           const float* noise, float* x_prev, float* pred_x0, const double* ws,
-                                                          int64_t n, DdimCoef k) {
+                                                          int64_t n, DdimCoef k, int nparts) {
     const int b = blockIdx.y;
     float mix = 1.0f;  // v = v_guided * mix
     if (k.has_uncond && k.rescale > 0.f) {
         const double nn = (double)n;
-        const double sc = ws[b * 4 + 0], qc = ws[b * 4 + 1], sg = ws[b * 4 + 2], qg = ws[b * 4 + 3];
+        double sc = 0, qc = 0, sg = 0, qg = 0;
+        for (int j = 0; j < nparts; ++j) {               // fixed order -> bit-reproducible
+            const double* pp = ws + ((int64_t)b * nparts + j) * 4;
+            sc += pp[0]; qc += pp[1]; sg += pp[2]; qg += pp[3];
+        }
         const double var_c = (qc - sc * sc / nn) / (nn - 1.0), var_g = (qg - sg * sg / nn) / (nn - 1.0);
         const float std_c = (float)sqrt(var_c > 0 ? var_c : 0), std_g = (float)sqrt(var_g > 0 ? var_g : 0);
         mix = k.rescale * (std_c / std_g) + (1.0f - k.rescale);
@@ -260,15 +264,11 @@ extern "C" int vcx_ddim_step3_f32(const float* x, const float* v_cond, const flo
     VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 4.0 * B * (double)n * 8);
     const unsigned gx = grid_for(n, 256);
     if (k.has_uncond && k.rescale > 0.f) {
-        if (hipMemsetAsync(ws, 0, sizeof(double) * 4 * B, s) != hipSuccess) {
-            vcx_set_error("vcx_ddim_step_f32: memset failed");
-            return VCX_ELAUNCH;
-        }
         hipLaunchKernelGGL(ddim_reduce_kernel, dim3(gx, B), dim3(256), 0, s, v_cond, v_uncond, v_img, (double*)ws, n, k);
         int rc = vcx_check_launch("vcx_ddim_step_f32(reduce)");
         if (rc) return rc;
     }
     hipLaunchKernelGGL(ddim_update_kernel, dim3(gx, B), dim3(256), 0, s, x, v_cond, v_uncond, v_img, noise, x_prev, pred_x0,
-                       (const double*)ws, n, k);
+                       (const double*)ws, n, k, (int)gx);
     return vcx_check_launch("vcx_ddim_step_f32");
 }

@@ -11,12 +11,12 @@ constexpr int MAXC = 4096;  // C/8 * pixel lanes must fit one block (<= 512 thre
 // blockDim = CW * PL, so a wave reads whole pixel rows back to back, the per-channel constants (8 partial sums /
 // 8 scale+shift pairs) live in registers, and the pixel loop is 4-way unrolled to keep four 16-byte loads in flight.
 // ---------------------------------------------------------------------------------------
-__global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int64_t pixels, int C, int groups,
+__global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ partials, int64_t pixels, int C, int groups,
                                 int64_t pix_per_block, int cw, int pl) {
-    __shared__ float gsum[64], gsq[64];
+    // Deterministic reduction (no atomics): per-thread channel sums -> LDS -> fixed-order sum over the pixel lanes ->
+    // fixed-order sum over a group's channels -> partials[n][chunk][group][2]; gn_finalize_kernel adds the chunks in order.
+    extern __shared__ float red[];                      // [pl][C][2] then reused as [C][2]
     const int tid = threadIdx.x;
-    if (tid < 64) { gsum[tid] = 0.f; gsq[tid] = 0.f; }
-    __syncthreads();
     const int n = blockIdx.y;
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = (p0 + pix_per_block < pixels) ? p0 + pix_per_block : pixels;
@@ -50,27 +50,50 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
             ss[e] += f * f;
         }
     }
-    // fold the 8 channels into their groups (consecutive channels mostly share one)
-    int gcur = (c8 * 8) / cpg;
-    float as = 0.f, aq = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int ge = (c8 * 8 + e) / cpg;
-        if (ge != gcur) {
-            atomicAdd(&gsum[gcur], as);
-            atomicAdd(&gsq[gcur], aq);
-            as = aq = 0.f;
-            gcur = ge;
-        }
-        as += s[e];
-        aq += ss[e];
+        red[((size_t)plane * C + c8 * 8 + e) * 2 + 0] = s[e];
+        red[((size_t)plane * C + c8 * 8 + e) * 2 + 1] = ss[e];
     }
-    atomicAdd(&gsum[gcur], as);
-    atomicAdd(&gsq[gcur], aq);
     __syncthreads();
-    if (tid < groups) {
-        atomicAdd(&stats[((int64_t)n * groups + tid) * 2 + 0], gsum[tid]);
-        atomicAdd(&stats[((int64_t)n * groups + tid) * 2 + 1], gsq[tid]);
+    for (int c = tid; c < C; c += blockDim.x) {          // pixel lanes, in order
+        float a = red[(size_t)c * 2], q = red[(size_t)c * 2 + 1];
+        for (int p = 1; p < pl; ++p) {
+            a += red[((size_t)p * C + c) * 2];
+            q += red[((size_t)p * C + c) * 2 + 1];
+        }
+        red[(size_t)c * 2] = a;
+        red[(size_t)c * 2 + 1] = q;
+    }
+    __syncthreads();
+    if (tid < groups) {                                   // channels of the group, in order
+        float a = 0.f, q = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+            a += red[(size_t)c * 2];
+            q += red[(size_t)c * 2 + 1];
+        }
+        float* dst = partials + (((int64_t)n * gridDim.x + blockIdx.x) * groups + tid) * 2;
+        dst[0] = a;
+        dst[1] = q;
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int chunks,
+                                                          int groups) {
+    // fixed summation tree: wave q adds the chunks c = q, q+4, q+8, ... in order, then the four wave sums are added in order
+    __shared__ float red[4][128];
+    const int n = blockIdx.x, q = threadIdx.x >> 6, j = threadIdx.x & 63;   // j indexes (group, sum|sumsq) in steps of 64
+    for (int jj = j; jj < groups * 2; jj += 64) {
+        const float* src = partials + (int64_t)n * chunks * groups * 2 + jj;
+        float a = 0.f;
+#pragma unroll 8
+        for (int c = q; c < chunks; c += 4) a += src[(int64_t)c * groups * 2];
+        red[q][jj] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < groups * 2) {
+        const int jj = threadIdx.x;
+        stats[(int64_t)n * groups * 2 + jj] = ((red[0][jj] + red[1][jj]) + red[2][jj]) + red[3][jj];
     }
 }
 
@@ -205,37 +228,44 @@ void gn_geometry(int C, int& cw, int& pl) {
 }
 
 int64_t pick_pix_per_block(int n_outer, int64_t pixels) {
-    // aim for ~2048 blocks chip-wide, at least 64 pixels per block, and at most 256 blocks per n: every block ends
-    // with one fp32 atomic per group on the same n's statistics, and > 256 blocks per address start to serialise in L2
-    int64_t chunks = (2048 + n_outer - 1) / n_outer;
-    if (chunks < 1) chunks = 1;
-    if (chunks > 256) chunks = 256;
-    int64_t ppb = (pixels + chunks - 1) / chunks;
-    if (ppb < 64) ppb = 64;
+    // A function of `pixels` only: the summation order - hence the bits of the result - must not depend on how many
+    // samples are batched (cond/uncond run as one B=2 forward and must equal two B=1 forwards exactly).
+    // <= 1024 partials per n, >= 128 pixels per block.
+    (void)n_outer;
+    int64_t ppb = (pixels + 1023) / 1024;
+    if (ppb < 128) ppb = 128;
     return ppb;
 }
 
 }  // namespace
 
-extern "C" int vcx_groupnorm_stats_f16(const void* x, float* stats, int n_outer, int64_t pixels, int C, int groups,
+extern "C" size_t vcx_groupnorm_ws_bytes(int n_outer, int64_t pixels, int groups) {
+    if (n_outer <= 0 || pixels <= 0 || groups <= 0) return 0;
+    const int64_t ppb = pick_pix_per_block(n_outer, pixels);
+    const int64_t chunks = (pixels + ppb - 1) / ppb;
+    return sizeof(float) * 2 * (size_t)n_outer * (size_t)chunks * (size_t)groups;
+}
+
+extern "C" int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, int n_outer, int64_t pixels, int C, int groups,
                                        void* stream) {
-    VCX_REQUIRE(x && stats, "vcx_groupnorm_stats_f16: null pointer");
-    VCX_REQUIRE(n_outer > 0 && pixels > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C % 8 == 0,
-                "vcx_groupnorm_stats_f16: need C %% 8 == 0, C %% groups == 0, groups <= 64 (C=%d groups=%d)", C, groups);
-    VCX_REQUIRE(((uintptr_t)x & 15) == 0, "vcx_groupnorm_stats_f16: x must be 16-byte aligned");
+    VCX_REQUIRE(x && stats && ws, "vcx_groupnorm_stats_f16: null pointer");
+    VCX_REQUIRE(n_outer > 0 && pixels > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C % 8 == 0 && C <= MAXC,
+                "vcx_groupnorm_stats_f16: need C %% 8 == 0, C %% groups == 0, groups <= 64, C <= %d (C=%d groups=%d)", MAXC, C, groups);
+    VCX_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)ws & 3) == 0, "vcx_groupnorm_stats_f16: x must be 16-byte aligned");
     VCX_REQUIRE(n_outer <= 65535, "vcx_groupnorm_stats_f16: n_outer too large");
     hipStream_t s = (hipStream_t)stream;
     VcxProfScope prof(VCX_FAM_GN, s, 0.0, 2.0 * n_outer * (double)pixels * C);
-    if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)n_outer * groups, s) != hipSuccess) {
-        vcx_set_error("vcx_groupnorm_stats_f16: memset failed");
-        return VCX_ELAUNCH;
-    }
     const int64_t ppb = pick_pix_per_block(n_outer, pixels);
-    dim3 grid((unsigned)((pixels + ppb - 1) / ppb), n_outer);
+    const int chunks = (int)((pixels + ppb - 1) / ppb);
+    dim3 grid((unsigned)chunks, n_outer);
     int cw, pl;
     gn_geometry(C, cw, pl);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(cw * pl), 0, s, (const half_t*)x, stats, pixels, C, groups, ppb, cw, pl);
-    return vcx_check_launch("vcx_groupnorm_stats_f16");
+    const size_t smem = sizeof(float) * 2 * (size_t)pl * C;
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(cw * pl), smem, s, (const half_t*)x, (float*)ws, pixels, C, groups, ppb, cw, pl);
+    int rc = vcx_check_launch("vcx_groupnorm_stats_f16");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_outer), dim3(256), 0, s, (const float*)ws, stats, chunks, groups);
+    return vcx_check_launch("vcx_groupnorm_stats_f16(finalize)");
 }
 
 extern "C" int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stats, const float* gamma, const float* beta,

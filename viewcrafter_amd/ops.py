@@ -116,7 +116,8 @@ def group_norm(x, gamma, beta, eps, silu, groups=32, out=None):
     stats = torch.empty((n_outer, groups, 2), dtype=_f32, device=x.device)
     L = lib()
     s = _stream()
-    check(L.vcx_groupnorm_stats_f16(x.data_ptr(), stats.data_ptr(), n_outer, pixels, C, groups, s), "groupnorm_stats")
+    ws = torch.empty((L.vcx_groupnorm_ws_bytes(n_outer, pixels, groups),), dtype=torch.uint8, device=x.device)
+    check(L.vcx_groupnorm_stats_f16(x.data_ptr(), stats.data_ptr(), ws.data_ptr(), n_outer, pixels, C, groups, s), "groupnorm_stats")
     if out is None:
         out = torch.empty_like(x)
     check(L.vcx_groupnorm_apply_f16(x.data_ptr(), out.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
@@ -227,7 +228,7 @@ def ddim_step(x, v_cond, v_uncond, noise, coef, ws=None, v_img=None, cfg_img=0.0
     x_prev = torch.empty_like(x)
     pred_x0 = torch.empty_like(x)
     if ws is None:
-        ws = torch.empty((4 * B,), dtype=torch.float64, device=x.device)
+        ws = torch.empty((1024 * B,), dtype=torch.float64, device=x.device)
     c = (ctypes.c_float * 9)(*([float(v) for v in coef[:8]] + [float(cfg_img)]))
     check(lib().vcx_ddim_step3_f32(x.data_ptr(), v_cond.data_ptr(), _ptr(v_uncond), _ptr(v_img), _ptr(noise),
                                    x_prev.data_ptr(), pred_x0.data_ptr(), ws.data_ptr(), B, n, c, _stream()), "ddim_step")
