@@ -462,10 +462,18 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const unsigned long long a_ext = conv ? 2ull * (unsigned long long)(d->M / (d->out_h * d->out_w)) * d->in_h * d->in_w * d->lda
                                           : 2ull * ((unsigned long long)(d->M - 1) * d->lda + d->K);
     const unsigned long long w_ext = 2ull * ((unsigned long long)(d->N - 1) * d->ldw + d->K);
+    // output / residual: 32-bit byte offsets up to 256 rows past the end must not wrap (rows >= M are dropped by the
+    // descriptor's range check, which only works if their offset is still >= the extent)
+    const unsigned long long esz = f32 ? 4 : 2;
+    const unsigned long long c_ext = esz * ((unsigned long long)(d->M - 1) * d->ldc + (geglu ? d->N / 2 : d->N));
+    const unsigned long long r_ext = d->residual ? 2ull * ((unsigned long long)(d->M - 1) * d->ldr + d->N) : 0;
+    const bool out_ok = esz * (unsigned long long)(d->M + 256) * d->ldc < lim && 2ull * (unsigned long long)(d->M + 256) * d->ldr < lim;
     const bool dma_ok = dma_enabled && d->K % 64 == 0 && d->N % 4 == 0 && (!conv || d->cin % 64 == 0) &&
-                        a_ext < lim && w_ext < lim && (!geglu || d->N >= 64);
+                        a_ext < lim && w_ext < lim && (!geglu || d->N >= 64) && out_ok;
     a.a_bytes = (unsigned)a_ext;
     a.w_bytes = (unsigned)w_ext;
+    a.c_bytes = (unsigned)c_ext;
+    a.r_bytes = (unsigned)r_ext;
     if (dma_ok) {
         // tile choice: the large (256-row, 8-wave) tiles halve the LDS traffic per MFMA but need >= ~1.5 waves of 256 tiles
         static const int force = []() { const char* e = getenv("VCX_GEMM_CFG"); return e ? atoi(e) : -1; }();

@@ -24,6 +24,7 @@ struct GemmArgs {
     float alpha;
     int tiles_m, tiles_n;
     unsigned a_bytes, w_bytes;   // operand extents for the DMA kernel's buffer descriptors (whole problem, not the launch's rows)
+    unsigned c_bytes, r_bytes;   // output / residual extents (the DMA kernel's epilogue addresses them through descriptors too)
     int m_begin;   // first output row of this launch (tail split of large-tile launches); rows are < M
     int tune;   // experiment bits from $VCX_GEMM_TUNE (0 in production)
 };

@@ -236,48 +236,90 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
                     }
                 }
             } else {
-                f4 bv[NFRAG];
-                if (flags & VCX_GEMM_BIAS_N) {
+                // Output and residual are addressed through buffer descriptors: rows >= M fall outside the extent (stores
+                // dropped, loads return 0), columns >= N get an out-of-range offset - no exec-mask branches, one 32-bit
+                // VALU add per access.  Column-fragment outer / 16-row group inner keeps one bias vector (4 registers) live,
+                // and the residual fetch runs RD accesses ahead of its use (C may alias R, so the compiler cannot hoist
+                // loads above earlier stores by itself; issuing them early here hides the memory round trip).
+                constexpr int ES = OUT_F32 ? 4 : 2;
+                constexpr int RD = NFRAG, NPAIR = NFRAG * MFRAG;   // residual prefetch distance: one 16-row group
+                const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.R), 0, (int)p.r_bytes, 0x00020000);
+                const unsigned coff = ((unsigned)mbase * (unsigned)p.ldc + (unsigned)nbase) * ES;
+                const unsigned roff = ((unsigned)mbase * (unsigned)p.ldr + (unsigned)nbase) * 2u;
+                const unsigned cstep = 16u * (unsigned)p.ldc * ES, rstep = 32u * (unsigned)p.ldr;
+                const bool has_res = flags & VCX_GEMM_RESIDUAL;
+                // a row-indexed addend (time embedding) is one row for the whole tile except where a tile straddles two frames
+                const int m_first = p.m_begin + tile_m * TBM;
+                const int radd_row = m_first / p.rowadd_div;
+                const bool radd_tile = (flags & VCX_GEMM_ROWADD) && (min(m_first + TBM, p.M) - 1) / p.rowadd_div == radd_row;
+                const bool per_row = (flags & VCX_GEMM_BIAS_M) || ((flags & VCX_GEMM_ROWADD) && !radd_tile);
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                u2v rr[RD];
+                // access i = b * NFRAG + a: all column fragments of one 16-row group back to back, so that every 128-byte
+                // line of C is completed within a few consecutive stores (partial lines that linger get evicted from L2
+                // half-written; measured 1.5x slower with the loops the other way round)
+                auto fetch = [&](int i) {
+                    rr[i % RD] = __builtin_amdgcn_raw_buffer_load_b64(srd_r, roff + (unsigned)(i / NFRAG) * rstep + (unsigned)(i % NFRAG) * 32u, 0, 0);
+                };
+                if (has_res) {
 #pragma unroll
-                    for (int a = 0; a < NFRAG; ++a) bv[a] = *reinterpret_cast<const f4*>(p.bias + min(nbase + a * 16, p.N - 4));
+                    for (int i = 0; i < RD; ++i) fetch(i);
+                }
+                f4 bv[NFRAG];
+#pragma unroll
+                for (int a = 0; a < NFRAG; ++a) {
+                    const int nc = min(nbase + a * 16, p.N - 4);
+                    bv[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nc) : f4{0.f, 0.f, 0.f, 0.f};
+                    if (radd_tile) {
+                        const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)radd_row * p.N + nc);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bv[a][r] += rv[r];
+                    }
                 }
 #pragma unroll
                 for (int b = 0; b < MFRAG; ++b) {
-                    const int m = mbase + b * 16;
-                    const int mc = min(m, p.M - 1);
-                    h4 rr[NFRAG];           // one 16-row group's residual loads are issued together
-                    if (flags & VCX_GEMM_RESIDUAL) {
-#pragma unroll
-                        for (int a = 0; a < NFRAG; ++a)
-                            rr[a] = *reinterpret_cast<const h4*>(p.R + (int64_t)mc * p.ldr + min(nbase + a * 16, p.N - 4));
-                    }
-                    const float bm = (flags & VCX_GEMM_BIAS_M) ? p.bias[mc] : 0.f;
-                    const float* radd = (flags & VCX_GEMM_ROWADD) ? p.rowadd + (int64_t)(mc / p.rowadd_div) * p.N : nullptr;
+                    const unsigned crow = coff + (unsigned)b * cstep;
 #pragma unroll
                     for (int a = 0; a < NFRAG; ++a) {
+                        const int i = b * NFRAG + a;
                         const int n0 = nbase + a * 16;
                         float v[4];
+                        if (per_row) {      // rare: V^T projections (per-row bias) and tiles that straddle two addend rows
+                            // same arithmetic as the tile-uniform case, (bias + addend) first and one fma: a row's result must
+                            // not depend on how the batch happens to align tiles with frames (bit-exact batch invariance)
+                            const int mc = min(mbase + b * 16, p.M - 1);
+                            f4 t = bv[a];
+                            if (flags & VCX_GEMM_ROWADD) {
+                                const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)(mc / p.rowadd_div) * p.N + min(n0, p.N - 4));
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + bm;
-                        if (flags & VCX_GEMM_BIAS_N) {
+                                for (int r = 0; r < 4; ++r) t[r] += rv[r];
+                            }
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += bv[a][r];
+                            for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[a][b][r], p.alpha, t[r]);
+                            if (flags & VCX_GEMM_BIAS_M) {
+                                const float bm = p.bias[mc];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += bm;
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[a][b][r], p.alpha, bv[a][r]);
                         }
-                        if (radd) {
-                            const f4 rv = *reinterpret_cast<const f4*>(radd + min(n0, p.N - 4));
+                        if (has_res) {
+                            const u2v raw = rr[i % RD];
+                            if (i + RD < NPAIR) fetch(i + RD);
+                            const h4 rv = __builtin_bit_cast(h4, raw);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
                         }
-                        if (flags & VCX_GEMM_RESIDUAL) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[a][r];
-                        }
-                        if (m < p.M && n0 < p.N) {
-                            if (OUT_F32)
-                                *reinterpret_cast<f4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n0) = f4{v[0], v[1], v[2], v[3]};
-                            else
-                                *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n0) =
-                                    h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        const unsigned voff = n0 < p.N ? crow + (unsigned)(a * 16 * ES) : OOB;
+                        if (OUT_F32) {
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, f4{v[0], v[1], v[2], v[3]}), srd_c, voff, 0, 0);
+                        } else {
+                            const h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, o), srd_c, voff, 0, 0);
                         }
                     }
                 }
