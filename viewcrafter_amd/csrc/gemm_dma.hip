@@ -190,20 +190,33 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
         if (more) load_tile(lkt, cur ^ 1);        // async: lands in the other buffer while this one is consumed
         const half_t* cx = sX + cur * TBM * BK;
         const half_t* cw = sW + cur * BN * BK;
+        // Fragment reads are software-pipelined by hand: the next weight fragment is requested before the 8-16 MFMAs that
+        // use the current one, and the activation fragments of the second K half are re-requested right after their last
+        // use in the first half.  (Left to itself hipcc issues every ds_read immediately before the MFMA that needs it -
+        // one exposed LDS round trip per MFMA group - and on gfx950 nothing else runs on the SIMD while it waits:
+        // tools/ubench.hip shows MFMA and VALU/other issue of the two waves of a SIMD do not overlap.)
+        {
+            h8 xf[MFRAG];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            h8 wf[NFRAG], xf[MFRAG];
+            for (int b = 0; b < MFRAG; ++b) xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(wm * WM + b * 16 + lr, lg));
+            h8 wcur = *reinterpret_cast<const h8*>(cw + lds_off(wn * WN + lr, lg));
 #pragma unroll
-            for (int a = 0; a < NFRAG; ++a)
-                wf[a] = *reinterpret_cast<const h8*>(cw + lds_off(wn * WN + a * 16 + lr, kk * 4 + lg));
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int b = 0; b < MFRAG; ++b)
-                xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(wm * WM + b * 16 + lr, kk * 4 + lg));
+                for (int a = 0; a < NFRAG; ++a) {
+                    h8 wnext = wcur;
+                    if (a + 1 < NFRAG) wnext = *reinterpret_cast<const h8*>(cw + lds_off(wn * WN + (a + 1) * 16 + lr, kk * 4 + lg));
+                    else if (kk == 0) wnext = *reinterpret_cast<const h8*>(cw + lds_off(wn * WN + lr, 4 + lg));
 #pragma unroll
-            for (int a = 0; a < NFRAG; ++a)
-#pragma unroll
-                for (int b = 0; b < MFRAG; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < MFRAG; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur, xf[b], acc[a][b], 0, 0, 0);
+                        if (a == NFRAG - 1 && kk == 0)
+                            xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(wm * WM + b * 16 + lr, 4 + lg));
+                    }
+                    wcur = wnext;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         if (ckt == nk - 1) {
             // ---- epilogue: acc[a][b][r] = out[m][n], m = tile_m*BM + wm*64 + b*16 + lr, n = tile_n*BN + wn*(BN/2) + a*16 + lg*4 + r
