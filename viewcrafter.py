@@ -71,6 +71,9 @@ class ViewCrafter:
         r = torch.load(path) if path.endswith(".pt") else torch.from_numpy(np.load(path))
         out = self.run_diffusion(r.float())
         torch.save(out.cpu(), os.path.join(self.opts.save_dir, "diffusion0.pt"))
+        # like the reference's nvs_single_view (viewcrafter.py:118-121): write the generated clip as a video as well
+        from viewcrafter_amd.utils.video_io import save_video
+        save_video((out + 1.0) / 2.0, os.path.join(self.opts.save_dir, "diffusion0.mp4"), fps=10, value_range=(0.0, 1.0))
         return out
 
     # ------------------------------------------------------------------ geometry stages (reference)
