@@ -146,6 +146,9 @@ int vcx_softmax_rows_f16(void* x, int64_t rows, int n, int64_t ld, void* stream)
  * ---------------------------------------------------------------------------------- */
 /* x*sigmoid(x) on fp32 -> fp32 (emb_layers SiLU, openaimodel3d.py:158-164). */
 int vcx_silu_f32(const float* x, float* y, int64_t n, void* stream);
+/* exact (erf) GELU on fp16 -> fp16, y may alias x (nn.GELU of the Resampler feed-forward,
+ * lvdm/modules/encoders/resampler.py:27-34). */
+int vcx_gelu_f16(const void* x, void* y, int64_t n, void* stream);
 /* sinusoidal embedding, lvdm/models/utils_diffusion.py:8-28: out[b] = [cos(t f) | sin(t f)] */
 int vcx_timestep_embedding_f32(const int64_t* t, float* out, int B, int dim, float max_period,
                                void* stream);

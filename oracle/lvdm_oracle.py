@@ -395,6 +395,38 @@ def decode_first_stage(sd, dd, z, scale_factor=0.18215):
 # =============================================================================================
 # DDIM sampler  (lvdm/models/samplers/ddim.py)
 # =============================================================================================
+# =============================================================================================
+# image_proj_model: Resampler (lvdm/modules/encoders/resampler.py), runs once per video before the loop
+# =============================================================================================
+def resampler_forward(sd, hp, x):
+    """Reference resampler.py:96-145 (`Resampler.forward`) with PerceiverAttention :51-93 and FeedForward :27-34.
+    sd: state dict with the reference's keys; hp: constructor kwargs; x [B, n1, embedding_dim] -> [B, nq(*T), output_dim]."""
+    heads, dh = hp["heads"], hp["dim_head"]
+
+    def ln(p, t):
+        return F.layer_norm(t, (t.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+    def split(t):                                     # reshape_tensor :37-48: (b, l, h*d) -> (b, h, l, d)
+        b, l, _ = t.shape
+        return t.view(b, l, heads, -1).transpose(1, 2)
+
+    lat = sd["latents"].repeat(x.shape[0], 1, 1)      # :137
+    x = _lin(sd, "proj_in", x)                        # :138
+    for i in range(hp["depth"]):
+        a, f = f"layers.{i}.0", f"layers.{i}.1"
+        xn, lnl = ln(a + ".norm1", x), ln(a + ".norm2", lat)                          # :72-73
+        q = _lin(sd, a + ".to_q", lnl)                                                  # :77
+        k, v = _lin(sd, a + ".to_kv", torch.cat((xn, lnl), dim=-2)).chunk(2, dim=-1)    # :78-79
+        q, k, v = split(q), split(k), split(v)
+        scale = 1 / math.sqrt(math.sqrt(dh))                                            # :86 (applied to q and k)
+        w = torch.softmax(((q * scale) @ (k * scale).transpose(-2, -1)).float(), dim=-1)
+        o = (w @ v).permute(0, 2, 1, 3).reshape(lat.shape[0], lat.shape[1], -1)         # :88-91
+        lat = _lin(sd, a + ".to_out", o) + lat                                          # :93, :140
+        h = _lin(sd, f + ".1", ln(f + ".0", lat))
+        lat = _lin(sd, f + ".3", F.gelu(h)) + lat                                       # :141
+    return ln("norm_out", _lin(sd, "proj_out", lat))                                    # :143-144
+
+
 def ddim_sample(apply_model, tables, scale_arr, x_T, cond, uncond, steps, eta=0.0, cfg_scale=7.5, guidance_rescale=0.7,
                 spacing="uniform_trailing", parameterization="v", noise_fn=None, uncond_img=None, cfg_img=None):
     """DDIMSampler.sample/ddim_sampling/p_sample_ddim, ddim.py:62-281, for the ViewCrafter call

@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 REF = os.environ.get("VCX_REFERENCE", "/root/reference")
 
 from oracle.weights import synth_input, synth_state_dict  # noqa: E402
-from tests.tiny_config import TINY_DDCONFIG, TINY_UNET, tiny_model_params  # noqa: E402
+from tests.tiny_config import TINY_DDCONFIG, TINY_RESAMPLER, TINY_UNET, tiny_model_params  # noqa: E402
 
 
 class AttrDict(dict):
@@ -209,10 +209,29 @@ def gen_ddim(out):
         print("multicond", float(samples.abs().mean()))
 
 
+def gen_resampler(out):
+    """image_proj_model (lvdm/modules/encoders/resampler.py): pure torch, imported unmodified."""
+    from lvdm.modules.encoders.resampler import Resampler
+    torch.manual_seed(0)
+    m = Resampler(**TINY_RESAMPLER).eval()
+    shapes = load_synth(m)
+    out["resampler_keys"] = np.array(sorted(shapes.keys()))
+    out["resampler_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    with torch.no_grad():
+        for tag, (b, n1) in {"a": (2, 17), "b": (1, 40)}.items():
+            x = synth_input(f"resampler_x_{tag}", (b, n1, TINY_RESAMPLER["embedding_dim"]))
+            y = m(x)
+            out[f"resampler_out_{tag}"] = y.numpy()
+            print("resampler", tag, tuple(y.shape), float(y.abs().mean()))
+
+
 def main():
     import_reference()
     torch.set_num_threads(8)
-    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim)):
+    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
+                     ("resampler_tiny", gen_resampler)):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         out = {}
         fn(out)
         path = os.path.join(HERE, name + ".npz")

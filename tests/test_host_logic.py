@@ -222,3 +222,19 @@ def test_multicond_sampler_schedule_uses_the_unfixed_scale_arr_prev(tiny_model):
     assert np.allclose(m.ddim_scale_arr_prev.numpy(), g["multicond_scale_arr_prev"])
     assert float(a.ddim_scale_arr_prev[0]) == 1.0 and float(m.ddim_scale_arr_prev[0]) == float(m.ddim_scale_arr[0])
     assert np.allclose(m._host["ratio"], (m.ddim_scale_arr_prev / m.ddim_scale_arr).numpy())
+
+
+def test_image_proj_model_resolves_natively_with_reference_state_dict_names():
+    """TARGET_ALIASES maps the YAML's Resampler target onto the libvcx implementation; its parameter names / shapes are
+    the reference's (pinned by the fixture written from the imported reference module)."""
+    import numpy as np
+    import os
+    from viewcrafter_amd.config import Config
+    from viewcrafter_amd.utils.diffusion_utils import instantiate_from_config
+    from tests.tiny_config import TINY_RESAMPLER
+    m = instantiate_from_config(Config(target="lvdm.modules.encoders.resampler.Resampler", params=Config.wrap(dict(TINY_RESAMPLER))))
+    assert type(m).__module__ == "viewcrafter_amd.lvdm.modules.encoders.resampler"
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "resampler_tiny.npz"))
+    want = {str(k): eval(str(s)) for k, s in zip(g["resampler_keys"], g["resampler_shapes"])}
+    have = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert have == want

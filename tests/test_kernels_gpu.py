@@ -349,3 +349,14 @@ def test_ddim_step(eta_noise):
     ref = math.sqrt(a_prev) * p0 + math.sqrt(1 - a_prev - sigma ** 2) * e + (sigma * nz if eta_noise else 0)
     assert float((x0 - p0).abs().max()) < 1e-4
     assert float((xp - ref).abs().max()) < 1e-4
+
+
+def test_gelu_f16_exact_erf():
+    """vcx_gelu_f16 (nn.GELU of the Resampler feed-forward): exact-erf form, in place, incl. the tails."""
+    from viewcrafter_amd import ops
+    x = torch.cat([rnd(4096, scale=3.0, seed=11), torch.tensor([-20.0, -6.0, -0.0, 0.0, 6.0, 20.0, 1e-4, -1e-4])]).to(DEV).half()
+    ref = torch.nn.functional.gelu(x.float())
+    y = ops.gelu_(x.clone())
+    assert y.dtype == torch.float16
+    assert float((y.float() - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
+    check(y, ref, tol=1e-3, name="gelu")

@@ -12,7 +12,7 @@ import torch
 
 from oracle import lvdm_oracle as O
 from oracle.weights import synth_input
-from tests.tiny_config import TINY_DDCONFIG, TINY_UNET, tiny_model_params
+from tests.tiny_config import TINY_DDCONFIG, TINY_RESAMPLER, TINY_UNET, tiny_model_params
 from tests.util import SCHEDULE_BUFFERS, golden, load_synth, psnr, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -167,3 +167,22 @@ def test_multicond_ddim_trajectory_vs_reference_golden(model):
     e = rel_l2(samples, g["multicond_samples"])
     print(f"multi-cond ddim: final latent rel-L2 {e:.3e}")
     assert e <= DDIM_TOL
+
+
+def test_resampler_vs_reference_golden():
+    """image_proj_model on libvcx (GEMMs, d=64 flash attention over image tokens ++ latents, GELU, LayerNorms) against the
+    reference's own outputs and the fp32 oracle; fp16 token stream, bound 8e-3 like the other transformer paths."""
+    from viewcrafter_amd.lvdm.modules.encoders.resampler import Resampler
+    m = Resampler(**TINY_RESAMPLER).eval()
+    sd = load_synth(m)
+    m = m.to(DEV)
+    g = golden("resampler_tiny")
+    assert sorted(sd.keys()) == [str(k) for k in g["resampler_keys"]]           # strict-load compatible naming
+    for tag, (b, n1) in {"a": (2, 17), "b": (1, 40)}.items():
+        x = synth_input(f"resampler_x_{tag}", (b, n1, TINY_RESAMPLER["embedding_dim"]))
+        y = m(x.to(DEV))
+        assert y.dtype == torch.float32 and tuple(y.shape) == g[f"resampler_out_{tag}"].shape
+        assert rel_l2(y, torch.from_numpy(g[f"resampler_out_{tag}"])) <= 8e-3, tag
+    x = synth_input("resampler_fresh", (3, 257, TINY_RESAMPLER["embedding_dim"]))   # CLIP-like token count (odd, > 256)
+    ref = O.resampler_forward({k: v for k, v in sd.items()}, TINY_RESAMPLER, x)
+    assert rel_l2(m(x.to(DEV)), ref) <= 8e-3

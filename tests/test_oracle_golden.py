@@ -8,7 +8,7 @@ import torch
 
 from oracle import lvdm_oracle as O
 from oracle.weights import synth_input, synth_state_dict
-from tests.tiny_config import TINY_DDCONFIG, TINY_UNET
+from tests.tiny_config import TINY_DDCONFIG, TINY_RESAMPLER, TINY_UNET
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -147,3 +147,14 @@ def test_multicond_ddim_trajectory_matches_reference():
                                   steps=5, eta=0.0, cfg_scale=7.5, guidance_rescale=0.7, uncond_img=uctx2, cfg_img=3.0)
     assert max_rel(torch.stack(preds).numpy(), g["multicond_pred_x0"]) < 2e-4
     assert max_rel(x0.numpy(), g["multicond_samples"]) < 2e-4
+
+
+def test_resampler_oracle_matches_reference():
+    """image_proj_model (reference lvdm/modules/encoders/resampler.py, imported unmodified by gen_golden.py)."""
+    g = load("resampler_tiny")
+    sd, _ = sd_from_fixture(g["resampler_keys"], g["resampler_shapes"])
+    for tag, (b, n1) in {"a": (2, 17), "b": (1, 40)}.items():
+        x = synth_input(f"resampler_x_{tag}", (b, n1, TINY_RESAMPLER["embedding_dim"]))
+        y = O.resampler_forward(sd, TINY_RESAMPLER, x)
+        assert y.shape == g[f"resampler_out_{tag}"].shape
+        assert max_rel(y.numpy(), g[f"resampler_out_{tag}"]) <= 2e-5, tag

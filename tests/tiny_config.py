@@ -17,6 +17,11 @@ TINY_DDCONFIG = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, 
                      num_res_blocks=2, attn_resolutions=[], dropout=0.0)
 
 
+# image_proj_model (configs/inference_pvd_1024.yaml:100-111), narrowed: dim 128, 2 heads of 64, 2 layers, 4 queries x 3 frames
+TINY_RESAMPLER = dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=4, embedding_dim=192, output_dim=128, ff_mult=4,
+                      video_length=3)
+
+
 def tiny_model_params(unet_target, vae_target, base_scale=0.3):
     """`params` of the model YAML (configs/inference_pvd_1024.yaml:6-110) with the tiny sub-configs and Identity
     conditioners (the CLIP encoders run once per video and are out of scope)."""

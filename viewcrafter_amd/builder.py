@@ -15,15 +15,22 @@ IDENTITY = Config(target="torch.nn.Identity")
 
 
 def model_config_from_yaml(path, conditioners="config"):
-    """conditioners: 'config' keeps the YAML's CLIP/Resampler targets (they resolve to the reference implementation,
-    which must be importable); 'identity' replaces them with nn.Identity so that pre-computed embeddings can be fed
-    (benchmarks, tests, and any caller that runs the conditioners elsewhere)."""
+    """conditioners: 'config' keeps the YAML's targets (the two OpenCLIP encoders resolve to the reference implementation,
+    which must be importable together with open_clip / kornia; the Resampler `image_proj_model` resolves to this package's
+    libvcx implementation through TARGET_ALIASES); 'clip_external' replaces only the two CLIP encoders with nn.Identity
+    (their token embeddings are computed elsewhere and fed in, the projector runs natively); 'identity' replaces all
+    three (benchmarks and tests feed the final context tensors)."""
     cfg = load_yaml(path)
     mc = copy.deepcopy(cfg["model"])
     mc["params"]["unet_config"]["params"]["use_checkpoint"] = False
     if conditioners == "identity":
         for k in ("cond_stage_config", "img_cond_stage_config", "image_proj_stage_config"):
             mc["params"][k] = IDENTITY
+    elif conditioners == "clip_external":
+        for k in ("cond_stage_config", "img_cond_stage_config"):
+            mc["params"][k] = IDENTITY
+    elif conditioners != "config":
+        raise ValueError(f"conditioners must be 'config', 'clip_external' or 'identity' (got {conditioners!r})")
     return Config.wrap(mc)
 
 

@@ -1,5 +1,6 @@
 // Element-wise, layout and DDIM-update kernels (all HBM/launch bound).
 #include "vcx_common.h"
+#include "gemm_args.h"   // gelu_erf
 #include <math.h>
 
 namespace {
@@ -153,6 +154,25 @@ inline unsigned grid_for(int64_t n, int cap = 4096) {
 }
 
 }  // namespace
+
+__global__ void gelu_f16_kernel(const half_t* x, half_t* y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const h8 v = reinterpret_cast<const h8*>(x)[i];
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)vcxgemm::gelu_erf((float)v[e]);
+        reinterpret_cast<h8*>(y)[i] = o;
+    }
+}
+
+extern "C" int vcx_gelu_f16(const void* x, void* y, int64_t n, void* stream) {
+    VCX_REQUIRE(x && y && n > 0 && n % 8 == 0, "vcx_gelu_f16: bad arguments (n must be a multiple of 8)");
+    VCX_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "vcx_gelu_f16: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 4.0 * n);
+    hipLaunchKernelGGL(gelu_f16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const half_t*)x, (half_t*)y, n / 8);
+    return vcx_check_launch("vcx_gelu_f16");
+}
 
 extern "C" int vcx_silu_f32(const float* x, float* y, int64_t n, void* stream) {
     VCX_REQUIRE(x && y && n > 0, "vcx_silu_f32: bad arguments");

@@ -165,6 +165,12 @@ def silu_f32(x):
     return out
 
 
+def gelu_(x):
+    """exact-erf GELU in place on a contiguous fp16 tensor (nn.GELU)."""
+    check(lib().vcx_gelu_f16(x.data_ptr(), x.data_ptr(), x.numel(), _stream()), "gelu")
+    return x
+
+
 def timestep_embedding(t, dim, max_period=10000.0):
     t = t.to(torch.int64).contiguous()
     out = torch.empty((t.shape[0], dim), dtype=_f32, device=t.device)

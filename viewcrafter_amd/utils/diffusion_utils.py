@@ -12,6 +12,8 @@ TARGET_ALIASES = {
     "lvdm.models.ddpm3d.LatentDiffusion": "viewcrafter_amd.lvdm.models.ddpm3d.LatentDiffusion",
     "lvdm.modules.networks.openaimodel3d.UNetModel": "viewcrafter_amd.lvdm.modules.networks.openaimodel3d.UNetModel",
     "lvdm.models.autoencoder.AutoencoderKL": "viewcrafter_amd.lvdm.models.autoencoder.AutoencoderKL",
+    "lvdm.modules.encoders.resampler.Resampler": "viewcrafter_amd.lvdm.modules.encoders.resampler.Resampler",
+    "lvdm.modules.encoders.resampler.ImageProjModel": "viewcrafter_amd.lvdm.modules.encoders.resampler.ImageProjModel",
 }
 
 
