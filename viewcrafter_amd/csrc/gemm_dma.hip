@@ -115,10 +115,10 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
     };
 
     // issue the DMA of K-step kt of the load tile into LDS buffer `buf`
-    auto load_tile = [&](int kt, int buf) {
+    auto load_tile = [&](int kt, int buf, int parts = 3) {       // parts: bit 0 = activation rows, bit 1 = weight rows
         half_t* dx = sX + buf * TBM * BK + wave * 8 * BK;
         half_t* dw = sW + buf * BN * BK + wave * 8 * BK;
-        if (CONV) {
+        if (CONV && (parts & 1)) {
             if (p.ups) {
                 // source offset of tap (ky,kx) relative to tap (0,0): ((by+ky)>>1, (bx+kx)>>1) pixels, by/bx = parity of iy0/ix0
                 const unsigned cb = (unsigned)ci0 * 2u, rowb = (unsigned)(p.in_w * (int)p.lda * 2), pixb = (unsigned)((int)p.lda * 2);
@@ -147,16 +147,18 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
                 if (++tkx == p.kw) { tkx = 0; ++tky; }
                 tap_off = (unsigned)((tky * p.in_w + tkx) * (int)p.lda * 2);
             }
-        } else {
+        } else if (!CONV && (parts & 1)) {
             const unsigned soff = (unsigned)kt * (BK * 2);
 #pragma unroll
             for (int i = 0; i < XROWS; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + RSTEP * i * BK), 16, xoff[i], soff, 0, 0);
         }
-        const unsigned soffw = (unsigned)kt * (BK * 2);
+        if (parts & 2) {
+            const unsigned soffw = (unsigned)kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < WROWS; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(dw + RSTEP * i * BK), 16, woff[i], soffw, 0, 0);
+            for (int i = 0; i < WROWS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(dw + RSTEP * i * BK), 16, woff[i], soffw, 0, 0);
+        }
     };
 
     const int wm = wave % Cfg::NWM, wn = wave / Cfg::NWM;
@@ -187,7 +189,13 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
             if (ltile < ntiles) init_load(ltile);
         }
         const bool more = ltile < ntiles;
-        if (more) load_tile(lkt, cur ^ 1);        // async: lands in the other buffer while this one is consumed
+        // the two waves of a SIMD (wave w and w + 4) issue their DMA at different points of the K-step, so that one is in its
+        // MFMA stream while the other sits in the (60-180 cycle per instruction) DMA issue
+        // Convolutions only: their operands come from L2 / the Infinity Cache and land within half a K-step (-3..5 % time).  A
+        // linear layer's activation rows come from HBM and need the whole K-step; issuing even just its weight slice late costs
+        // 10-30 % (measured), so linear layers keep both waves early.
+        const int late_parts = (CONV && Cfg::THREADS == 512 && wave >= 4) ? 3 : 0;
+        if (more) load_tile(lkt, cur ^ 1, 3 & ~late_parts);        // async: lands in the other buffer while this one is consumed
         const half_t* cx = sX + cur * TBM * BK;
         const half_t* cw = sW + cur * BN * BK;
         // Fragment reads are software-pipelined by hand: the next weight fragment is requested before the 8-16 MFMAs that
@@ -202,6 +210,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
             h8 wcur = *reinterpret_cast<const h8*>(cw + lds_off(wn * WN + lr, lg));
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
+                if (kk == 1 && more && late_parts) load_tile(lkt, cur ^ 1, late_parts);
 #pragma unroll
                 for (int a = 0; a < NFRAG; ++a) {
                     h8 wnext = wcur;
