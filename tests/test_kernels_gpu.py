@@ -243,6 +243,27 @@ def test_flash_online_softmax_rescale_forced():
     check(out, attn_ref(q[None], k[None], v[None], 0.125)[0], tol=3e-3, name="flash rescale")
 
 
+@pytest.mark.parametrize("growth", [1.5, 6.0, 12.0])
+def test_flash_deferred_max_staircase(growth):
+    """The running max is only moved when a tile exceeds it by more than 2^8 (deferred rescale).  Scores that climb by
+    `growth` log2-units per 64-key tile exercise all three regimes: never / sometimes / always over the threshold, including
+    tiles exponentiated against a stale max right before a rescale."""
+    from viewcrafter_amd import ops
+    n, tiles = 640, 10
+    q = rnd(n, 64, seed=61) * 0.3
+    k = rnd(n, 64, seed=62) * 0.3
+    v = rnd(n, 64, seed=63)
+    # add a component along e0 so that q.k/8*log2(e) grows by `growth` per tile for every query with q0 = 1
+    q[:, 0] = 1.0
+    k[:, 0] = (torch.arange(n) // 64).float() * (growth * 8.0 / 1.4426950408889634)
+    k[:, 0] += rnd(n, seed=64) * 0.5
+    q, k, v = q.to(DEV).half(), k.to(DEV).half(), v.to(DEV).half()
+    out = torch.empty(n, 64, device=DEV, dtype=torch.float16)
+    ops.flash_attn(q, k, v.t().contiguous(), out, n_groups=1, heads=1, nq=n, nk=n, kv_rows=n, kv_div=1, ldq=64, ldk=64,
+                   ldvt=n, ldo=64, scale=0.125)
+    check(out, attn_ref(q[None], k[None], v[None], 0.125)[0], tol=3e-3, name=f"flash staircase {growth}")
+
+
 @pytest.mark.parametrize("T,shared", [(5, True), (4, False)])
 def test_flash_cross_attention_text_plus_image(T, shared):
     """softmax(QK_txt)V_txt + softmax(QK_img)V_img with 77 text keys (padded to 80 rows)."""

@@ -22,6 +22,7 @@ namespace {
 // (a sum over keys does not care about the order as long as P and V agree on it).
 // =======================================================================================
 constexpr int FK = 64;   // keys per tile
+constexpr float FLASH_DEFER = 8.0f;   // log2 units: a tile's probabilities may reach 2^8 before the running max is moved
 
 struct FlashArgs {
     const half_t* q;
@@ -158,21 +159,31 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][kb][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[b], mx * p.scale_log2);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
-            m_run[b] = m_new;
+            // Deferred max update: the running max (log2 units) moves only when some query of the wave would exceed it by more
+            // than FLASH_DEFER; otherwise the tile is exponentiated against the old max (P <= 2^FLASH_DEFER: exact in the
+            // fp32 sums, same relative precision in fp16) and the O / l rescale - 64 multiplies and an exponential per lane -
+            // is skipped.  The decision precedes the exponentiation of the tile it covers and the previous tile's P V is
+            // complete, so everything still at the old scale (O, l) is rescaled exactly once.
+            const float cand = mx * p.scale_log2;
+            if (__builtin_amdgcn_ballot_w64(cand > m_run[b] + FLASH_DEFER) != 0) {     // wave-uniform branch
+                const float m_new = fmaxf(m_run[b], cand);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+                m_run[b] = m_new;
+                l_run[b] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { oacc[b][0][i] *= alpha; oacc[b][1][i] *= alpha; }
+            }
+            const float m_use = m_run[b];
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][kb][r], p.scale_log2, -m_new));
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][kb][r], p.scale_log2, -m_use));
                     sacc[b][kb][r] = pv;
                     psum += pv;
                 }
-            l_run[b] = l_run[b] * alpha + psum;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { oacc[b][0][i] *= alpha; oacc[b][1][i] *= alpha; }
+            l_run[b] += psum;
         }
         // ---- O^T += V^T P^T; each V^T fragment feeds QB MFMAs
 #pragma unroll
