@@ -468,7 +468,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const unsigned long long c_ext = esz * ((unsigned long long)(d->M - 1) * d->ldc + (geglu ? d->N / 2 : d->N));
     const unsigned long long r_ext = d->residual ? 2ull * ((unsigned long long)(d->M - 1) * d->ldr + d->N) : 0;
     const bool out_ok = esz * (unsigned long long)(d->M + 256) * d->ldc < lim && 2ull * (unsigned long long)(d->M + 256) * d->ldr < lim;
-    const bool dma_ok = dma_enabled && d->K % 64 == 0 && d->N % 4 == 0 && (!conv || d->cin % 64 == 0) &&
+    const bool dma_ok = dma_enabled && d->K % 64 == 0 && d->N % ((geglu || f32) ? 4 : 8) == 0 && (!conv || d->cin % 64 == 0) &&   // fp16 output goes out in dwordx4 pieces of 8 columns
                         a_ext < lim && w_ext < lim && (!geglu || d->N >= 64) && out_ok;
     a.a_bytes = (unsigned)a_ext;
     a.w_bytes = (unsigned)w_ext;
