@@ -330,16 +330,26 @@ __global__ void __launch_bounds__(256) tattn_d64_kernel(TAttnArgs p) {
             oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], s == 0 ? zero16 : oacc[db], 0, 0, 0);
         }
     }
-    if (rvalid) {
-        half_t* dst = p.o + (((int64_t)b * p.T + lq) * p.P + pix) * p.ldo + h * 64;
+    // Output row (frame lq) of this (pixel, head): column group k = 4 db + gq holds columns 8k + 4 hi .. + 3 in this lane, i.e. a
+    // row is split 8 bytes / 8 bytes between lanes l and l + 32.  v_permlane32_swap on the packed words of groups k (vdst) and
+    // k + 1 (src) leaves lanes 0-31 with columns 8k .. 8k+7 and lanes 32-63 with 8k+8 .. 8k+15: four 16-byte stores per lane
+    // instead of eight 8-byte ones (T21 of the HIP guide; the store tail is issue-bound).
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    u2v pk[8];
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int d0 = db * 32 + 8 * gq + 4 * hi;
-                *reinterpret_cast<h4*>(dst + d0) = h4{(half_t)oacc[db][gq * 4 + 0], (half_t)oacc[db][gq * 4 + 1],
-                                                      (half_t)oacc[db][gq * 4 + 2], (half_t)oacc[db][gq * 4 + 3]};
-            }
+        for (int gq = 0; gq < 4; ++gq)
+            pk[db * 4 + gq] = __builtin_bit_cast(u2v, h4{(half_t)oacc[db][gq * 4 + 0], (half_t)oacc[db][gq * 4 + 1],
+                                                        (half_t)oacc[db][gq * 4 + 2], (half_t)oacc[db][gq * 4 + 3]});
+    half_t* dst = p.o + (((int64_t)b * p.T + lq) * p.P + pix) * p.ldo + h * 64 + hi * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const unsigned a0 = pk[k][0], a1 = pk[k][1], b0 = pk[k + 1][0], b1 = pk[k + 1][1];
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        if (rvalid) *reinterpret_cast<u4v*>(dst + 8 * k) = u4v{s0[0], s1[0], s0[1], s1[1]};
     }
 }
 
