@@ -21,19 +21,21 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + (
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int TBN, int XST>
+template <int TBM, int TBN, int XST>
 __global__ void __launch_bounds__(512, 2) gemm_pp(const half_t* X, const half_t* W, half_t* C, int M, int N, int K) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WN = TBN / 4, NF = WN / 16;                // wave strip (64 or 80 columns) and its 16-column fragments
     constexpr int WP = TBN / 64;                           // DMA pieces of the weight tile per wave (4 or 5)
-    half_t* sX = reinterpret_cast<half_t*>(smem);          // [XST][256 * 64]
-    half_t* sW = sX + XST * 256 * BK;                      // [2][TBN * 64]
+    constexpr int XP = TBM / 64;                           // DMA pieces of the row tile per wave (4 or 3)
+    constexpr int GM = TBM / 2, MF = GM / 16, MH = MF / 2;  // rows per wave group, its 16-row fragments, fragments per phase
+    half_t* sX = reinterpret_cast<half_t*>(smem);          // [XST][TBM * 64]
+    half_t* sW = sX + XST * TBM * BK;                      // [2][TBN * 64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
     const int lr = lane & 15, lg = lane >> 4;
-    const int tiles_n = N / TBN, tiles_m = M / 256;
+    const int tiles_n = N / TBN, tiles_m = M / TBM;
     // XCD-aware order: blocks b, b+8, b+16, ... (same XCD) walk one contiguous band of tiles
     const int nt = tiles_m * tiles_n, q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
@@ -46,43 +48,43 @@ __global__ void __launch_bounds__(512, 2) gemm_pp(const half_t* X, const half_t*
     for (int q = 0; q < WP; ++q) {
         const int r = 64 * q + 8 * wave + (lane >> 3);
         const unsigned csrc = (unsigned)((lane & 7) ^ ((r >> 1) & 7)) * 16u;
-        if (q < 4) xoff[q] = (unsigned)((long long)(tile_m * 256 + r) * K * 2) + csrc;
+        if (q < XP) xoff[q] = (unsigned)((long long)(tile_m * TBM + r) * K * 2) + csrc;
         woff[q] = (unsigned)((long long)(tile_n * TBN + r) * K * 2) + csrc;
     }
     auto dma_x = [&](int kt, int q) {   // piece q of the X rows of K-tile kt -> stage kt % 3
-        half_t* d = sX + (kt % XST) * 256 * BK + (64 * q + 8 * wave) * BK;
+        half_t* d = sX + (kt % XST) * TBM * BK + (64 * q + 8 * wave) * BK;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_x, (lds_ptr_t)d, 16, xoff[q], (unsigned)kt * 128u, 0, 0);
     };
     auto dma_w = [&](int kt, int q) {
         half_t* d = sW + (kt & 1) * TBN * BK + (64 * q + 8 * wave) * BK;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)d, 16, woff[q], (unsigned)kt * 128u, 0, 0);
     };
-    f4 acc[NF][8];
+    f4 acc[NF][MF];
 #pragma unroll
     for (int a = 0; a < NF; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MF; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
     const int nk = K / BK;
     // prologue: W(0), X(0), X(1); rows of tile T+2 and weights of tile T+1 are issued during tile T
     constexpr int XAHEAD = XST - 1;        // the rows are fetched XAHEAD K-tiles ahead, the weights one
 #pragma unroll
     for (int q = 0; q < WP; ++q) dma_w(0, q);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dma_x(0, q);
+    for (int q = 0; q < XP; ++q) dma_x(0, q);
     if (XAHEAD == 2 && nk > 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma_x(1, q);
-        WAIT_VM(4);
+        for (int q = 0; q < XP; ++q) dma_x(1, q);
+        WAIT_VM(XP);
     } else {
         WAIT_VM(0);
     }
     BARRIER();
     if (grp == 1) BARRIER();          // group 1 runs one slot behind group 0
     for (int kt = 0; kt < nk; ++kt) {
-        const half_t* cx = sX + (kt % XST) * 256 * BK + (grp * 128) * BK;
+        const half_t* cx = sX + (kt % XST) * TBM * BK + (grp * GM) * BK;
         const half_t* cw = sW + (kt & 1) * TBN * BK + (wc * WN) * BK;
         const bool w_next = kt + 1 < nk, x_next = kt + XAHEAD < nk;
-        h8 wf[NF], xf[4];
+        h8 wf[NF], xf[MH];
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
             const int kk = ph >> 1, mh = ph & 1;
@@ -92,15 +94,15 @@ __global__ void __launch_bounds__(512, 2) gemm_pp(const half_t* X, const half_t*
                 for (int a = 0; a < NF; ++a) wf[a] = *reinterpret_cast<const h8*>(cw + lds_off(a * 16 + lr, kk * 4 + lg));
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) xf[b] = *reinterpret_cast<const h8*>(cx + lds_off((mh * 4 + b) * 16 + lr, kk * 4 + lg));
+            for (int b = 0; b < MH; ++b) xf[b] = *reinterpret_cast<const h8*>(cx + lds_off((mh * MH + b) * 16 + lr, kk * 4 + lg));
             if (ph < 2) {
                 if (w_next) {
                     dma_w(kt + 1, 2 * ph); dma_w(kt + 1, 2 * ph + 1);
                     if (WP == 5 && ph == 1) dma_w(kt + 1, 4);
                 }
-            } else if (x_next) { dma_x(kt + XAHEAD, 2 * (ph - 2)); dma_x(kt + XAHEAD, 2 * (ph - 2) + 1); }
+            } else if (x_next) { dma_x(kt + XAHEAD, 2 * (ph - 2)); if (2 * (ph - 2) + 1 < XP) dma_x(kt + XAHEAD, 2 * (ph - 2) + 1); }
             if (ph == 3) {             // the weights of tile kt+1 (and everything older) must have landed; with three row stages the rows of kt+2 may fly
-                if (XAHEAD == 2 && x_next) WAIT_VM(4); else WAIT_VM(0);
+                if (XAHEAD == 2 && x_next) WAIT_VM(XP); else WAIT_VM(0);
             }
             BARRIER();
             // ---- MFMA slot
@@ -109,17 +111,17 @@ __global__ void __launch_bounds__(512, 2) gemm_pp(const half_t* X, const half_t*
 #pragma unroll
             for (int a = 0; a < NF; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][mh * 4 + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][mh * 4 + b], 0, 0, 0);
+                for (int b = 0; b < MH; ++b)
+                    acc[a][mh * MH + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][mh * MH + b], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             BARRIER();
         }
     }
     if (grp == 0) BARRIER();          // match group 1's extra barrier
     // epilogue: plain fp16 store (acc[a][b][r] = C[m = 16 b + lr][n = 16 a + 4 lg + r] inside the wave tile)
-    half_t* cbase = C + (long long)(tile_m * 256 + grp * 128 + lr) * N + tile_n * TBN + wc * WN + lg * 4;
+    half_t* cbase = C + (long long)(tile_m * TBM + grp * GM + lr) * N + tile_n * TBN + wc * WN + lg * 4;
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
+    for (int b = 0; b < MF; ++b)
 #pragma unroll
         for (int a = 0; a < NF; ++a)
             *reinterpret_cast<h4*>(cbase + (long long)b * 16 * N + a * 16) =
@@ -138,11 +140,11 @@ int main(int argc, char** argv) {
     hipMalloc(&dx, hx.size() * 2); hipMalloc(&dw, hw.size() * 2); hipMalloc(&dc, (size_t)M * N * 2);
     hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
-    auto run = [&](auto kern, int tbn, int xst, const char* name) {
-        if (N % tbn) { printf("%s: N %% %d != 0, skipped\n", name, tbn); return; }
-        const size_t smem = (size_t)(xst * 256 + 2 * tbn) * BK * 2;
+    auto run = [&](auto kern, int tbm, int tbn, int xst, const char* name) {
+        if (N % tbn || M % tbm) { printf("%s: shape not a multiple of the tile, skipped\n", name); return; }
+        const size_t smem = (size_t)(xst * tbm + 2 * tbn) * BK * 2;
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        const int grid = (M / 256) * (N / tbn);
+        const int grid = (M / tbm) * (N / tbn);
         hipMemset(dc, 0, (size_t)M * N * 2);
         kern<<<grid, 512, smem>>>(dx, dw, dc, M, N, K);
         hipError_t e = hipDeviceSynchronize();
@@ -166,8 +168,8 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
         printf("%-22s %dx%dx%d: %.3f ms  %.0f TF/s   (max |err| %.3g, max |ref| %.3g)\n", name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9, maxerr, maxref);
     };
-    run(gemm_pp<256, 3>, 256, 3, "256x256, 3 row stages");
-    run(gemm_pp<256, 2>, 256, 2, "256x256, 2 row stages");
-    run(gemm_pp<320, 2>, 320, 2, "256x320, 2 row stages");
+    run(gemm_pp<256, 256, 3>, 256, 256, 3, "256x256, 3 row stages");
+    run(gemm_pp<256, 320, 2>, 256, 320, 2, "256x320, 2 row stages");
+    run(gemm_pp<192, 320, 3>, 192, 320, 3, "192x320, 3 row stages");
     return 0;
 }
