@@ -35,7 +35,9 @@ def rnd(*shape, scale=1.0, seed=0):
 
 # ---------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (1000, 160, 72), (130, 24, 8), (3600, 1280, 1280),
-                                   (77, 640, 1024), (2, 1280, 320), (513, 4, 2880)])
+                                   (77, 640, 1024), (2, 1280, 320), (513, 4, 2880),
+                                   # N = 8 (mod 16): the dwordx4 epilogue's last fragment pair is half valid; ragged M as well
+                                   (300, 200, 128), (257, 328, 192), (4097, 72, 64)])
 def test_gemm_linear(M, N, K):
     from viewcrafter_amd import ops
     x = rnd(M, K, seed=1).to(DEV).half()
