@@ -121,12 +121,17 @@ int vcx_layernorm_f16(const void* x, void* y, const float* gamma, const float* b
  *   V^T rows : vt + (h*64)*ldvt + (g / kv_div)*kv_rows       64 rows (d) x nk cols (keys)
  *   O rows   : o  + (g*nq)*ldo + h*64
  * kv_rows is the row count between consecutive K/V groups (>= nk, multiple of 8).
- * accumulate != 0 adds into O (second softmax of the text (+) image cross-attention,
- * attention.py:129-142).
+ * flags: VCX_ATTN_ACCUMULATE adds into O (second softmax of the text (+) image
+ * cross-attention, attention.py:129-142); VCX_ATTN_LOG2_LOGITS says the caller folded
+ * scale * log2(e) into Q and/or K (e.g. as the alpha of the projection GEMM), so that
+ * Q K^T is already the base-2 logit - `scale` is then ignored and the kernel saves one
+ * multiply-add per score.
  * ---------------------------------------------------------------------------------- */
+#define VCX_ATTN_ACCUMULATE 1
+#define VCX_ATTN_LOG2_LOGITS 2
 int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* vt, void* o, int n_groups,
                            int heads, int nq, int nk, int kv_rows, int kv_div, int64_t ldq,
-                           int64_t ldk, int64_t ldvt, int64_t ldo, float scale, int accumulate,
+                           int64_t ldk, int64_t ldvt, int64_t ldo, float scale, int flags,
                            void* stream);
 
 /* Temporal self-attention over T <= 32 frames per pixel, head dim 64

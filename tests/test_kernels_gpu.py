@@ -266,6 +266,69 @@ def test_flash_deferred_max_staircase(growth):
     check(out, attn_ref(q[None], k[None], v[None], 0.125)[0], tol=3e-3, name=f"flash staircase {growth}")
 
 
+def _log2_q(q, scale=0.125):
+    """fp16(scale * log2(e) * q): what the projection GEMM's alpha produces for the VCX_ATTN_LOG2_LOGITS path."""
+    return (q.float() * (scale * 1.4426950408889634)).half()
+
+
+LN2 = 0.6931471805599453
+
+
+@pytest.mark.parametrize("nq,nk", [(256, 256), (300, 300), (144, 77), (96, 1000), (2304, 2304)])
+def test_flash_log2_logits(nq, nk):
+    """VCX_ATTN_LOG2_LOGITS: scores arrive in base-2 units, the running max rides in the MFMA C operand.  QB = 1 and 2,
+    partial query blocks and key tiles."""
+    from viewcrafter_amd import ops
+    G, heads = 3, 2
+    C = heads * 64
+    q = _log2_q(rnd(G * nq, C, seed=70)).to(DEV)
+    k = rnd(G * nk, C, seed=71).to(DEV).half()
+    v = rnd(G * nk, C, seed=72).to(DEV).half()
+    nkp = (nk + 7) // 8 * 8
+    kp = torch.zeros(G, nkp, C, device=DEV, dtype=torch.float16); kp[:, :nk] = k.view(G, nk, C)
+    vp = torch.zeros(G, nkp, C, device=DEV, dtype=torch.float16); vp[:, :nk] = v.view(G, nk, C)
+    out = torch.empty(G * nq, C, device=DEV, dtype=torch.float16)
+    ops.flash_attn(q, kp.view(-1, C), vp.view(-1, C).t().contiguous(), out, n_groups=G, heads=heads, nq=nq, nk=nk, kv_rows=nkp,
+                   kv_div=1, ldq=C, ldk=C, ldvt=G * nkp, ldo=C, scale=0.0, log2_logits=True)
+
+    def split(t, n):
+        return t.view(G, n, heads, 64).permute(0, 2, 1, 3).reshape(G * heads, n, 64)
+    ref = attn_ref(split(q, nq), split(k, nk), split(v, nk), LN2).view(G, heads, nq, 64).permute(0, 2, 1, 3).reshape(G * nq, C)
+    check(out, ref, tol=3e-3, name="flash log2-logits")
+
+
+@pytest.mark.parametrize("growth", [-9.0, 1.5, 6.0, 12.0])
+def test_flash_log2_logits_staircase(growth):
+    """Deferred max with the max folded into the accumulator: scores climbing (or falling) by `growth` log2 units per tile,
+    on top of an offset of -40 so that the forced first-tile update is what keeps the probabilities representable."""
+    from viewcrafter_amd import ops
+    n = 640
+    q = rnd(n, 64, seed=61) * 0.3
+    k = rnd(n, 64, seed=62) * 0.3
+    v = rnd(n, 64, seed=63)
+    q[:, 0] = 1.0
+    k[:, 0] = ((torch.arange(n) // 64).float() * growth - 40.0) * (8.0 / 1.4426950408889634)
+    k[:, 0] += rnd(n, seed=64) * 0.5
+    q, k, v = _log2_q(q).to(DEV), k.to(DEV).half(), v.to(DEV).half()
+    out = torch.empty(n, 64, device=DEV, dtype=torch.float16)
+    ops.flash_attn(q, k, v.t().contiguous(), out, n_groups=1, heads=1, nq=n, nk=n, kv_rows=n, kv_div=1, ldq=64, ldk=64,
+                   ldvt=n, ldo=64, scale=0.0, log2_logits=True)
+    check(out, attn_ref(q[None], k[None], v[None], LN2)[0], tol=3e-3, name=f"flash log2 staircase {growth}")
+
+
+def test_flash_log2_logits_accumulate():
+    from viewcrafter_amd import ops
+    n, nk = 288, 80
+    q = _log2_q(rnd(n, 64, seed=73)).to(DEV)
+    k1, v1, k2, v2 = [rnd(nk, 64, seed=74 + i).to(DEV).half() for i in range(4)]
+    out = torch.empty(n, 64, device=DEV, dtype=torch.float16)
+    kw = dict(n_groups=1, heads=1, nq=n, kv_rows=nk, kv_div=1, ldq=64, ldk=64, ldvt=nk, ldo=64, scale=0.0, log2_logits=True)
+    ops.flash_attn(q, k1, v1.t().contiguous(), out, nk=77, **kw)
+    ops.flash_attn(q, k2, v2.t().contiguous(), out, nk=nk, accumulate=True, **kw)
+    ref = attn_ref(q[None], k1[None, :77], v1[None, :77], LN2)[0] + attn_ref(q[None], k2[None], v2[None], LN2)[0]
+    check(out, ref, tol=3e-3, name="flash log2 accumulate")
+
+
 @pytest.mark.parametrize("T,shared", [(5, True), (4, False)])
 def test_flash_cross_attention_text_plus_image(T, shared):
     """softmax(QK_txt)V_txt + softmax(QK_img)V_img with 77 text keys (padded to 80 rows)."""

@@ -32,7 +32,7 @@ struct FlashArgs {
     int heads, nq, nk, kv_rows, kv_div;
     int64_t ldq, ldk, ldvt, ldo;
     float scale_log2;
-    int accumulate;
+    int accumulate;   // VCX_ATTN_* flag bits
 };
 
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
@@ -43,7 +43,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // halves the LDS bytes per MFMA - like the GEMM, the QB = 1 kernel is bound by LDS traffic, not by the matrix pipe.
 // K / V^T tiles go HBM -> LDS by DMA (buffer_load ... lds); rows / key columns beyond nk use an out-of-range offset and
 // arrive as zeros (masked to -inf before the softmax anyway).
-template <int QB>
+//
+// PRE (VCX_ATTN_LOG2_LOGITS): the caller folded scale * log2(e) into Q and/or K, so Q K^T is the base-2 logit itself.
+// The first MFMA of a score accumulator then takes C = -m (the running max, kept in a 16-register tuple that changes only
+// when the max moves) and the matrix pipe delivers s - m directly: the per-score fma of the plain path disappears
+// (VALU and MFMA issue do not overlap on a SIMD - tools/ubench.hip - so every VALU instruction removed is time).
+template <int QB, bool PRE>
 __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) half_t sK[2][64 * 64];
@@ -108,11 +113,17 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        m_run[b] = -1e30f;
+        m_run[b] = PRE ? 0.f : -1e30f;     // PRE: the first tile always moves the max (see below), 0 keeps its scores exact
         l_run[b] = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { oacc[b][0][i] = 0.f; oacc[b][1][i] = 0.f; }
     }
+
+    f16v cinit[PRE ? QB : 1];              // PRE: -m_run broadcast, the C operand of the first score MFMA
+#pragma unroll
+    for (int b = 0; b < (PRE ? QB : 1); ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cinit[b][i] = 0.f;
 
     const int ntiles = (p.nk + FK - 1) / FK;
     load_tile(0, 0);
@@ -135,7 +146,7 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
                 const h8 kf = *reinterpret_cast<const h8*>(cK + tile_off(kb * 32 + lq, s * 2 + hi));
 #pragma unroll
                 for (int b = 0; b < QB; ++b)
-                    sacc[b][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[b][s], s == 0 ? zero16 : sacc[b][kb], 0, 0, 0);
+                    sacc[b][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[b][s], s == 0 ? (PRE ? cinit[b] : zero16) : sacc[b][kb], 0, 0, 0);
             }
         // ---- online softmax per query block in the log2 domain: p = 2^(s*c - m), one fma + one v_exp per score.
         // Key masking exists only in the code path of a partial last tile (block-uniform branch).
@@ -164,6 +175,30 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
             // fp32 sums, same relative precision in fp16) and the O / l rescale - 64 multiplies and an exponential per lane -
             // is skipped.  The decision precedes the exponentiation of the tile it covers and the previous tile's P V is
             // complete, so everything still at the old scale (O, l) is rescaled exactly once.
+            float psum = 0.f;
+            if (PRE) {
+                // the scores are already s - m_run: the max moves by max(mx, 0) (by mx on the first tile, where nothing is
+                // accumulated yet and m_run = 0 is only a placeholder)
+                const bool first = kt == 0;
+                if (first || __builtin_amdgcn_ballot_w64(mx > FLASH_DEFER) != 0) {      // wave-uniform branch
+                    const float delta = first ? mx : fmaxf(mx, 0.f);
+                    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                    m_run[b] += delta;
+                    l_run[b] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { oacc[b][0][i] *= alpha; oacc[b][1][i] *= alpha; }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { sacc[b][0][i] -= delta; sacc[b][1][i] -= delta; cinit[b][i] = -m_run[b]; }
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(sacc[b][kb][r]);
+                        sacc[b][kb][r] = pv;
+                        psum += pv;
+                    }
+            } else {
             const float cand = mx * p.scale_log2;
             if (__builtin_amdgcn_ballot_w64(cand > m_run[b] + FLASH_DEFER) != 0) {     // wave-uniform branch
                 const float m_new = fmaxf(m_run[b], cand);
@@ -174,7 +209,6 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
                 for (int i = 0; i < 16; ++i) { oacc[b][0][i] *= alpha; oacc[b][1][i] *= alpha; }
             }
             const float m_use = m_run[b];
-            float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -183,6 +217,7 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
                     sacc[b][kb][r] = pv;
                     psum += pv;
                 }
+            }
             l_run[b] += psum;
         }
         // ---- O^T += V^T P^T; each V^T fragment feeds QB MFMAs
@@ -226,7 +261,7 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = oacc[b][db][gq * 4 + r] * inv;
-                    if (p.accumulate) {
+                    if (p.accumulate & VCX_ATTN_ACCUMULATE) {
                         const h4 old = *reinterpret_cast<const h4*>(orow + d0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
@@ -394,7 +429,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(half_t* x, int n, int
 
 extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* vt, void* o, int n_groups, int heads,
                                       int nq, int nk, int kv_rows, int kv_div, int64_t ldq, int64_t ldk, int64_t ldvt,
-                                      int64_t ldo, float scale, int accumulate, void* stream) {
+                                      int64_t ldo, float scale, int flags, void* stream) {
     VCX_REQUIRE(q && k && vt && o, "vcx_attn_flash_d64_f16: null pointer");
     VCX_REQUIRE(n_groups > 0 && heads > 0 && nq > 0 && nk > 0 && kv_div > 0, "vcx_attn_flash_d64_f16: empty problem");
     VCX_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && kv_rows % 8 == 0 && kv_rows >= nk,
@@ -408,7 +443,8 @@ extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* 
     a.heads = heads; a.nq = nq; a.nk = nk; a.kv_rows = kv_rows; a.kv_div = kv_div;
     a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
     a.scale_log2 = scale * 1.4426950408889634f;
-    a.accumulate = accumulate;
+    a.accumulate = flags;
+    const bool pre = flags & VCX_ATTN_LOG2_LOGITS;
     hipStream_t s = (hipStream_t)stream;
     const double nprob = (double)n_groups * heads;
     VcxProfScope prof(VCX_FAM_FLASH, s, 4.0 * nprob * nq * (double)nk * 64, 2.0 * nprob * 64 * (2.0 * nq + 2.0 * nk));
@@ -422,10 +458,12 @@ extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* 
     if (force_qb == 2) qb2 = true;
     if (qb2) {
         dim3 grid(blocks2, n_groups * heads);
-        hipLaunchKernelGGL(flash_d64_kernel<2>, grid, dim3(256), 0, s, a);
+        if (pre) hipLaunchKernelGGL((flash_d64_kernel<2, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((flash_d64_kernel<2, false>), grid, dim3(256), 0, s, a);
     } else {
         dim3 grid((nq + 127) / 128, n_groups * heads);
-        hipLaunchKernelGGL(flash_d64_kernel<1>, grid, dim3(256), 0, s, a);
+        if (pre) hipLaunchKernelGGL((flash_d64_kernel<1, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((flash_d64_kernel<1, false>), grid, dim3(256), 0, s, a);
     }
     return vcx_check_launch("vcx_attn_flash_d64_f16");
 }

@@ -10,6 +10,7 @@ Activations are channels-last fp16.  A spatial transformer sees tokens [(b t h w
 SAME row order (Linear/LayerNorm are row-wise, so no '(b t) c h w <-> (b h w) t c' copies are needed — only the
 temporal attention kernel itself walks frames with a stride of h*w rows).
 """
+import math
 import torch
 from torch import nn
 
@@ -231,23 +232,26 @@ class SpatialTransformer(PackedModule):
             a1, a2 = blk.attn1.packed(), blk.attn2.packed()
             # ---- self-attention over the h*w tokens of each frame
             h1 = ops.layer_norm(t, *ln[0])
-            qk = ops.linear(h1, a1["wqk"])                                           # [tokens, 2D]
+            # scale * log2(e) rides in the projections (sqrt of it on Q and on K: one fp16 rounding each, as without it), so the
+            # attention kernel gets base-2 logits and its running max can live in the MFMA accumulator (VCX_ATTN_LOG2_LOGITS)
+            qk = ops.linear(h1, a1["wqk"], alpha=math.sqrt(blk.attn1.scale * ops.LOG2E))   # [tokens, 2D]
             vt = ops.gemm(a1["wv"], h1, M=D, N=tokens, K=D, lda=D)                   # [D, tokens]
             o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
             ops.flash_attn(qk, qk[:, D:], vt, o, n_groups=n, heads=heads, nq=N, nk=N, kv_rows=N, kv_div=1, ldq=2 * D,
-                           ldk=2 * D, ldvt=tokens, ldo=D, scale=blk.attn1.scale)
+                           ldk=2 * D, ldvt=tokens, ldo=D, scale=blk.attn1.scale, log2_logits=True)
             t = ops.linear(o, a1["wo"], a1["bo"], residual=t)
             # ---- cross-attention: softmax(Q K_txt) V_txt + softmax(Q K_img) V_img
             h2 = ops.layer_norm(t, *ln[1])
-            q2 = ops.linear(h2, a2["wq"])
+            q2 = ops.linear(h2, a2["wq"], alpha=blk.attn2.scale * ops.LOG2E)
             o2 = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
             nb = kv.n_txt_rows // 80
             ops.flash_attn(q2, kv.k_txt, kv.vt_txt, o2, n_groups=n, heads=heads, nq=N, nk=blk.attn2.text_context_len,
-                           kv_rows=80, kv_div=frames_per_video, ldq=D, ldk=D, ldvt=nb * 80, ldo=D, scale=blk.attn2.scale)
+                           kv_rows=80, kv_div=frames_per_video, ldq=D, ldk=D, ldvt=nb * 80, ldo=D, scale=blk.attn2.scale,
+                           log2_logits=True)
             if kv.k_img is not None:
                 ops.flash_attn(q2, kv.k_img, kv.vt_img, o2, n_groups=n, heads=heads, nq=N, nk=kv.n_img, kv_rows=kv.n_img,
                                kv_div=1 if kv.img_per_frame else frames_per_video, ldq=D, ldk=D,
-                               ldvt=kv.vt_img.shape[1], ldo=D, scale=blk.attn2.scale, accumulate=True)
+                               ldvt=kv.vt_img.shape[1], ldo=D, scale=blk.attn2.scale, accumulate=True, log2_logits=True)
             t = ops.linear(o2, a2["wo"], a2["bo"], residual=t)
             # ---- feed-forward
             t = blk.ff.run(ops.layer_norm(t, *ln[2]), t)

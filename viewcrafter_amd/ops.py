@@ -136,9 +136,17 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 # ------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------
-def flash_attn(q, k, vt, out, *, n_groups, heads, nq, nk, kv_rows, kv_div, ldq, ldk, ldvt, ldo, scale, accumulate=False):
+ATTN_ACCUMULATE, ATTN_LOG2_LOGITS = 1, 2
+LOG2E = 1.4426950408889634
+
+
+def flash_attn(q, k, vt, out, *, n_groups, heads, nq, nk, kv_rows, kv_div, ldq, ldk, ldvt, ldo, scale, accumulate=False,
+               log2_logits=False):
+    """softmax(scale Q K^T) V per (group, head); `log2_logits`: Q K^T already is the base-2 logit (scale * log2 e was folded
+    into the projections, e.g. as the GEMM alpha) and `scale` is ignored."""
+    flags = (ATTN_ACCUMULATE if accumulate else 0) | (ATTN_LOG2_LOGITS if log2_logits else 0)
     check(lib().vcx_attn_flash_d64_f16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), n_groups, heads, nq,
-                                       nk, kv_rows, kv_div, ldq, ldk, ldvt, ldo, scale, 1 if accumulate else 0,
+                                       nk, kv_rows, kv_div, ldq, ldk, ldvt, ldo, scale, flags,
                                        _stream()), "attn_flash_d64")
     return out
 
