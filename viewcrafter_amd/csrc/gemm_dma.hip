@@ -26,9 +26,11 @@ constexpr unsigned OOB = 0xFFFFFFFFu;   // voffset beyond any descriptor's num_r
 
 // Tile configuration: block tile TBM x TBN, NWM x NWN waves, each wave owns (TBM/NWM) x (TBN/NWN) outputs.
 //   small : 128 x {128,160}, 2x2 waves (64 x {64,80} per wave), 2 blocks/CU      - few tiles / small M
-//   large : 256 x {256,320}, 2x4 waves (128 x {64,80} per wave), 1 block/CU      - LDS bytes per MFMA drop from ~690 to
+//   large : 256 x {256,320}, 4x2 waves (64 x {128,160} per wave), 1 block/CU      - LDS bytes per MFMA drop from ~690 to
 //           ~450 (DMA writes 230 -> 115-128, fragment reads 461 -> 333-384): the small tile is LDS-bandwidth bound
 //           (profiles/r01_gemm_experiments.md: removing the DMA gives +25 %, removing barriers or DMA waits nothing).
+//           4 (M) x 2 (N) rather than 2 x 4: a wave's output strip is 256-320 bytes of every row (whole 64-byte sectors,
+//           all stores dwordx4) instead of 128-160; tools/ubench_store.hip: the store phase of a tile is 12-26 % shorter.
 template <int TBM_, int TBN_, int NWM_, int NWN_>
 struct TileCfg {
     static constexpr int TBM = TBM_, TBN = TBN_, NWM = NWM_, NWN = NWN_;
@@ -38,7 +40,8 @@ struct TileCfg {
     static constexpr int XROWS = TBM * 8 / THREADS;   // DMA instructions per thread for the activation tile
     static constexpr int WROWS = TBN * 8 / THREADS;
     static constexpr int RSTEP = THREADS / 8;         // tile rows covered by one DMA instruction of the block
-    static constexpr size_t SMEM = (size_t)2 * (TBM + TBN) * BK * sizeof(half_t);
+    static constexpr size_t STAGES = (size_t)2 * (TBM + TBN) * BK * sizeof(half_t);
+    static constexpr size_t SMEM = STAGES + (size_t)TBN * NWM * sizeof(float);   // + one bias strip per wave (epilogue)
 };
 
 template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32>
@@ -232,10 +235,13 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
             const int mbase = p.m_begin + tile_m * TBM + wm * WM + lr;
             const int nbase = tile_n * BN + wn * WN + lg * 4;
             if (GEGLU) {
+                // Packed GEGLU weights come in 64-column blocks [32 value | 32 gate] (packing.py): of a wave's fragments, 4j and
+                // 4j + 1 are values, 4j + 2 and 4j + 3 their gates; output fragment a = 2j + i pairs xfrag(a) with xfrag(a) + 2.
+                auto xfrag = [](int a) { return 4 * (a >> 1) + (a & 1); };
                 f4 bx[NFRAG / 2 + 1], bg[NFRAG / 2 + 1];
 #pragma unroll
                 for (int a = 0; a < NFRAG / 2; ++a) {
-                    const int nx = min(nbase + a * 16, p.N - 36);
+                    const int nx = min(nbase + xfrag(a) * 16, p.N - 36);
                     bx[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nx) : f4{0.f, 0.f, 0.f, 0.f};
                     bg[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nx + 32) : f4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -257,8 +263,8 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
                         half_t o[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float xv = acc[a][b][r] * p.alpha + bx[a][r];
-                            const float gv = acc[a + NFRAG / 2][b][r] * p.alpha + bg[a][r];
+                            const float xv = acc[xfrag(a)][b][r] * p.alpha + bx[a][r];
+                            const float gv = acc[xfrag(a) + 2][b][r] * p.alpha + bg[a][r];
                             o[r] = (half_t)(xv * gelu_erf(gv));
                         }
                         packed[a] = __builtin_bit_cast(u2v, h4{o[0], o[1], o[2], o[3]});
@@ -271,11 +277,11 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
                             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                             const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                             const int col = (a + (int)odd) * 16 + (int)half * 8;             // 8 output columns of this lane
-                            const int nx = tile_n * BN + wn * WN + (a + (int)odd) * 16;      // packed-space column of the fragment's values
+                            const int nx = tile_n * BN + wn * WN + xfrag(a + (int)odd) * 16;  // packed-space column of the fragment's values
                             const unsigned voff = nx + 48 <= p.N ? crow + (unsigned)col * 2u : OOB;
                             __builtin_amdgcn_raw_buffer_store_b128(u4v{s0[0], s1[0], s0[1], s1[1]}, srd_c, voff, 0, 0);
                         } else {
-                            const int nx = tile_n * BN + wn * WN + a * 16;
+                            const int nx = tile_n * BN + wn * WN + xfrag(a) * 16;
                             const unsigned voff = nx + 48 <= p.N ? crow + (unsigned)(a * 16 + lg * 4) * 2u : OOB;
                             __builtin_amdgcn_raw_buffer_store_b64(packed[a], srd_c, voff, 0, 0);
                         }
@@ -335,24 +341,27 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
 #pragma unroll
                     for (int i = 0; i < RDU; ++i) fetch(i);
                 }
-                f4 bv[NFRAG];
-#pragma unroll
-                for (int a = 0; a < NFRAG; ++a) {
-                    const int nc = min(nbase + a * 16, p.N - 4);
-                    bv[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nc) : f4{0.f, 0.f, 0.f, 0.f};
+                // Column addends (bias, plus the tile's time-embedding row when it is uniform over the tile) live in a private
+                // LDS strip of the wave, not in registers: a 160-column strip would pin 40 VGPRs through the whole epilogue.
+                float* sB = reinterpret_cast<float*>(smem_raw + Cfg::STAGES) + wave * WN;
+                if (lane < WN / 4) {
+                    const int nc = min(nstrip + lane * 4, p.N - 4);
+                    f4 t = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nc) : f4{0.f, 0.f, 0.f, 0.f};
                     if (radd_tile) {
                         const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)radd_row * p.N + nc);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) bv[a][r] += rv[r];
+                        for (int r = 0; r < 4; ++r) t[r] += rv[r];
                     }
+                    *reinterpret_cast<f4*>(sB + lane * 4) = t;
                 }
+                int bopaque = 0;     // re-read per 16-row group (an address the compiler cannot prove loop-invariant)
                 // value of accumulator fragment (a, b) with bias / addend applied (everything but the residual)
                 auto finish = [&](int a, int b, float (&v)[4]) {
                     if (per_row) {      // rare: V^T projections (per-row bias) and tiles that straddle two addend rows
                         // same arithmetic as the tile-uniform case, (bias + addend) first and one fma: a row's result must
                         // not depend on how the batch happens to align tiles with frames (bit-exact batch invariance)
                         const int mc = min(mbase + b * 16, p.M - 1);
-                        f4 t = bv[a];
+                        f4 t = *reinterpret_cast<const f4*>(sB + bopaque + a * 16 + lg * 4);
                         if (flags & VCX_GEMM_ROWADD) {
                             const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)(mc / p.rowadd_div) * p.N + min(nbase + a * 16, p.N - 4));
 #pragma unroll
@@ -366,13 +375,15 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
                             for (int r = 0; r < 4; ++r) v[r] += bm;
                         }
                     } else {
+                        const f4 t = *reinterpret_cast<const f4*>(sB + bopaque + a * 16 + lg * 4);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[a][b][r], p.alpha, bv[a][r]);
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[a][b][r], p.alpha, t[r]);
                     }
                 };
 #pragma unroll
                 for (int b = 0; b < MFRAG; ++b) {
                     const unsigned crow = coff0 + (unsigned)b * cstep;
+                    asm volatile("" : "+v"(bopaque));
 #pragma unroll
                     for (int u = 0; u < UNITS; ++u) {
                         const int i = b * UNITS + u;
@@ -458,8 +469,8 @@ int launch(const GemmArgs& a, hipStream_t s) {
 template <class Cfg>
 int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) {
     if (geglu) {
-        if constexpr (Cfg::NF % 2 == 0) return conv ? launch<Cfg, true, true, false>(a, s) : launch<Cfg, false, true, false>(a, s);
-        vcx_set_error("vcx_gemm_f16(dma): GEGLU needs an even fragment count");
+        if constexpr (Cfg::NF % 4 == 0) return conv ? launch<Cfg, true, true, false>(a, s) : launch<Cfg, false, true, false>(a, s);
+        vcx_set_error("vcx_gemm_f16(dma): GEGLU needs whole 64-column packed blocks per wave");
         return VCX_EINVAL;
     }
     if (f32) return conv ? launch<Cfg, true, false, true>(a, s) : launch<Cfg, false, false, true>(a, s);
@@ -472,8 +483,8 @@ int vcxgemm::launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, h
     switch (cfg) {
         case 0: return dispatch<TileCfg<128, 128, 2, 2>>(a, conv, geglu, f32, s);
         case 1: return dispatch<TileCfg<128, 160, 2, 2>>(a, conv, geglu, f32, s);
-        case 2: return dispatch<TileCfg<256, 256, 2, 4>>(a, conv, geglu, f32, s);
-        case 3: return dispatch<TileCfg<256, 320, 2, 4>>(a, conv, geglu, f32, s);
+        case 2: return dispatch<TileCfg<256, 256, 4, 2>>(a, conv, geglu, f32, s);
+        case 3: return dispatch<TileCfg<256, 320, 4, 2>>(a, conv, geglu, f32, s);
     }
     vcx_set_error("vcx_gemm_f16(dma): unknown tile configuration %d", cfg);
     return VCX_EINVAL;
