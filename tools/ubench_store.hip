@@ -54,6 +54,50 @@ __global__ void __launch_bounds__(512) k(unsigned short* C, int ldc, int tiles_m
 #pragma unroll
                 for (int u = 0; u < 5; ++u)
                     __builtin_amdgcn_raw_buffer_store_b128(val, srd, base + (unsigned)b * 16u * ldc * 2u + (u * 32 + (lg & 1) * 16 + (lg >> 1) * 8) * 2u, 0, 0);
+        } else if (MODE == 5) {
+            // 8x1 waves (32 rows x 320 columns each), fragment pattern: 16 rows x 64 B per store, 10 per row group
+            const unsigned base = ((unsigned)(tm * 256 + wave * 32 + lr) * ldc + tn * 320) * 2u;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int u = 0; u < 10; ++u)
+                    __builtin_amdgcn_raw_buffer_store_b128(val, srd, base + (unsigned)b * 16u * ldc * 2u + (u * 32 + (lg & 1) * 16 + (lg >> 1) * 8) * 2u, 0, 0);
+        } else if (MODE == 6) {
+            // 4x2 waves, fragment pattern, but the two waves of a row group interleave 64-byte pieces (wave wn takes units 2u + wn)
+            const int wm = wave & 3, wn = wave >> 2;
+            const unsigned base = ((unsigned)(tm * 256 + wm * 64 + lr) * ldc + tn * 320) * 2u;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int u = 0; u < 5; ++u)
+                    __builtin_amdgcn_raw_buffer_store_b128(val, srd, base + (unsigned)b * 16u * ldc * 2u + ((2 * u + wn) * 32 + (lg & 1) * 16 + (lg >> 1) * 8) * 2u, 0, 0);
+        } else if (MODE == 7) {
+            // whole 640-byte rows, but each wave takes every 8th row (row r = 8 i + wave) instead of 32 consecutive rows
+#pragma unroll
+            for (int j = 0; j < 20; ++j) {
+                const int c = j * 64 + lane, rr = c / 40, ch = c % 40;
+                const unsigned off = ((unsigned)(tm * 256 + rr * 8 + wave) * ldc + tn * 320) * 2u + ch * 16u;
+                __builtin_amdgcn_raw_buffer_store_b128(val, srd, off, 0, 0);
+            }
+        } else if (MODE == 8) {
+            // 256 x 256 tile (tiles_n recomputed by the caller), 4x2 waves: 64 rows x 256 B per wave = two whole lines per row
+            const int wm = wave & 3, wn = wave >> 2;
+            const unsigned base = ((unsigned)(tm * 256 + wm * 64 + lr) * ldc + tn * 256 + wn * 128) * 2u;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    __builtin_amdgcn_raw_buffer_store_b128(val, srd, base + (unsigned)b * 16u * ldc * 2u + (u * 32 + (lg & 1) * 16 + (lg >> 1) * 8) * 2u, 0, 0);
+        } else if (MODE == 9) {
+            // 256 x 320 tile, 4x2 waves with an uneven split on line boundaries: wn = 0 takes columns 0..191, wn = 1 192..319
+            const int wm = wave & 3, wn = wave >> 2;
+            const unsigned base = ((unsigned)(tm * 256 + wm * 64 + lr) * ldc + tn * 320 + wn * 192) * 2u;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+                    if (u < (wn ? 4 : 6))
+                        __builtin_amdgcn_raw_buffer_store_b128(val, srd, base + (unsigned)b * 16u * ldc * 2u + (u * 32 + (lg & 1) * 16 + (lg >> 1) * 8) * 2u, 0, 0);
         } else if (MODE == 4) {
             // whole tile rows: the block writes 256 rows x 640 B, each wave 32 rows, each store 64 lanes x 16 B = 1.6 rows
             const int c0 = wave * 32 * 40;
@@ -69,7 +113,8 @@ __global__ void __launch_bounds__(512) k(unsigned short* C, int ldc, int tiles_m
 
 template <int MODE>
 void run(const char* name, unsigned short* C, int M, int N) {
-    const int tiles_m = M / 256, tiles_n = N / 320, nt = tiles_m * tiles_n;
+    const int tiles_m = M / 256, tiles_n = N / (MODE == 8 ? 256 : 320), nt = tiles_m * tiles_n;
+    if (N % (MODE == 8 ? 256 : 320)) return;
     k<MODE><<<256, 512>>>(C, N, tiles_m, tiles_n, nt);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -82,13 +127,18 @@ void run(const char* name, unsigned short* C, int M, int N) {
 }
 
 int main() {
-    unsigned short* C; hipMalloc(&C, (size_t)460800 * 1280 * 2);
-    for (int N : {320, 960}) {
+    unsigned short* C; hipMalloc(&C, (size_t)460800 * 1920 * 2);
+    for (int N : {320, 1280, 1920}) {
         run<0>("2x4 waves, fragment pattern widened (2 x b128 + b64 / group)", C, 460800, N);
         run<1>("2x4 waves, fragment pattern narrow (5 x b64 / group)", C, 460800, N);
         run<3>("4x2 waves, fragment pattern widened (5 x b128 / group)", C, 460800, N);
         run<2>("4x2 waves, row-major 320-byte pieces (LDS-staged epilogue)", C, 460800, N);
         run<4>("whole 640-byte tile rows", C, 460800, N);
+        run<5>("8x1 waves, fragment pattern (10 x b128 / group)", C, 460800, N);
+        run<6>("4x2 waves, fragment pattern, pieces interleaved between the waves", C, 460800, N);
+        run<7>("whole 640-byte rows, wave takes every 8th row", C, 460800, N);
+        run<8>("256x256 tile, 4x2 waves: 2 whole lines per wave and row", C, 460800, N);
+        run<9>("256x320 tile, 4x2 waves split 192 | 128 columns (whole lines)", C, 460800, N);
     }
     return 0;
 }
