@@ -66,6 +66,9 @@ def import_reference():
         tvu = types.ModuleType("torchvision.utils")
         tvu.make_grid = lambda *a, **k: None
         tv.utils = tvu
+        import importlib.machinery
+        tv.__spec__ = importlib.machinery.ModuleSpec("torchvision", None)   # transformers probes find_spec("torchvision")
+        tvu.__spec__ = importlib.machinery.ModuleSpec("torchvision.utils", None)
         sys.modules["torchvision"] = tv
         sys.modules["torchvision.utils"] = tvu
     if REF not in sys.path:
@@ -225,11 +228,77 @@ def gen_resampler(out):
             print("resampler", tag, tuple(y.shape), float(y.abs().mean()))
 
 
+def install_clip_stand_ins():
+    """`open_clip` and `kornia` are third-party packages that are neither in /root/reference nor in this image; the reference's
+    condition.py imports both at module level.  The stand-ins of oracle/clip_oracle.py (open_clip's module tree on
+    torch.nn.MultiheadAttention, kornia's blur + bicubic resize) are installed under those names so that the reference's
+    OWN embedder code (condition.py:174-240, 302-378) runs unmodified on top of them."""
+    from oracle import clip_oracle as co
+    oc = types.ModuleType("open_clip")
+    oc.create_model_and_transforms = lambda arch, device=None, pretrained=None: (co.StandInCLIP(arch), None, None)
+
+    def tokenize(texts, context_length=77):
+        assert all(t == "" for t in texts), "the stand-in only knows the empty prompt"
+        return co.tokenize_empty(len(texts), context_length)
+    oc.tokenize = tokenize
+    sys.modules["open_clip"] = oc
+    k = types.ModuleType("kornia")
+    k.geometry = types.ModuleType("kornia.geometry")
+    k.enhance = types.ModuleType("kornia.enhance")
+
+    def resize(x, size, interpolation="bilinear", align_corners=None, antialias=False):
+        assert interpolation == "bicubic" and align_corners is True
+        return co.kornia_resize(x, size, antialias)
+    k.geometry.resize = resize
+    k.enhance.normalize = co.kornia_normalize
+    sys.modules["kornia"], sys.modules["kornia.geometry"], sys.modules["kornia.enhance"] = k, k.geometry, k.enhance
+
+
+CLIP_TINY = "vcx-tiny-test"
+
+
+def gen_clip(out):
+    """The reference's two OpenCLIP embedders (condition.py) on the tiny stand-in towers."""
+    install_clip_stand_ins()
+    from lvdm.modules.encoders.condition import FrozenOpenCLIPEmbedder, FrozenOpenCLIPImageEmbedderV2
+    torch.manual_seed(0)
+    txt = FrozenOpenCLIPEmbedder(arch=CLIP_TINY, device="cpu", freeze=True, layer="penultimate").eval()
+    shapes = load_synth(txt)
+    out["clip_text_keys"] = np.array(sorted(shapes.keys()))
+    out["clip_text_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    img = FrozenOpenCLIPImageEmbedderV2(arch=CLIP_TINY, device="cpu", freeze=True).eval()
+    shapes = load_synth(img)
+    out["clip_image_keys"] = np.array(sorted(shapes.keys()))
+    out["clip_image_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    with torch.no_grad():
+        y = txt([""] * 2)
+        out["clip_text_empty"] = y.numpy()
+        rng = np.random.default_rng(7)
+        tokens = torch.zeros(3, 77, dtype=torch.long)
+        for i, n in enumerate((5, 20, 75)):
+            tokens[i, 0] = 49406
+            tokens[i, 1:1 + n] = torch.from_numpy(rng.integers(0, 49406, n))
+            tokens[i, 1 + n] = 49407
+        out["clip_text_tokens"] = tokens.numpy()
+        y = txt.encode_with_transformer(tokens)
+        out["clip_text_random"] = y.numpy()
+        print("clip text", tuple(y.shape), float(y.abs().mean()))
+        for tag, shp in {"down": (2, 3, 320, 448), "up": (1, 3, 96, 64)}.items():
+            x = torch.tanh(synth_input(f"clip_image_{tag}", shp))
+            y = img(x)
+            out[f"clip_image_{tag}"] = y.numpy()
+            print("clip image", tag, tuple(y.shape), float(y.abs().mean()))
+
+
 def main():
+    try:      # condition.py imports these; resolve transformers' lazy modules before the torchvision stub confuses its probes
+        from transformers import T5Tokenizer, T5EncoderModel, CLIPTokenizer, CLIPTextModel  # noqa: F401
+    except Exception as e:  # pragma: no cover
+        print("transformers not importable:", e)
     import_reference()
     torch.set_num_threads(8)
     for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
-                     ("resampler_tiny", gen_resampler)):
+                     ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         out = {}

@@ -238,3 +238,58 @@ def test_image_proj_model_resolves_natively_with_reference_state_dict_names():
     want = {str(k): eval(str(s)) for k, s in zip(g["resampler_keys"], g["resampler_shapes"])}
     have = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert have == want
+
+
+def test_clip_encoders_resolve_natively_with_reference_state_dict_names():
+    """The YAML targets of the two OpenCLIP encoders resolve to the libvcx implementation; parameter names / shapes equal
+    those of the reference modules (fixture written by the reference's condition.py on the open_clip stand-in)."""
+    import numpy as np
+    import os
+    from viewcrafter_amd.config import Config
+    from viewcrafter_amd.utils.diffusion_utils import instantiate_from_config
+    from viewcrafter_amd.lvdm.modules.encoders import condition as cond
+    from tests.tiny_config import CLIP_TINY, CLIP_TINY_CFG
+    cond.CLIP_CONFIGS[CLIP_TINY] = CLIP_TINY_CFG
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_tiny.npz"))
+    for target, params, key in (("FrozenOpenCLIPEmbedder", dict(arch=CLIP_TINY, freeze=True, layer="penultimate"), "clip_text"),
+                                ("FrozenOpenCLIPImageEmbedderV2", dict(arch=CLIP_TINY, freeze=True), "clip_image")):
+        m = instantiate_from_config(Config(target="lvdm.modules.encoders.condition." + target, params=Config.wrap(params)))
+        assert type(m).__module__ == "viewcrafter_amd.lvdm.modules.encoders.condition"
+        want = {str(k): eval(str(s)) for k, s in zip(g[key + "_keys"], g[key + "_shapes"])}
+        have = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert have == want, (sorted(set(have) ^ set(want)))
+        assert not any(p.requires_grad for p in m.parameters())
+
+
+def test_clip_tokenizer_contract(tmp_path, monkeypatch):
+    """Empty prompt -> <start_of_text><end_of_text>; a non-empty prompt without a vocabulary fails loudly; with a (toy)
+    vocabulary file the byte-pair merges are applied in rank order and long prompts are truncated with the end token kept."""
+    import gzip
+    import pytest
+    from viewcrafter_amd.lvdm.modules.encoders import condition as cond
+    monkeypatch.delenv("VCX_CLIP_BPE", raising=False)
+    cond._bpe_from_env.cache_clear()
+    t = cond.tokenize(["", ""])
+    assert t.shape == (2, 77) and t[0, :3].tolist() == [49406, 49407, 0] and int(t.sum()) == 2 * (49406 + 49407)
+    try:
+        import open_clip  # noqa: F401
+        return
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError, match="VCX_CLIP_BPE"):
+        cond.tokenize(["a view"])
+    merges = ["#version: toy", "v i", "vi e", "vie w</w>", "a b"] + [f"x{i} y{i}" for i in range(49152 - 256 - 2 - 4)]
+    path = tmp_path / "bpe.txt.gz"
+    with gzip.open(path, "wb") as f:
+        f.write("\n".join(merges).encode())
+    monkeypatch.setenv("VCX_CLIP_BPE", str(path))
+    cond._bpe_from_env.cache_clear()
+    bpe = cond._bpe_from_env()
+    byte = cond._bytes_to_unicode()
+    ids = cond.tokenize(["A  View"])[0].tolist()
+    assert ids[0] == 49406 and ids[3] == 49407 and ids[4] == 0
+    assert ids[1] == bpe.encoder[byte[ord("a")] + "</w>"]                 # single letter word: its </w> symbol
+    assert ids[2] == bpe.encoder["view</w>"] == 512 + 2                     # merged by the three toy merges
+    long = cond.tokenize(["a " * 200])[0]
+    assert long[-1] == 49407 and long[0] == 49406 and (long[1:-1] == ids[1]).all()
+    cond._bpe_from_env.cache_clear()

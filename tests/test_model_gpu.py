@@ -186,3 +186,36 @@ def test_resampler_vs_reference_golden():
     x = synth_input("resampler_fresh", (3, 257, TINY_RESAMPLER["embedding_dim"]))   # CLIP-like token count (odd, > 256)
     ref = O.resampler_forward({k: v for k, v in sd.items()}, TINY_RESAMPLER, x)
     assert rel_l2(m(x.to(DEV)), ref) <= 8e-3
+
+
+def test_clip_encoders_vs_reference_golden():
+    """The two OpenCLIP condition encoders on libvcx (per-head GEMM + masked row softmax attention, head dim 64 and 80,
+    causal text mask, padded token rows) against the outputs of the reference's own embedder code."""
+    from tests.tiny_config import CLIP_TINY, CLIP_TINY_CFG
+    from viewcrafter_amd.lvdm.modules.encoders import condition as cond
+    from oracle import clip_oracle as C
+    cond.CLIP_CONFIGS[CLIP_TINY] = CLIP_TINY_CFG
+    g = golden("clip_tiny")
+    txt = cond.FrozenOpenCLIPEmbedder(arch=CLIP_TINY, layer="penultimate").eval()
+    sd = load_synth(txt)
+    assert sorted(sd.keys()) == [str(k) for k in g["clip_text_keys"]]            # strict-load compatible naming
+    txt = txt.to(DEV)
+    y = txt([""] * 2)
+    assert y.dtype == torch.float32 and tuple(y.shape) == g["clip_text_empty"].shape
+    assert rel_l2(y, torch.from_numpy(g["clip_text_empty"])) <= 8e-3
+    y = txt.encode_with_transformer(torch.from_numpy(g["clip_text_tokens"]))
+    assert rel_l2(y, torch.from_numpy(g["clip_text_random"])) <= 8e-3
+    img = cond.FrozenOpenCLIPImageEmbedderV2(arch=CLIP_TINY).eval()
+    sd = load_synth(img)
+    assert sorted(sd.keys()) == [str(k) for k in g["clip_image_keys"]]
+    img = img.to(DEV)
+    for tag, shp in {"down": (2, 3, 320, 448), "up": (1, 3, 96, 64)}.items():
+        x = torch.tanh(synth_input(f"clip_image_{tag}", shp))
+        y = img(x.to(DEV))
+        assert y.dtype == torch.float32 and tuple(y.shape) == g[f"clip_image_{tag}"].shape
+        assert rel_l2(y, torch.from_numpy(g[f"clip_image_{tag}"])) <= 8e-3, tag
+    # a fresh input (3 images, 576x1024-like aspect) against the fp32 oracle
+    x = torch.tanh(synth_input("clip_image_fresh", (3, 3, 288, 512)))
+    v = CLIP_TINY_CFG["vision"]
+    ref = C.clip_image_forward(sd, x, v["width"] // v["head_width"], v["layers"], v["patch_size"])
+    assert rel_l2(img(x.to(DEV)), ref) <= 8e-3

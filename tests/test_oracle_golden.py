@@ -158,3 +158,26 @@ def test_resampler_oracle_matches_reference():
         y = O.resampler_forward(sd, TINY_RESAMPLER, x)
         assert y.shape == g[f"resampler_out_{tag}"].shape
         assert max_rel(y.numpy(), g[f"resampler_out_{tag}"]) <= 2e-5, tag
+
+
+def test_clip_encoders_oracle_matches_reference():
+    """The reference's FrozenOpenCLIPEmbedder / FrozenOpenCLIPImageEmbedderV2 code (condition.py, run by gen_golden.py on the
+    open_clip / kornia stand-ins) against the state-dict restatement the GPU tests use as their fp32 oracle."""
+    from oracle import clip_oracle as C
+    from tests.tiny_config import CLIP_TINY_CFG
+    assert C.CLIP_CONFIGS["vcx-tiny-test"] == CLIP_TINY_CFG
+    g = load("clip_tiny")
+    t, v = CLIP_TINY_CFG["text"], CLIP_TINY_CFG["vision"]
+    sd, _ = sd_from_fixture(g["clip_text_keys"], g["clip_text_shapes"])
+    assert not any(k.startswith("model.visual.") for k in sd) and "model.transformer.resblocks.0.attn.in_proj_weight" in sd
+    y = C.clip_text_forward(sd, C.tokenize_empty(2), t["heads"], t["layers"], layer_idx=1)
+    assert max_rel(y.numpy(), g["clip_text_empty"]) <= 2e-5
+    y = C.clip_text_forward(sd, torch.from_numpy(g["clip_text_tokens"]), t["heads"], t["layers"], layer_idx=1)
+    assert max_rel(y.numpy(), g["clip_text_random"]) <= 2e-5
+    sd, _ = sd_from_fixture(g["clip_image_keys"], g["clip_image_shapes"])
+    assert not any(k.startswith("model.transformer.") for k in sd) and "model.visual.conv1.weight" in sd
+    for tag, shp in {"down": (2, 3, 320, 448), "up": (1, 3, 96, 64)}.items():
+        x = torch.tanh(synth_input(f"clip_image_{tag}", shp))
+        y = C.clip_image_forward(sd, x, v["width"] // v["head_width"], v["layers"], v["patch_size"])
+        assert y.shape == g[f"clip_image_{tag}"].shape
+        assert max_rel(y.numpy(), g[f"clip_image_{tag}"]) <= 2e-5, tag

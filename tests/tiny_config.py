@@ -38,3 +38,10 @@ def tiny_model_params(unet_target, vae_target, base_scale=0.3):
                                        "lossconfig": ident}},
         cond_stage_config=ident, img_cond_stage_config=ident, image_proj_stage_config=ident,
     ))
+
+
+# tiny OpenCLIP-shaped towers (vision head dim 80 like ViT-H; 224 / 56 = 4x4 patches + class token = 17 tokens)
+CLIP_TINY = "vcx-tiny-test"
+CLIP_TINY_CFG = dict(embed_dim=64,
+                     vision=dict(image_size=224, layers=3, width=160, head_width=80, patch_size=56, mlp_ratio=2.0),
+                     text=dict(context_length=77, vocab_size=49408, width=128, heads=2, layers=3, mlp_ratio=2.0))

@@ -15,9 +15,9 @@ IDENTITY = Config(target="torch.nn.Identity")
 
 
 def model_config_from_yaml(path, conditioners="config"):
-    """conditioners: 'config' keeps the YAML's targets (the two OpenCLIP encoders resolve to the reference implementation,
-    which must be importable together with open_clip / kornia; the Resampler `image_proj_model` resolves to this package's
-    libvcx implementation through TARGET_ALIASES); 'clip_external' replaces only the two CLIP encoders with nn.Identity
+    """conditioners: 'config' keeps the YAML's targets (the two OpenCLIP encoders and the Resampler `image_proj_model` all
+    resolve to this package's libvcx implementations through TARGET_ALIASES; neither open_clip nor kornia is needed - a
+    non-empty text prompt needs CLIP's BPE vocabulary, see lvdm/modules/encoders/condition.py); 'clip_external' replaces only the two CLIP encoders with nn.Identity
     (their token embeddings are computed elsewhere and fed in, the projector runs natively); 'identity' replaces all
     three (benchmarks and tests feed the final context tensors)."""
     cfg = load_yaml(path)

@@ -14,6 +14,9 @@ TARGET_ALIASES = {
     "lvdm.models.autoencoder.AutoencoderKL": "viewcrafter_amd.lvdm.models.autoencoder.AutoencoderKL",
     "lvdm.modules.encoders.resampler.Resampler": "viewcrafter_amd.lvdm.modules.encoders.resampler.Resampler",
     "lvdm.modules.encoders.resampler.ImageProjModel": "viewcrafter_amd.lvdm.modules.encoders.resampler.ImageProjModel",
+    "lvdm.modules.encoders.condition.FrozenOpenCLIPEmbedder": "viewcrafter_amd.lvdm.modules.encoders.condition.FrozenOpenCLIPEmbedder",
+    "lvdm.modules.encoders.condition.FrozenOpenCLIPImageEmbedderV2":
+        "viewcrafter_amd.lvdm.modules.encoders.condition.FrozenOpenCLIPImageEmbedderV2",
 }
 
 
