@@ -21,8 +21,8 @@ namespace {
 // WITHOUT any cross-lane movement by reading the V^T fragment with the same key permutation
 // (a sum over keys does not care about the order as long as P and V agree on it).
 // =======================================================================================
-constexpr int FK = 64;   // keys per tile
-constexpr float FLASH_DEFER = 8.0f;   // log2 units: a tile's probabilities may reach 2^8 before the running max is moved
+[[maybe_unused]] constexpr int FK = 64;   // keys per tile
+[[maybe_unused]] constexpr float FLASH_DEFER = 8.0f;   // log2 units: a tile's probabilities may reach 2^8 before the running max is moved
 
 struct FlashArgs {
     const half_t* q;

@@ -2,19 +2,19 @@
 // (no VGPR staging, no ds_write), addressed through buffer descriptors whose hardware range check supplies the zero
 // fill: padded taps, rows beyond M and weight rows beyond N simply use an out-of-range offset.
 //
-// Why a second kernel: PMC on the register-staged kernel (profiles/r01_pmc_gemm.txt) shows ~5 VALU + 2 SALU
-// instructions per MFMA — 64-bit address arithmetic, bounds predicates and exec-mask branches around every 16-byte
-// load — and MFMA-busy of only ~28 %.  Here a K-step costs, per thread, 4 x (v_add + bit-extract + select) for the
+// Why a second kernel: PMC on the register-staged kernel (gemm.hip; SQ_INSTS_VALU / SQ_INSTS_SALU / MFMA-busy, early round 1)
+// showed ~5 VALU + 2 SALU instructions per MFMA — 64-bit address arithmetic, bounds predicates and exec-mask branches around
+// every 16-byte load — and MFMA-busy of only ~28 %.  Here a K-step costs, per thread, 4 x (v_add + bit-extract + select) for the
 // activation rows of a convolution (nothing at all for a linear layer: the K offset rides in the scalar soffset) and
 // zero instructions for the weight rows.
 //
-// Same tiling as gemm.hip (128 x {128,160} x 64, 4 waves 2x2, weight = MFMA A operand, activation = B operand,
-// XOR-swizzled LDS, persistent XCD-aware tile walk, cross-tile software pipeline); the LDS image is lane-linear per
-// DMA instruction, so the swizzle is applied to the SOURCE chunk each lane fetches (both-sides rule).
+// Same operand roles as gemm.hip (weight = MFMA A operand, activation = B operand, 64-deep K-steps, XOR-swizzled LDS,
+// persistent XCD-aware tile walk, cross-tile software pipeline), tile shapes per TileCfg below; the LDS image is
+// lane-linear per DMA instruction, so the swizzle is applied to the SOURCE chunk each lane fetches (both-sides rule).
 //
-// Eligibility (checked by vcx_gemm_f16, which falls back to gemm.hip otherwise): K % 64 == 0, N % 4 == 0, operand
-// extents < 4 GiB (32-bit buffer offsets), convolutions with cin % 64 == 0 (a K-step then lies inside one tap, so
-// the tap is block-uniform) and no fused upsampling.
+// Eligibility (checked by vcx_gemm_f16, which falls back to gemm.hip otherwise): K % 64 == 0, N % 8 == 0 (N % 4 for the
+// GEGLU and fp32 epilogues), operand / output extents < 4 GiB (32-bit buffer offsets), convolutions with cin % 64 == 0 (a
+// K-step then lies inside one tap, so the tap is block-uniform); stride-2, (3,1,1) and fused nearest-2x taps included.
 #include "gemm_args.h"
 
 using namespace vcxgemm;
@@ -22,7 +22,7 @@ using namespace vcxgemm;
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-constexpr unsigned OOB = 0xFFFFFFFFu;   // voffset beyond any descriptor's num_records -> the load returns zeros
+[[maybe_unused]] constexpr unsigned OOB = 0xFFFFFFFFu;   // voffset beyond any descriptor's num_records -> the load returns zeros
 
 // Tile configuration: block tile TBM x TBN, NWM x NWN waves, each wave owns (TBM/NWM) x (TBN/NWN) outputs.
 //   small : 128 x {128,160}, 2x2 waves (64 x {64,80} per wave), 2 blocks/CU      - few tiles / small M
