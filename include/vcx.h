@@ -52,7 +52,10 @@ int vcx_device_arch(char* name_host, int len);
  *   nn.Conv3d (3,1,1)    lvdm/modules/networks/openaimodel3d.py:255-266
  *   nn.Conv1d k=1        lvdm/modules/attention.py:332-334 (init_attn proj)
  * Mode 1 geometry: image [n_img, in_h, in_w, cin] with pixel stride lda (elements);
- * K = kh*kw*cin ordered (ky, kx, c); output pixel (oy, ox) reads input pixel
+ * K = kh*kw*cin ordered (ky, kx, c) - or, with VCX_GEMM_CONV_SLABK (cin % 64 == 0), in
+ * slabs of 64 input channels, (c / 64, ky, kx, c % 64): all taps of one channel slab are
+ * consecutive K-steps, so the tap re-reads of a tile's input hit L2; output pixel (oy, ox)
+ * reads input pixel
  * ((oy*stride + ky - pad_h) >> ups, (ox*stride + kx - pad_w) >> ups), zero outside
  * [0, in_h<<ups) x [0, in_w<<ups)  (ups=1 fuses F.interpolate(scale_factor=2,'nearest'),
  * openaimodel3d.py:100-103, ae_modules.py:124).  A temporal (3,1,1) convolution is the
@@ -68,6 +71,7 @@ int vcx_device_arch(char* name_host, int len);
                                    [64b, 64b+32) are x for output cols [32b, 32b+32),
                                    rows [64b+32, 64b+64) their gates; out has N/2 columns */
 #define VCX_GEMM_OUT_F32 0x20   /* store fp32 instead of fp16                             */
+#define VCX_GEMM_CONV_SLABK 0x40 /* mode 1: W rows are ordered (c / 64, ky, kx, c % 64)     */
 
 typedef struct vcx_gemm_desc {
     const void* A;        /* fp16 activations                                             */

@@ -293,3 +293,21 @@ def test_clip_tokenizer_contract(tmp_path, monkeypatch):
     long = cond.tokenize(["a " * 200])[0]
     assert long[-1] == 49407 and long[0] == 49406 and (long[1:-1] == ids[1]).all()
     cond._bpe_from_env.cache_clear()
+
+
+def test_pack_conv_slab_major_order_for_64_channel_multiples():
+    """cin % 64 == 0 and more than one tap: K is ordered (c / 64, tap, c % 64) - VCX_GEMM_CONV_SLABK, the order both GEMM
+    kernels walk when ops.conv2d / temporal_conv3 set the flag from the same predicate."""
+    from oracle.weights import synth_input
+    from viewcrafter_amd.packing import conv_slab_major, pack_conv
+    assert conv_slab_major(320, 9) and conv_slab_major(128, 3) and not conv_slab_major(320, 1) and not conv_slab_major(8, 9)
+    w = synth_input("w_slab", (5, 128, 3, 3))
+    x = synth_input("x_slab", (2, 4, 6, 128))
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
+    cols = torch.stack([xp[:, ky:ky + 4, kx:kx + 6, :] for ky in range(3) for kx in range(3)], dim=3)     # n h w tap c
+    cols = cols.view(2, 4, 6, 9, 2, 64).permute(0, 1, 2, 4, 3, 5).reshape(2, 4, 6, 9 * 128)               # n h w (slab tap c64)
+    out = cols @ pack_conv(w).t()
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    assert torch.allclose(out, ref, atol=1e-4)
+    w1 = synth_input("w_1x1", (5, 128, 1, 1))
+    assert torch.equal(pack_conv(w1), w1[:, :, 0, 0])

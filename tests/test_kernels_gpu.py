@@ -127,6 +127,19 @@ def test_conv3x3(n, H, W, cin, cout, stride):
     check(out, ref, name="conv3x3")
 
 
+def test_conv3x3_slab_major_on_the_register_staged_kernel():
+    """cin % 64 == 0 (weights packed slab-major, VCX_GEMM_CONV_SLABK) but cout % 8 != 0: the DMA kernel is not eligible, so the
+    register-staged kernel walks the same K order (the UNet's 320 -> 4 output convolution is this case)."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import pack_conv
+    n, H, W, cin, cout = 2, 9, 16, 128, 12
+    x = rnd(n, H, W, cin, seed=90).to(DEV).half()
+    w = (rnd(cout, cin, 3, 3, seed=91) / math.sqrt(9 * cin)).to(DEV).half()
+    b = rnd(cout, seed=92).to(DEV)
+    out = ops.conv2d(x, pack_conv(w), b, kh=3, kw=3)
+    check(out, conv_ref(x, w, b), name="conv3x3 slab-major, generic kernel")
+
+
 def test_conv3x3_upsample_fused():
     from viewcrafter_amd import ops
     from viewcrafter_amd.packing import pack_conv

@@ -21,7 +21,7 @@ SYMBOLS = [
     "vcx_profile_begin", "vcx_profile_end",
 ]
 
-GEMM_BIAS_N, GEMM_BIAS_M, GEMM_ROWADD, GEMM_RESIDUAL, GEMM_GEGLU, GEMM_OUT_F32 = 1, 2, 4, 8, 16, 32
+GEMM_BIAS_N, GEMM_BIAS_M, GEMM_ROWADD, GEMM_RESIDUAL, GEMM_GEGLU, GEMM_OUT_F32, GEMM_CONV_SLABK = 1, 2, 4, 8, 16, 32, 64
 PROF_FAMILIES = ("gemm", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "elementwise")
 
 

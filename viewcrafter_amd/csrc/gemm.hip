@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
             }
         }
         ci = chunk * 8; ky = 0; kx = 0;
-        if (CONV) {
+        if (CONV && !(p.flags & VCX_GEMM_CONV_SLABK)) {
             while (ci >= p.cin) {
                 ci -= p.cin;
                 if (++kx == p.kw) { kx = 0; ++ky; }
@@ -125,10 +125,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
             wreg[i] = v;
         }
         if (CONV) {  // advance the tap walker to the next K-step
-            ci += BK;
-            while (ci >= p.cin) {
-                ci -= p.cin;
-                if (++kx == p.kw) { kx = 0; ++ky; }
+            if (p.flags & VCX_GEMM_CONV_SLABK) {      // k = ((c / 64) * taps + tap) * 64 + c % 64: a K-step is one tap of one slab
+                if (++kx == p.kw) {
+                    kx = 0;
+                    if (++ky == p.kh) { ky = 0; ci += BK; }
+                }
+            } else {
+                ci += BK;
+                while (ci >= p.cin) {
+                    ci -= p.cin;
+                    if (++kx == p.kw) { kx = 0; ++ky; }
+                }
             }
         }
     };
@@ -407,6 +414,8 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const bool conv = d->mode == 1;
     const bool geglu = flags & VCX_GEMM_GEGLU;
     const bool f32 = flags & VCX_GEMM_OUT_F32;
+    VCX_REQUIRE(!(flags & VCX_GEMM_CONV_SLABK) || (d->mode == 1 && d->cin % 64 == 0),
+                "vcx_gemm_f16: VCX_GEMM_CONV_SLABK needs a convolution with cin %% 64 == 0 (cin=%d)", d->cin);
     VCX_REQUIRE(d->mode == 0 || d->mode == 1, "vcx_gemm_f16: unknown mode %d", d->mode);
     VCX_REQUIRE(!(geglu && (f32 || (flags & (VCX_GEMM_ROWADD | VCX_GEMM_RESIDUAL | VCX_GEMM_BIAS_M)))),
                 "vcx_gemm_f16: GEGLU combines only with BIAS_N");

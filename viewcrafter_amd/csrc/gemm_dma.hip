@@ -142,13 +142,20 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + RSTEP * i * BK), 16, v, 0, 0, 0);
                 }
             }
-            ci0 += BK;                                   // advance the (block-uniform) K walker
-            tap_off += BK * 2;
-            if (ci0 == p.cin) {
-                ci0 = 0;
+            if (p.flags & VCX_GEMM_CONV_SLABK) {         // advance the (block-uniform) K walker: taps inside a 64-channel slab
                 ++tap;
                 if (++tkx == p.kw) { tkx = 0; ++tky; }
-                tap_off = (unsigned)((tky * p.in_w + tkx) * (int)p.lda * 2);
+                if (tap == p.kh * p.kw) { tap = 0; tkx = 0; tky = 0; ci0 += BK; }
+                tap_off = (unsigned)((tky * p.in_w + tkx) * (int)p.lda * 2 + ci0 * 2);
+            } else {                                     // channel slabs inside a tap
+                ci0 += BK;
+                tap_off += BK * 2;
+                if (ci0 == p.cin) {
+                    ci0 = 0;
+                    ++tap;
+                    if (++tkx == p.kw) { tkx = 0; ++tky; }
+                    tap_off = (unsigned)((tky * p.in_w + tkx) * (int)p.lda * 2);
+                }
             }
         } else if (!CONV && (parts & 1)) {
             const unsigned soff = (unsigned)kt * (BK * 2);

@@ -7,8 +7,9 @@ latent is [B, T, H, W, C] and all token matrices are [rows, C] views of it.
 import ctypes
 import torch
 
-from ._lib import (GEMM_BIAS_M, GEMM_BIAS_N, GEMM_GEGLU, GEMM_OUT_F32, GEMM_RESIDUAL, GEMM_ROWADD, PROF_FAMILIES,
+from ._lib import (GEMM_BIAS_M, GEMM_BIAS_N, GEMM_CONV_SLABK, GEMM_GEGLU, GEMM_OUT_F32, GEMM_RESIDUAL, GEMM_ROWADD, PROF_FAMILIES,
                    GemmDesc, VcxError, check, lib)
+from .packing import conv_slab_major
 
 _f16 = torch.float16
 _f32 = torch.float32
@@ -69,6 +70,8 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
         d.in_h, d.in_w, d.out_h, d.out_w = conv["in_h"], conv["in_w"], conv["out_h"], conv["out_w"]
         d.cin, d.kh, d.kw = conv["cin"], conv["kh"], conv["kw"]
         d.stride, d.pad_h, d.pad_w, d.ups = conv["stride"], conv["pad_h"], conv["pad_w"], conv.get("ups", 0)
+        if conv.get("slabk", conv_slab_major(conv["cin"], conv["kh"] * conv["kw"])):     # the order pack_conv() produced
+            flags |= GEMM_CONV_SLABK
     d.flags = flags
     d.alpha = alpha
     check(lib().vcx_gemm_f16(ctypes.byref(d), _stream()), "vcx_gemm_f16")
@@ -82,7 +85,7 @@ def linear(x, w, bias=None, **kw):
 
 
 def conv2d(x, w, bias, *, kh, kw, stride=1, pad_h=None, pad_w=None, ups=0, out_hw=None, **kwargs):
-    """x [n, H, W, Cin] channels-last fp16, w [Cout, kh*kw*Cin] (tap-major).  Returns [n, Ho, Wo, Cout]."""
+    """x [n, H, W, Cin] channels-last fp16, w [Cout, kh*kw*Cin] as packed by packing.pack_conv.  Returns [n, Ho, Wo, Cout]."""
     n, H, W, cin = x.shape
     if pad_h is None:
         pad_h = kh // 2
@@ -100,7 +103,7 @@ def conv2d(x, w, bias, *, kh, kw, stride=1, pad_h=None, pad_w=None, ups=0, out_h
 
 
 def temporal_conv3(x, w, bias, **kwargs):
-    """x [B, T, P, C]; (3,1,1) convolution along T with zero padding; w [Cout, 3*Cin] (tap-major)."""
+    """x [B, T, P, C]; (3,1,1) convolution along T with zero padding; w [Cout, 3*Cin] as packed by packing.pack_conv."""
     B, T, P, C = x.shape
     geom = dict(in_h=T, in_w=P, out_h=T, out_w=P, cin=C, kh=3, kw=1, stride=1, pad_h=1, pad_w=0, ups=0)
     out = gemm(x, w, M=B * T * P, N=w.shape[0], K=3 * C, lda=x.stride(2), bias=bias, conv=geom, **kwargs)

@@ -7,11 +7,21 @@ Kernel layouts: fp16 [N_out][K] with K ordered (tap, cin); GEGLU rows interleave
 import torch
 
 
+def conv_slab_major(cin, taps):
+    """Convolutions with cin % 64 == 0 and more than one tap keep their K axis in slabs of 64 input channels with the taps
+    inside (VCX_GEMM_CONV_SLABK, include/vcx.h): the 9 (or 3) tap re-reads of a tile's input are then consecutive K-steps
+    and hit L2 instead of going back to the memory side.  pack_conv and ops.conv2d / temporal_conv3 share this predicate."""
+    return cin % 64 == 0 and taps > 1
+
+
 def pack_conv(w):
-    """[Cout, Cin, *kernel] -> [Cout, taps*Cin] with the tap index slow and Cin fast (im2col order of the
-    channels-last gather in csrc/gemm.hip)."""
+    """[Cout, Cin, *kernel] -> [Cout, taps*Cin]: K ordered (tap, c) - the im2col order of the channels-last gather in
+    csrc/gemm.hip - or (c / 64, tap, c % 64) where conv_slab_major() says so."""
     cout, cin = w.shape[0], w.shape[1]
     wk = w.reshape(cout, cin, -1)            # [Cout, Cin, taps]
+    taps = wk.shape[2]
+    if conv_slab_major(cin, taps):
+        return wk.view(cout, cin // 64, 64, taps).permute(0, 1, 3, 2).reshape(cout, -1).contiguous()
     return wk.permute(0, 2, 1).reshape(cout, -1).contiguous()
 
 
