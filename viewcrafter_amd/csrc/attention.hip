@@ -33,6 +33,7 @@ struct FlashArgs {
     int64_t ldq, ldk, ldvt, ldo;
     float scale_log2;
     int accumulate;   // VCX_ATTN_* flag bits
+    int nqb, nprob;   // query blocks per problem, problems (group x head): the 1-D grid is nqb * roundup(nprob, 8)
 };
 
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
@@ -58,8 +59,13 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int lq = lane & 31, hi = lane >> 5;
-    const int g = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
-    const int q0 = (blockIdx.x * 4 + wave) * (32 * QB);
+    // Workgroups go to the 8 XCDs round-robin by linear id.  All query blocks of one (group, head) problem are given ids of
+    // the same residue mod 8, so the problem's K / V^T (2.4 MB at 9216 keys) is pulled into ONE XCD's L2 instead of all eight.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int prob = (slot / p.nqb) * 8 + xcd;
+    if (prob >= p.nprob) return;
+    const int g = prob / p.heads, h = prob % p.heads;
+    const int q0 = ((slot % p.nqb) * 4 + wave) * (32 * QB);
 
     const half_t* qbase = p.q + ((int64_t)g * p.nq) * p.ldq + h * 64;
     const int64_t kvrow0 = (int64_t)(g / p.kv_div) * p.kv_rows;
@@ -437,7 +443,7 @@ extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* 
                 (long long)ldq, (long long)ldk, (long long)ldvt, kv_rows, nk);
     VCX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0 && ((uintptr_t)o & 7) == 0,
                 "vcx_attn_flash_d64_f16: pointers must be 16-byte aligned");
-    VCX_REQUIRE((int64_t)n_groups * heads <= 65535, "vcx_attn_flash_d64_f16: too many (group, head) problems");
+    VCX_REQUIRE((int64_t)n_groups * heads * ((nq + 127) / 128) < (1ll << 30), "vcx_attn_flash_d64_f16: too many workgroups");
     FlashArgs a;
     a.q = (const half_t*)q; a.k = (const half_t*)k; a.vt = (const half_t*)vt; a.o = (half_t*)o;
     a.heads = heads; a.nq = nq; a.nk = nk; a.kv_rows = kv_rows; a.kv_div = kv_div;
@@ -456,12 +462,16 @@ extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* 
     bool qb2 = (double)nq / (blocks2 * 256.0) >= 0.8;
     if (force_qb == 1) qb2 = false;
     if (force_qb == 2) qb2 = true;
+    a.nprob = n_groups * heads;
+    const int prob_pad = (a.nprob + 7) / 8 * 8;
     if (qb2) {
-        dim3 grid(blocks2, n_groups * heads);
+        a.nqb = blocks2;
+        dim3 grid(blocks2 * prob_pad);
         if (pre) hipLaunchKernelGGL((flash_d64_kernel<2, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((flash_d64_kernel<2, false>), grid, dim3(256), 0, s, a);
     } else {
-        dim3 grid((nq + 127) / 128, n_groups * heads);
+        a.nqb = (nq + 127) / 128;
+        dim3 grid(a.nqb * prob_pad);
         if (pre) hipLaunchKernelGGL((flash_d64_kernel<1, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((flash_d64_kernel<1, false>), grid, dim3(256), 0, s, a);
     }
