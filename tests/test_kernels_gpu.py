@@ -91,6 +91,26 @@ def test_gemm_rowadd():
     check(out, ref, name="rowadd")
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(2853, 5120, 128, False), (1500, 4096, 64, True), (16640, 5120, 64, True), (2048, 2560, 192, False)])
+def test_gemm_panel_walk_many_column_tiles(M, N, K, geglu):
+    """>= 16 column tiles switch the persistent walk to 8-row panels (tile_m fastest): every output tile must still be
+    produced exactly once, including the ragged last panel and the large-tile / tail-split launches."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import pack_geglu
+    x = rnd(M, K, seed=101).to(DEV).half()
+    w = (rnd(N, K, seed=102) / math.sqrt(K)).to(DEV)
+    b = rnd(N, seed=103).to(DEV) * 0.1
+    if geglu:
+        wp, bp = pack_geglu(w, b)
+        out = ops.linear(x, wp.half(), bp, geglu=True)
+        a, g = (x.float() @ w.half().float().t() + b).chunk(2, dim=-1)
+        ref = a * F.gelu(g)
+    else:
+        out = ops.linear(x, w.half(), b)
+        ref = x.float() @ w.half().float().t() + b
+    check(out, ref, name="panel walk")
+
+
 @pytest.mark.parametrize("C", [64, 320])
 def test_gemm_geglu(C):
     from viewcrafter_amd import ops
