@@ -19,10 +19,12 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("M,N,K", [(B * T * H * W, 320, 320), (B * T * H * W // 4, 640, 640), (110000, 320, 128), (100000, 512, 64),
-                                   (B * T * H * W, 960, 320)])
+                                   (B * T * H * W, 960, 320),
+                                   # >= 16 column tiles: the 8-row panel walk, with a ragged last panel (113 row tiles)
+                                   (B * T * H * W // 16, 5120, 128)])
 def test_gemm_linearity_and_subsample_exactness_at_full_size(M, N, K):
     """(x1 + x2) W^T == x1 W^T + x2 W^T up to fp16 rounding, and random rows agree with an fp32 matmul: exercises the
-    256x{256,320} tiles, the tail split onto small tiles and the persistent tile walk at the real M."""
+    256x{256,320} tiles, the tail split onto small tiles and the persistent tile walk (row-major and panel) at the real M."""
     from viewcrafter_amd import ops
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
     x1 = torch.randn(M, K, device=DEV, generator=g).half()
