@@ -44,20 +44,29 @@ extern "C" int vcx_device_arch(char* name_host, int len) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Profiling: a pool of event pairs; each profiled launch takes the next pair.
+// Profiling: HIP-event brackets around RUNS of launches of one kernel family on one stream.  A run is opened by the
+// first launch of a family and closed - one hipEventRecord - when a launch of another family (or vcx_profile_end)
+// follows; the closing event of a run is the opening event of the next one.  Each hipEventRecord costs ~2-3 us of GPU
+// time, so bracketing runs instead of launches roughly halves the overhead inside bench.py's timed region.
 // ---------------------------------------------------------------------------------------
 struct ProfRec {
     hipEvent_t a, b;
-    int start_rec;   // >= 0: the start timestamp is record start_rec's END event (back-to-back launches on one stream
-                     // share one event: each hipEventRecord costs ~2 us of GPU time, 2100 launches per DDIM step)
+    int start_rec;   // >= 0: the start timestamp is record start_rec's END event
     int family;
-    double flops, bytes;
+    double launches, flops, bytes;
     hipStream_t stream;
 };
 static std::vector<ProfRec> g_recs;
 static int g_nrec = 0;
 static bool g_prof_on = false;
-static int g_last_rec = -1;     // last record whose end event can serve as the next start
+static int g_open = -1;         // the run still open (its end event not yet recorded)
+
+static void prof_close_open_run() {
+    if (g_open >= 0) {
+        (void)hipEventRecord(g_recs[g_open].b, g_recs[g_open].stream);
+        g_open = -1;
+    }
+}
 
 extern "C" int vcx_profile_begin(int max_records) {
     if (max_records <= 0) max_records = 1;
@@ -68,18 +77,19 @@ extern "C" int vcx_profile_begin(int max_records) {
             return VCX_ELAUNCH;
         }
         r.family = 0;
-        r.flops = r.bytes = 0;
+        r.launches = r.flops = r.bytes = 0;
         r.start_rec = -1;
         r.stream = nullptr;
         g_recs.push_back(r);
     }
     g_nrec = 0;
-    g_last_rec = -1;
+    g_open = -1;
     g_prof_on = true;
     return VCX_OK;
 }
 
 extern "C" int vcx_profile_end(double* out_host) {
+    prof_close_open_run();
     g_prof_on = false;
     for (int i = 0; i < VCX_PROF_FAMILIES * 4; ++i) out_host[i] = 0.0;
     for (int i = 0; i < g_nrec; ++i) {
@@ -95,7 +105,7 @@ extern "C" int vcx_profile_end(double* out_host) {
             return VCX_ELAUNCH;
         }
         double* o = out_host + 4 * r.family;
-        o[0] += 1.0;
+        o[0] += r.launches;
         o[1] += (double)ms;
         o[2] += r.flops;
         o[3] += r.bytes;
@@ -105,23 +115,34 @@ extern "C" int vcx_profile_end(double* out_host) {
 }
 
 VcxProfScope::VcxProfScope(int family, hipStream_t stream, double flops, double bytes) : rec(-1), s(stream) {
-    if (!g_prof_on || g_nrec >= (int)g_recs.size()) return;
+    if (!g_prof_on) return;
+    if (g_open >= 0 && g_recs[g_open].family == family && g_recs[g_open].stream == s) {   // same run: just account
+        ProfRec& r = g_recs[g_open];
+        r.launches += 1.0;
+        r.flops += flops;
+        r.bytes += bytes;
+        return;
+    }
+    if (g_nrec >= (int)g_recs.size()) {       // pool exhausted: stop recording (the open run is closed at its true end)
+        prof_close_open_run();
+        return;
+    }
+    const int prev = g_open;
+    const bool chain = prev >= 0 && g_recs[prev].stream == s;
+    prof_close_open_run();
     rec = g_nrec++;
     ProfRec& r = g_recs[rec];
     r.family = family;
+    r.launches = 1.0;
     r.flops = flops;
     r.bytes = bytes;
     r.stream = s;
-    if (g_last_rec >= 0 && g_recs[g_last_rec].stream == s) {
-        r.start_rec = g_last_rec;          // previous launch's end event doubles as this launch's start
+    if (chain) {
+        r.start_rec = prev;                  // the previous run's end event doubles as this run's start
     } else {
         r.start_rec = -1;
         (void)hipEventRecord(r.a, s);
     }
+    g_open = rec;
 }
-VcxProfScope::~VcxProfScope() {
-    if (rec >= 0) {
-        (void)hipEventRecord(g_recs[rec].b, s);
-        g_last_rec = rec;
-    }
-}
+VcxProfScope::~VcxProfScope() {}
