@@ -138,6 +138,17 @@ int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* vt, void* o
                            int64_t ldk, int64_t ldvt, int64_t ldo, float scale, int flags,
                            void* stream);
 
+/* Two key/value sets in one pass:  O = softmax(scale Q K1^T) V1 + softmax(scale Q K2^T) V2
+ * - the text (+) image cross-attention of attention.py:129-142 (image_cross_attention_scale
+ * = 1) without reading Q twice and without writing O, reading it back and writing it again.
+ * Same addressing as above per set (kv_rows / kv_div / ldk / ldvt / nk with suffix 1, 2);
+ * the two partial results are added in fp32 and rounded once.  flags: VCX_ATTN_LOG2_LOGITS. */
+int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const void* vt1, const void* k2,
+                                const void* vt2, void* o, int n_groups, int heads, int nq,
+                                int nk1, int kv_rows1, int kv_div1, int64_t ldk1, int64_t ldvt1,
+                                int nk2, int kv_rows2, int kv_div2, int64_t ldk2, int64_t ldvt2,
+                                int64_t ldq, int64_t ldo, float scale, int flags, void* stream);
+
 /* Temporal self-attention over T <= 32 frames per pixel, head dim 64
  * (TemporalTransformer -> CrossAttention.forward, attention.py:365-412, 81-126).
  * qkv is [(b t p)][ld] with q at col 0, k at col k_off, v at col v_off (+ h*64);

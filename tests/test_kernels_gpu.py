@@ -397,6 +397,43 @@ def test_flash_cross_attention_text_plus_image(T, shared):
     check(out, ref, tol=3e-3, name="cross-attn")
 
 
+@pytest.mark.parametrize("T,shared,nq,log2", [(5, True, 144, True), (4, False, 144, False), (3, True, 1000, True), (2, False, 77, True)])
+def test_flash_dual_text_plus_image(T, shared, nq, log2):
+    """vcx_attn_flash_dual_d64_f16: softmax(QK_txt)V_txt + softmax(QK_img)V_img in one pass (77 text keys padded to 80 rows,
+    256 shared or 16 per-frame image keys), against the two separate softmaxes in fp32."""
+    from viewcrafter_amd import ops
+    B, heads = 2, 2
+    C = heads * 64
+    G = B * T
+    n_img = 256 if shared else 16
+    q = rnd(G * nq, C, seed=155)
+    kt = torch.zeros(B, 80, C); vtx = torch.zeros(B, 80, C)
+    kt[:, :77] = rnd(B, 77, C, seed=156); vtx[:, :77] = rnd(B, 77, C, seed=157)
+    ng_img = B if shared else G
+    ki = rnd(ng_img, n_img, C, seed=158); vi = rnd(ng_img, n_img, C, seed=159)
+    scale = 0.125
+    qd = _log2_q(q, scale).to(DEV) if log2 else q.to(DEV).half()
+    kt, vtx, ki, vi = [t.to(DEV).half() for t in (kt, vtx, ki, vi)]
+    out = torch.empty(G * nq, C, device=DEV, dtype=torch.float16)
+    vt_t = vtx.reshape(B * 80, C).t().contiguous()
+    vi_t = vi.reshape(ng_img * n_img, C).t().contiguous()
+    ops.flash_attn_dual(qd, kt.view(B * 80, C), vt_t, ki.view(-1, C), vi_t, out, n_groups=G, heads=heads, nq=nq, nk1=77, kv_rows1=80,
+                        kv_div1=T, ldk1=C, ldvt1=B * 80, nk2=n_img, kv_rows2=n_img, kv_div2=T if shared else 1, ldk2=C,
+                        ldvt2=ng_img * n_img, ldq=C, ldo=C, scale=scale, log2_logits=log2)
+
+    def split(t, n):  # [groups, n, C] -> [(groups heads), n, 64]
+        return t.view(-1, n, heads, 64).permute(0, 2, 1, 3).reshape(-1, n, 64)
+    sc = LN2 if log2 else scale
+    qh = split(qd.view(G, nq, C), nq)
+    kth = split(kt[:, :77].repeat_interleave(T, 0), 77)
+    vth = split(vtx[:, :77].repeat_interleave(T, 0), 77)
+    kih = split(ki.repeat_interleave(T, 0) if shared else ki, n_img)
+    vih = split(vi.repeat_interleave(T, 0) if shared else vi, n_img)
+    ref = attn_ref(qh, kth, vth, sc) + attn_ref(qh, kih, vih, sc)
+    ref = ref.view(G, heads, nq, 64).permute(0, 2, 1, 3).reshape(G * nq, C)
+    check(out, ref, tol=3e-3, name="dual cross-attn")
+
+
 @pytest.mark.parametrize("B,T,P,heads", [(1, 16, 40, 2), (2, 25, 37, 5), (1, 4, 8, 1)])
 def test_temporal_attention(B, T, P, heads):
     from viewcrafter_amd import ops

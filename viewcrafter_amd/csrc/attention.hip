@@ -34,6 +34,11 @@ struct FlashArgs {
     float scale_log2;
     int accumulate;   // VCX_ATTN_* flag bits
     int nqb, nprob;   // query blocks per problem, problems (group x head): the 1-D grid is nqb * roundup(nprob, 8)
+    // second key / value set of the DUAL kernel (O = softmax(Q K1^T) V1 + softmax(Q K2^T) V2 in one pass over Q and O)
+    const half_t* k2;
+    const half_t* vt2;
+    int nk2, kv_rows2, kv_div2;
+    int64_t ldk2, ldvt2;
 };
 
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
@@ -49,7 +54,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // The first MFMA of a score accumulator then takes C = -m (the running max, kept in a 16-register tuple that changes only
 // when the max moves) and the matrix pipe delivers s - m directly: the per-score fma of the plain path disappears
 // (VALU and MFMA issue do not overlap on a SIMD - tools/ubench.hip - so every VALU instruction removed is time).
-template <int QB, bool PRE>
+//
+// DUAL: text (+) image cross-attention (attention.py:129-142) in one launch: the key / value loop runs twice, over (k, vt)
+// and over (k2, vt2), each with its own softmax normalisation; the first result stays in registers (fp32) and the sum is
+// rounded once.  Q is read once and O written once - run as two launches these layers are pure overhead (Q read twice,
+// O written, read back and written again at 2.2-2.6 TB/s).
+template <int QB, bool PRE, bool DUAL = false>
 __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) half_t sK[2][64 * 64];
@@ -68,14 +78,6 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
     const int q0 = ((slot % p.nqb) * 4 + wave) * (32 * QB);
 
     const half_t* qbase = p.q + ((int64_t)g * p.nq) * p.ldq + h * 64;
-    const int64_t kvrow0 = (int64_t)(g / p.kv_div) * p.kv_rows;
-    const half_t* kbase = p.k + kvrow0 * p.ldk + h * 64;
-    const half_t* vbase = p.vt + (int64_t)(h * 64) * p.ldvt + kvrow0;
-    const unsigned k_bytes = (unsigned)(((int64_t)(p.nk - 1) * p.ldk + 64) * 2);
-    const unsigned v_bytes = (unsigned)((63ll * p.ldvt + ((p.nk + 7) & ~7)) * 2);
-    const __amdgpu_buffer_rsrc_t srd_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kbase), 0, (int)k_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vbase), 0, (int)v_bytes, 0x00020000);
-
     // Q fragments (B operand): lane (q = lq, hi) holds Q[q][s*16 + hi*8 .. +7]
     const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     h8 qf[QB][4];
@@ -89,6 +91,25 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
             qf[b][s] = qvalid[b] ? *reinterpret_cast<const h8*>(qbase + (int64_t)qrow * p.ldq + s * 16 + hi * 8) : zero8;
     }
 
+    // DUAL: normalised result of the first key set - fp32 with one query block per wave, packed fp16 with two (registers)
+    typedef half_t h16v __attribute__((ext_vector_type(16)));
+    f16v keep[(DUAL && QB == 1) ? QB : 1][2];
+    h16v keep16[(DUAL && QB == 2) ? QB : 1][2];
+#pragma unroll 1
+  for (int set = 0; set < (DUAL ? 2 : 1); ++set) {
+    const half_t* k_s = (DUAL && set) ? p.k2 : p.k;
+    const half_t* vt_s = (DUAL && set) ? p.vt2 : p.vt;
+    const int nk_s = (DUAL && set) ? p.nk2 : p.nk, kv_rows_s = (DUAL && set) ? p.kv_rows2 : p.kv_rows;
+    const int kv_div_s = (DUAL && set) ? p.kv_div2 : p.kv_div;
+    const int64_t ldk_s = (DUAL && set) ? p.ldk2 : p.ldk, ldvt_s = (DUAL && set) ? p.ldvt2 : p.ldvt;
+    const int64_t kvrow0 = (int64_t)(g / kv_div_s) * kv_rows_s;
+    const half_t* kbase = k_s + kvrow0 * ldk_s + h * 64;
+    const half_t* vbase = vt_s + (int64_t)(h * 64) * ldvt_s + kvrow0;
+    const unsigned k_bytes = (unsigned)(((int64_t)(nk_s - 1) * ldk_s + 64) * 2);
+    const unsigned v_bytes = (unsigned)((63ll * ldvt_s + ((nk_s + 7) & ~7)) * 2);
+    const __amdgpu_buffer_rsrc_t srd_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kbase), 0, (int)k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vbase), 0, (int)v_bytes, 0x00020000);
+
     // DMA map: 512 16-byte chunks per tile and operand, 2 per thread; source chunk swizzled, LDS image lane-linear
     const int srow = tid >> 3, spos = tid & 7;
     unsigned koff[2], voff[2];
@@ -97,20 +118,20 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
     for (int i = 0; i < 2; ++i) {
         const int r = srow + 32 * i;
         const int csrc = spos ^ ((r >> 1) & 7);
-        koff[i] = (unsigned)((int64_t)r * p.ldk * 2) + csrc * 16;       // + kt*64 rows per tile
-        voff[i] = (unsigned)((int64_t)r * p.ldvt * 2) + csrc * 16;      // + kt*128 bytes per tile
+        koff[i] = (unsigned)((int64_t)r * ldk_s * 2) + csrc * 16;       // + kt*64 rows per tile
+        voff[i] = (unsigned)((int64_t)r * ldvt_s * 2) + csrc * 16;      // + kt*128 bytes per tile
         vkey[i] = csrc * 8;                                             // first key of this V^T chunk inside the tile
     }
-    const unsigned krow_bytes = (unsigned)(p.ldk * 2);
+    const unsigned krow_bytes = (unsigned)(ldk_s * 2);
     auto load_tile = [&](int kt, int buf) {
         half_t* dk = &sK[buf][wave * 8 * 64];
         half_t* dv = &sV[buf][wave * 8 * 64];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int key = kt * FK + srow + 32 * i;
-            const unsigned kv = key < p.nk ? koff[i] + (unsigned)(kt * FK) * krow_bytes : 0xFFFFFFFFu;
+            const unsigned kv = key < nk_s ? koff[i] + (unsigned)(kt * FK) * krow_bytes : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_k, (lds_ptr_t)(dk + 32 * i * 64), 16, kv, 0, 0, 0);
-            const unsigned vv = (kt * FK + vkey[i] < p.nk) ? voff[i] + (unsigned)(kt * FK * 2) : 0xFFFFFFFFu;
+            const unsigned vv = (kt * FK + vkey[i] < nk_s) ? voff[i] + (unsigned)(kt * FK * 2) : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_v, (lds_ptr_t)(dv + 32 * i * 64), 16, vv, 0, 0, 0);
         }
     };
@@ -131,7 +152,7 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) cinit[b][i] = 0.f;
 
-    const int ntiles = (p.nk + FK - 1) / FK;
+    const int ntiles = (nk_s + FK - 1) / FK;
     load_tile(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
@@ -157,7 +178,7 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
         // ---- online softmax per query block in the log2 domain: p = 2^(s*c - m), one fma + one v_exp per score.
         // Key masking exists only in the code path of a partial last tile (block-uniform branch).
         const int key_base = kt * FK;
-        if (key_base + FK > p.nk) {
+        if (key_base + FK > nk_s) {
 #pragma unroll
             for (int b = 0; b < QB; ++b)
 #pragma unroll
@@ -165,7 +186,7 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (key >= p.nk) sacc[b][kb][r] = -1e30f;
+                        if (key >= nk_s) sacc[b][kb][r] = -1e30f;
                     }
         }
 #pragma unroll
@@ -257,6 +278,16 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
     for (int b = 0; b < QB; ++b) {
         const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32);
         const float inv = 1.0f / l_tot;
+        if (DUAL && set == 0) {          // keep softmax(Q K1^T) V1, go round again for the second set
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (QB == 1) keep[QB == 1 ? b : 0][db][i] = oacc[b][db][i] * inv;
+                    else keep16[QB == 2 ? b : 0][db][i] = (half_t)(oacc[b][db][i] * inv);
+                }
+            continue;
+        }
         if (qvalid[b]) {
             half_t* orow = p.o + ((int64_t)g * p.nq + q0 + b * 32 + lq) * p.ldo + h * 64;
 #pragma unroll
@@ -267,6 +298,10 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = oacc[b][db][gq * 4 + r] * inv;
+                    if (DUAL) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += QB == 1 ? keep[QB == 1 ? b : 0][db][gq * 4 + r] : (float)keep16[QB == 2 ? b : 0][db][gq * 4 + r];
+                    }
                     if (p.accumulate & VCX_ATTN_ACCUMULATE) {
                         const h4 old = *reinterpret_cast<const h4*>(orow + d0);
 #pragma unroll
@@ -276,6 +311,7 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
                 }
         }
     }
+  }
 #endif
 }
 
@@ -450,6 +486,7 @@ extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* 
     a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.accumulate = flags;
+    a.k2 = nullptr; a.vt2 = nullptr; a.nk2 = 0; a.kv_rows2 = 0; a.kv_div2 = 1; a.ldk2 = 0; a.ldvt2 = 0;
     const bool pre = flags & VCX_ATTN_LOG2_LOGITS;
     hipStream_t s = (hipStream_t)stream;
     const double nprob = (double)n_groups * heads;
@@ -476,6 +513,55 @@ extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* 
         else hipLaunchKernelGGL((flash_d64_kernel<1, false>), grid, dim3(256), 0, s, a);
     }
     return vcx_check_launch("vcx_attn_flash_d64_f16");
+}
+
+extern "C" int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const void* vt1, const void* k2, const void* vt2, void* o,
+                                           int n_groups, int heads, int nq, int nk1, int kv_rows1, int kv_div1, int64_t ldk1,
+                                           int64_t ldvt1, int nk2, int kv_rows2, int kv_div2, int64_t ldk2, int64_t ldvt2,
+                                           int64_t ldq, int64_t ldo, float scale, int flags, void* stream) {
+    VCX_REQUIRE(q && k1 && vt1 && k2 && vt2 && o, "vcx_attn_flash_dual_d64_f16: null pointer");
+    VCX_REQUIRE(n_groups > 0 && heads > 0 && nq > 0 && nk1 > 0 && nk2 > 0 && kv_div1 > 0 && kv_div2 > 0,
+                "vcx_attn_flash_dual_d64_f16: empty problem");
+    VCX_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && ldk1 % 8 == 0 && ldvt1 % 8 == 0 && ldk2 % 8 == 0 && ldvt2 % 8 == 0 &&
+                kv_rows1 % 8 == 0 && kv_rows1 >= nk1 && kv_rows2 % 8 == 0 && kv_rows2 >= nk2,
+                "vcx_attn_flash_dual_d64_f16: strides must be multiples of 8 and kv_rows >= nk");
+    VCX_REQUIRE((((uintptr_t)q | (uintptr_t)k1 | (uintptr_t)vt1 | (uintptr_t)k2 | (uintptr_t)vt2) & 15) == 0 && ((uintptr_t)o & 7) == 0,
+                "vcx_attn_flash_dual_d64_f16: pointers must be 16-byte aligned");
+    VCX_REQUIRE(!(flags & VCX_ATTN_ACCUMULATE), "vcx_attn_flash_dual_d64_f16: VCX_ATTN_ACCUMULATE is not supported here");
+    VCX_REQUIRE((int64_t)n_groups * heads * ((nq + 127) / 128) < (1ll << 30), "vcx_attn_flash_dual_d64_f16: too many workgroups");
+    VCX_REQUIRE(((int64_t)(nk1 - 1) * ldk1 + 64) * 2 < 0xFFFF0000ll && (63ll * ldvt1 + nk1 + 8) * 2 < 0xFFFF0000ll &&
+                ((int64_t)(nk2 - 1) * ldk2 + 64) * 2 < 0xFFFF0000ll && (63ll * ldvt2 + nk2 + 8) * 2 < 0xFFFF0000ll,
+                "vcx_attn_flash_dual_d64_f16: K / V^T extents per (group, head) must stay below 4 GiB");
+    FlashArgs a;
+    a.q = (const half_t*)q; a.o = (half_t*)o;
+    a.k = (const half_t*)k1; a.vt = (const half_t*)vt1; a.nk = nk1; a.kv_rows = kv_rows1; a.kv_div = kv_div1; a.ldk = ldk1; a.ldvt = ldvt1;
+    a.k2 = (const half_t*)k2; a.vt2 = (const half_t*)vt2; a.nk2 = nk2; a.kv_rows2 = kv_rows2; a.kv_div2 = kv_div2; a.ldk2 = ldk2; a.ldvt2 = ldvt2;
+    a.heads = heads; a.nq = nq; a.ldq = ldq; a.ldo = ldo;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.accumulate = flags;
+    a.nprob = n_groups * heads;
+    hipStream_t s = (hipStream_t)stream;
+    const double nprob = (double)n_groups * heads;
+    VcxProfScope prof(VCX_FAM_FLASH, s, 4.0 * nprob * nq * (double)(nk1 + nk2) * 64, 2.0 * nprob * 64 * (2.0 * nq + 2.0 * (nk1 + nk2)));
+    // two query blocks per wave (half the LDS fragment traffic per MFMA) unless that wastes > 20 % of the 256-row blocks; with
+    // two blocks the kept first result is packed fp16 and the running-max-in-C variant is not used (register budget)
+    static const int force_qb = []() { const char* e = getenv("VCX_FLASH_QB"); return e ? atoi(e) : 0; }();
+    const int blocks2 = (nq + 255) / 256;
+    bool qb2 = (double)nq / (blocks2 * 256.0) >= 0.8;
+    if (force_qb == 1) qb2 = false;
+    if (force_qb == 2) qb2 = true;
+    const bool pre = flags & VCX_ATTN_LOG2_LOGITS;
+    a.nqb = qb2 ? blocks2 : (nq + 127) / 128;
+    dim3 grid(a.nqb * ((a.nprob + 7) / 8 * 8));
+    if (qb2) {
+        if (pre) a.scale_log2 = 1.0f;       // the plain kernel multiplies the scores by scale_log2: base-2 logits need 1
+        hipLaunchKernelGGL((flash_d64_kernel<2, false, true>), grid, dim3(256), 0, s, a);
+    } else if (pre) {
+        hipLaunchKernelGGL((flash_d64_kernel<1, true, true>), grid, dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((flash_d64_kernel<1, false, true>), grid, dim3(256), 0, s, a);
+    }
+    return vcx_check_launch("vcx_attn_flash_dual_d64_f16");
 }
 
 extern "C" int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads, int64_t ld,

@@ -245,13 +245,15 @@ class SpatialTransformer(PackedModule):
             q2 = ops.linear(h2, a2["wq"], alpha=blk.attn2.scale * ops.LOG2E)
             o2 = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
             nb = kv.n_txt_rows // 80
-            ops.flash_attn(q2, kv.k_txt, kv.vt_txt, o2, n_groups=n, heads=heads, nq=N, nk=blk.attn2.text_context_len,
-                           kv_rows=80, kv_div=frames_per_video, ldq=D, ldk=D, ldvt=nb * 80, ldo=D, scale=blk.attn2.scale,
-                           log2_logits=True)
-            if kv.k_img is not None:
-                ops.flash_attn(q2, kv.k_img, kv.vt_img, o2, n_groups=n, heads=heads, nq=N, nk=kv.n_img, kv_rows=kv.n_img,
-                               kv_div=1 if kv.img_per_frame else frames_per_video, ldq=D, ldk=D,
-                               ldvt=kv.vt_img.shape[1], ldo=D, scale=blk.attn2.scale, accumulate=True, log2_logits=True)
+            if kv.k_img is not None:     # text (+) image in one pass over q2 / o2
+                ops.flash_attn_dual(q2, kv.k_txt, kv.vt_txt, kv.k_img, kv.vt_img, o2, n_groups=n, heads=heads, nq=N,
+                                    nk1=blk.attn2.text_context_len, kv_rows1=80, kv_div1=frames_per_video, ldk1=D, ldvt1=nb * 80,
+                                    nk2=kv.n_img, kv_rows2=kv.n_img, kv_div2=1 if kv.img_per_frame else frames_per_video,
+                                    ldk2=D, ldvt2=kv.vt_img.shape[1], ldq=D, ldo=D, scale=blk.attn2.scale, log2_logits=True)
+            else:
+                ops.flash_attn(q2, kv.k_txt, kv.vt_txt, o2, n_groups=n, heads=heads, nq=N, nk=blk.attn2.text_context_len,
+                               kv_rows=80, kv_div=frames_per_video, ldq=D, ldk=D, ldvt=nb * 80, ldo=D, scale=blk.attn2.scale,
+                               log2_logits=True)
             t = ops.linear(o2, a2["wo"], a2["bo"], residual=t)
             # ---- feed-forward
             t = blk.ff.run(ops.layer_norm(t, *ln[2]), t)

@@ -154,6 +154,16 @@ def flash_attn(q, k, vt, out, *, n_groups, heads, nq, nk, kv_rows, kv_div, ldq, 
     return out
 
 
+def flash_attn_dual(q, k1, vt1, k2, vt2, out, *, n_groups, heads, nq, nk1, kv_rows1, kv_div1, ldk1, ldvt1, nk2, kv_rows2, kv_div2,
+                    ldk2, ldvt2, ldq, ldo, scale, log2_logits=False):
+    """softmax(scale Q K1^T) V1 + softmax(scale Q K2^T) V2 in one pass over Q and O (text (+) image cross-attention)."""
+    check(lib().vcx_attn_flash_dual_d64_f16(q.data_ptr(), k1.data_ptr(), vt1.data_ptr(), k2.data_ptr(), vt2.data_ptr(),
+                                            out.data_ptr(), n_groups, heads, nq, nk1, kv_rows1, kv_div1, ldk1, ldvt1, nk2,
+                                            kv_rows2, kv_div2, ldk2, ldvt2, ldq, ldo, scale,
+                                            ATTN_LOG2_LOGITS if log2_logits else 0, _stream()), "attn_flash_dual_d64")
+    return out
+
+
 def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale):
     check(lib().vcx_attn_temporal_d64_f16(qkv.data_ptr(), out.data_ptr(), B, T, P, heads, ld, k_off, v_off, ldo, scale,
                                           _stream()), "attn_temporal_d64")
