@@ -316,6 +316,210 @@ __global__ void __launch_bounds__(256, 2) flash_d64_kernel(FlashArgs p) {
 }
 
 // =======================================================================================
+// Text (+) image cross-attention with the keys and values RESIDENT in LDS.
+// Both key sets of a (frame group, head) unit - 77 text keys and 256 image tokens shared by all frames of a video - are
+// 6 tiles of 64 keys = 96 KB of K and V^T: a block of 8 waves loads them once and then streams over its share of the
+// unit's queries (all frames x pixels), every wave on its own, with no barrier and no DMA in the loop.  The per-tile DMA +
+// barrier pipeline of flash_d64_kernel costs more than the arithmetic when a query block only meets six key tiles.
+// =======================================================================================
+struct XAttnArgs {
+    const half_t* q;
+    half_t* o;
+    const half_t* k1;
+    const half_t* vt1;
+    const half_t* k2;
+    const half_t* vt2;
+    int heads, nk1, nk2, kv_rows1, kv_rows2, split, nunits;
+    int64_t ldq, ldo, ldk1, ldvt1, ldk2, ldvt2;
+    int64_t rows_per_unit, rows_per_block;      // queries of one (group, head) unit = frames * nq; a block's share (x 512)
+    float scale_log2;
+};
+
+__global__ void __launch_bounds__(512, 1) xattn_resident_d64_kernel(XAttnArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int T1 = 2, T2 = 4, NT = T1 + T2;              // key tiles: text (<= 128 keys), image (<= 256 keys)
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsmem[];
+    half_t* sK = reinterpret_cast<half_t*>(xsmem);           // [NT][64 keys][64] swizzled
+    half_t* sV = sK + NT * 64 * 64;                          // [NT][64 d][64 keys] swizzled
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int unit = blockIdx.x / p.split, part = blockIdx.x % p.split;
+    const int gb = unit / p.heads, h = unit % p.heads;
+
+    // ---- K / V^T of both sets -> LDS (8 rows per DMA instruction, 16 instructions per tile, spread over the 8 waves)
+    {
+        const int srow8 = lane >> 3, spos = lane & 7;
+        for (int idx = wave; idx < NT * 16; idx += 8) {
+            const int t = idx >> 4, j = idx & 15;
+            const bool second = t >= T1;
+            const int kt = second ? t - T1 : t;
+            const int nk = second ? p.nk2 : p.nk1;
+            const int64_t ldk = second ? p.ldk2 : p.ldk1, ldvt = second ? p.ldvt2 : p.ldvt1;
+            const int64_t kvrow0 = (int64_t)gb * (second ? p.kv_rows2 : p.kv_rows1);
+            const half_t* kbase = (second ? p.k2 : p.k1) + kvrow0 * ldk + h * 64;
+            const half_t* vbase = (second ? p.vt2 : p.vt1) + (int64_t)(h * 64) * ldvt + kvrow0;
+            const int r = (j & 7) * 8 + srow8;                 // row inside the tile: key (K part) or d (V^T part)
+            const int csrc = spos ^ ((r >> 1) & 7);
+            if (j < 8) {
+                const unsigned bytes = (unsigned)(((int64_t)(nk - 1) * ldk + 64) * 2);
+                const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kbase), 0, (int)bytes, 0x00020000);
+                const int key = kt * 64 + r;
+                const unsigned v = key < nk ? (unsigned)((int64_t)key * ldk * 2) + csrc * 16 : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(sK + t * 4096 + (j & 7) * 512), 16, v, 0, 0, 0);
+            } else {
+                const unsigned bytes = (unsigned)((63ll * ldvt + ((nk + 7) & ~7)) * 2);
+                const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vbase), 0, (int)bytes, 0x00020000);
+                const int key0 = kt * 64 + csrc * 8;
+                const unsigned v = key0 < nk ? (unsigned)((int64_t)r * ldvt * 2) + (unsigned)(kt * 128) + csrc * 16 : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(sV + t * 4096 + (j & 7) * 512), 16, v, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
+
+    const int64_t row_begin = (int64_t)part * p.rows_per_block;
+    const int64_t row_end = row_begin + p.rows_per_block < p.rows_per_unit ? row_begin + p.rows_per_block : p.rows_per_unit;
+    const half_t* qbase = p.q + ((int64_t)gb * p.rows_per_unit) * p.ldq + h * 64;
+    half_t* obase = p.o + ((int64_t)gb * p.rows_per_unit) * p.ldo + h * 64;
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    typedef half_t h16v __attribute__((ext_vector_type(16)));
+
+    for (int64_t r0 = row_begin + wave * 64; r0 < row_end; r0 += 512) {       // this wave's two 32-row query blocks
+        h8 qf[2][4];
+        bool qvalid[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t qrow = r0 + b * 32 + lq;
+            qvalid[b] = qrow < row_end;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                qf[b][s] = qvalid[b] ? *reinterpret_cast<const h8*>(qbase + qrow * p.ldq + s * 16 + hi * 8) : zero8;
+        }
+        h16v keep[2][2];
+#pragma unroll 1
+        for (int set = 0; set < 2; ++set) {
+            const int t0 = set ? T1 : 0, nt = set ? T2 : T1, nk = set ? p.nk2 : p.nk1;
+            f16v oacc[2][2];
+            float m_run[2], l_run[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                m_run[b] = -1e30f;
+                l_run[b] = 0.f;
+                oacc[b][0] = zero16;
+                oacc[b][1] = zero16;
+            }
+#pragma unroll 1
+            for (int kt = 0; kt < nt; ++kt) {
+                if (kt * 64 >= nk) break;
+                const half_t* cK = sK + (t0 + kt) * 4096;
+                const half_t* cV = sV + (t0 + kt) * 4096;
+                f16v sacc[2][2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const h8 kf = *reinterpret_cast<const h8*>(cK + tile_off(kb * 32 + lq, s * 2 + hi));
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            sacc[b][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[b][s], s == 0 ? zero16 : sacc[b][kb], 0, 0, 0);
+                    }
+                const int key_base = kt * 64;
+                if (key_base + 64 > nk) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                if (key >= nk) sacc[b][kb][r] = -1e30f;
+                            }
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float mx = -1e30f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][kb][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const float cand = mx * p.scale_log2;
+                    if (__builtin_amdgcn_ballot_w64(cand > m_run[b] + FLASH_DEFER) != 0) {     // deferred max, as in flash_d64_kernel
+                        const float m_new = fmaxf(m_run[b], cand);
+                        const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+                        m_run[b] = m_new;
+                        l_run[b] *= alpha;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { oacc[b][0][i] *= alpha; oacc[b][1][i] *= alpha; }
+                    }
+                    const float m_use = m_run[b];
+                    float psum = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][kb][r], p.scale_log2, -m_use));
+                            sacc[b][kb][r] = pv;
+                            psum += pv;
+                        }
+                    l_run[b] += psum;
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        h8 pf[2];
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) pf[b][j] = (half_t)sacc[b][kb][8 * s + j];
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const int row = db * 32 + lq;
+                            const int c0 = kb * 4 + 2 * s;
+                            const h4 lo = *reinterpret_cast<const h4*>(cV + tile_off(row, c0) + 4 * hi);
+                            const h4 hi4 = *reinterpret_cast<const h4*>(cV + tile_off(row, c0 + 1) + 4 * hi);
+                            const h8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) oacc[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[b], oacc[b][db], 0, 0, 0);
+                        }
+                    }
+            }
+            // ---- normalise; keep the first set's result, add and store after the second
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32);
+                const float inv = 1.0f / l_tot;
+                if (set == 0) {
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) keep[b][db][i] = (half_t)(oacc[b][db][i] * inv);
+                } else if (qvalid[b]) {
+                    half_t* orow = obase + (r0 + b * 32 + lq) * p.ldo;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int d0 = db * 32 + 8 * gq + 4 * hi;
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = oacc[b][db][gq * 4 + r] * inv + (float)keep[b][db][gq * 4 + r];
+                            *reinterpret_cast<h4*>(orow + d0) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        }
+                }
+            }
+        }
+    }
+#endif
+}
+
+// =======================================================================================
 // Temporal attention: T <= 32 frames, d = 64.
 // =======================================================================================
 struct TAttnArgs {
@@ -543,6 +747,42 @@ extern "C" int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const 
     hipStream_t s = (hipStream_t)stream;
     const double nprob = (double)n_groups * heads;
     VcxProfScope prof(VCX_FAM_FLASH, s, 4.0 * nprob * nq * (double)(nk1 + nk2) * 64, 2.0 * nprob * 64 * (2.0 * nq + 2.0 * (nk1 + nk2)));
+    // Both key sets shared by the same frame groups and small enough for LDS: the resident-K/V kernel (no per-tile pipeline)
+    static const bool resident_on = []() { const char* e = getenv("VCX_XATTN_RESIDENT"); return !(e && e[0] == '0'); }();
+    if (resident_on && kv_div1 == kv_div2 && n_groups % kv_div1 == 0 && nk1 <= 128 && nk2 <= 256) {
+        XAttnArgs x;
+        x.q = (const half_t*)q; x.o = (half_t*)o;
+        x.k1 = (const half_t*)k1; x.vt1 = (const half_t*)vt1; x.k2 = (const half_t*)k2; x.vt2 = (const half_t*)vt2;
+        x.heads = heads; x.nk1 = nk1; x.nk2 = nk2; x.kv_rows1 = kv_rows1; x.kv_rows2 = kv_rows2;
+        x.ldq = ldq; x.ldo = ldo; x.ldk1 = ldk1; x.ldvt1 = ldvt1; x.ldk2 = ldk2; x.ldvt2 = ldvt2;
+        x.scale_log2 = (flags & VCX_ATTN_LOG2_LOGITS) ? 1.0f : scale * 1.4426950408889634f;
+        x.nunits = (n_groups / kv_div1) * heads;
+        x.rows_per_unit = (int64_t)kv_div1 * nq;
+        static const int cus = []() {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                return prop.multiProcessorCount;
+            return 256;
+        }();
+        int split = cus / x.nunits;
+        if (split < 1) split = 1;
+        const int64_t iters = (x.rows_per_unit + 511) / 512;
+        if (split > iters) split = (int)iters;
+        x.rows_per_block = ((iters + split - 1) / split) * 512;
+        x.split = (int)((x.rows_per_unit + x.rows_per_block - 1) / x.rows_per_block);
+        constexpr int XSMEM = 6 * 64 * 64 * 2 * 2;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_resident_d64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XSMEM) != hipSuccess) {
+                vcx_set_error("vcx_attn_flash_dual_d64_f16: cannot reserve %d bytes of LDS", XSMEM);
+                return VCX_ELAUNCH;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(xattn_resident_d64_kernel, dim3(x.nunits * x.split), dim3(512), XSMEM, s, x);
+        return vcx_check_launch("vcx_attn_flash_dual_d64_f16(resident)");
+    }
     // two query blocks per wave (half the LDS fragment traffic per MFMA) unless that wastes > 20 % of the 256-row blocks; with
     // two blocks the kept first result is packed fp16 and the running-max-in-C variant is not used (register budget)
     static const int force_qb = []() { const char* e = getenv("VCX_FLASH_QB"); return e ? atoi(e) : 0; }();
