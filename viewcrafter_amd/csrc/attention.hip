@@ -419,8 +419,15 @@ __global__ void __launch_bounds__(512, 1) xattn_resident_d64_kernel(XAttnArgs p)
                 const half_t* cK = sK + (t0 + kt) * 4096;
                 const half_t* cV = sV + (t0 + kt) * 4096;
                 f16v sacc[2][2];
+                const int key_base = kt * 64;
+                const bool half2 = key_base + 32 < nk;           // wave-uniform: the tile's second 32 keys hold a valid key
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (kb == 1 && !half2) {                     // e.g. 77 text keys: keys 96..127 do not exist
+                        sacc[0][1] = zero16;
+                        sacc[1][1] = zero16;
+                        break;
+                    }
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const h8 kf = *reinterpret_cast<const h8*>(cK + tile_off(kb * 32 + lq, s * 2 + hi));
@@ -428,7 +435,7 @@ __global__ void __launch_bounds__(512, 1) xattn_resident_d64_kernel(XAttnArgs p)
                         for (int b = 0; b < 2; ++b)
                             sacc[b][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[b][s], s == 0 ? zero16 : sacc[b][kb], 0, 0, 0);
                     }
-                const int key_base = kt * 64;
+                }
                 if (key_base + 64 > nk) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
@@ -470,7 +477,8 @@ __global__ void __launch_bounds__(512, 1) xattn_resident_d64_kernel(XAttnArgs p)
                     l_run[b] += psum;
                 }
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (kb == 1 && !half2) break;                // all-zero probabilities: nothing to add
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         h8 pf[2];
@@ -489,6 +497,7 @@ __global__ void __launch_bounds__(512, 1) xattn_resident_d64_kernel(XAttnArgs p)
                             for (int b = 0; b < 2; ++b) oacc[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[b], oacc[b][db], 0, 0, 0);
                         }
                     }
+                }
             }
             // ---- normalise; keep the first set's result, add and store after the second
 #pragma unroll
