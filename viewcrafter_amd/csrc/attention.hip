@@ -546,13 +546,13 @@ struct TAttnArgs {
 // cross-lane movement.  Q and K fragments are read straight from global memory (a frame row of one head is one
 // 128-byte line); V goes through a wave-private LDS patch [32][72] from which the V^T fragments are gathered with
 // 16-bit reads (rows >= T zero-filled).  Traffic is the algorithmic minimum (q, k, v read once, o written once).
-__global__ void __launch_bounds__(256) tattn_d64_kernel(TAttnArgs p) {
+__global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
     constexpr int VLD = 72;                                           // LDS row pitch (halfs): 144 B keeps 16-B alignment
-    __shared__ __attribute__((aligned(16))) half_t sVt[4][32 * VLD];
+    __shared__ __attribute__((aligned(16))) half_t sVt[8][32 * VLD];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int lq = lane & 31, hi = lane >> 5;
-    const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t pair = (int64_t)blockIdx.x * 8 + wave;
     if (pair >= p.npairs) return;                                     // wave-uniform; no block-level sync below
     const int h = (int)(pair % p.heads);
     const int64_t pix = (pair / p.heads) % p.P;
@@ -827,9 +827,9 @@ extern "C" int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T,
     a.npairs = (int64_t)B * P * heads;
     hipStream_t s = (hipStream_t)stream;
     VcxProfScope prof(VCX_FAM_TATTN, s, 4.0 * a.npairs * (double)T * T * 64, 2.0 * a.npairs * T * 64 * 4.0);
-    const int64_t nblk = (a.npairs + 3) / 4;
+    const int64_t nblk = (a.npairs + 7) / 8;
     VCX_REQUIRE(nblk < (1ll << 31), "vcx_attn_temporal_d64_f16: grid too large");
-    hipLaunchKernelGGL(tattn_d64_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(tattn_d64_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
     return vcx_check_launch("vcx_attn_temporal_d64_f16");
 }
 
