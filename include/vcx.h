@@ -99,8 +99,9 @@ int vcx_gemm_f16(const vcx_gemm_desc* desc_host, void* stream);
  *   per-video   TemporalConvBlock GN openaimodel3d.py:256-266, TemporalTransformer.norm
  *               attention.py:331   (statistics span T*H*W)
  * x is [n_outer][pixels][C]; statistics are taken over (pixels, C/groups) per (n, group).
- * stats: fp32 [n_outer][groups][2] = (sum, sum of squares); written by _stats, which reduces
- * deterministically (fixed summation order, no atomics) through the caller's workspace `ws` of
+ * stats: fp32 [n_outer][groups][2] = (mean, biased variance); written by _stats, which reduces
+ * Welford/Chan-style ((count, mean, M2) partials merged in a fixed order: robust to |mean| >> std
+ * like torch's GroupNorm, deterministic, no atomics) through the caller's workspace `ws` of
  * vcx_groupnorm_ws_bytes() bytes; consumed by _apply which computes
  *   y = (x - mean) * rsqrt(var + eps) * gamma[c] + beta[c], then x*sigmoid(x) if silu.
  * ---------------------------------------------------------------------------------- */

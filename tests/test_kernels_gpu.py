@@ -228,6 +228,21 @@ def test_groupnorm(n, pix, C, silu, eps):
     check(out, ref.permute(0, 2, 1), name="groupnorm")
 
 
+@pytest.mark.parametrize("n,pix,C,offset,std", [(2, 9216, 320, 100.0, 0.1), (1, 5000, 640, -300.0, 0.25), (1, 230400, 320, 60.0, 0.05)])
+def test_groupnorm_large_common_offset(n, pix, C, offset, std):
+    """|mean| >> std (what real checkpoints produce in the VAE decoder and the deep UNet levels): a one-pass
+    E[x^2] - mean^2 in fp32 cancels catastrophically here; the kernel's shifted sums + Chan merges must not.
+    The reference is torch's (Welford) group_norm on the same fp16-rounded input in fp64."""
+    from viewcrafter_amd import ops
+    x = (offset + std * rnd(n, pix, C, seed=46)).to(DEV).half()
+    g = (1 + 0.2 * rnd(C, seed=47)).to(DEV)
+    b = (0.1 * rnd(C, seed=48)).to(DEV)
+    out = ops.group_norm(x, g, b, 1e-5, False)
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, g.double(), b.double(), 1e-5).permute(0, 2, 1)
+    # fp16 spacing at |x| ~ 100 is 0.06 ~ std, so the INPUT is coarse; given that input the normalised output must still match
+    check(out, ref.float(), tol=3e-3, name="groupnorm offset")
+
+
 @pytest.mark.parametrize("rows,C", [(10, 64), (1001, 320), (333, 1280), (5, 512)])
 def test_layernorm(rows, C):
     from viewcrafter_amd import ops
@@ -397,7 +412,10 @@ def test_flash_cross_attention_text_plus_image(T, shared):
     check(out, ref, tol=3e-3, name="cross-attn")
 
 
-@pytest.mark.parametrize("T,shared,nq,log2", [(5, True, 144, True), (4, False, 144, False), (3, True, 1000, True), (2, False, 77, True)])
+# (shared=True -> xattn_resident_d64_kernel, shared=False -> the flash-pipeline DUAL kernel); log2=False drives the
+# scale_log2 != 1 branch of both (the product always folds the scale into the Q projection, log2=True)
+@pytest.mark.parametrize("T,shared,nq,log2", [(5, True, 144, True), (4, False, 144, False), (3, True, 1000, True), (2, False, 77, True),
+                                              (3, True, 576, False), (2, True, 200, False)])
 def test_flash_dual_text_plus_image(T, shared, nq, log2):
     """vcx_attn_flash_dual_d64_f16: softmax(QK_txt)V_txt + softmax(QK_img)V_img in one pass (77 text keys padded to 80 rows,
     256 shared or 16 per-frame image keys), against the two separate softmaxes in fp32."""

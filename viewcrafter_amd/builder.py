@@ -63,4 +63,7 @@ def randomize_parameters(model, seed=0, std_scale=1.0):
             p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=p.device))
         else:
             p.copy_(0.05 * torch.randn(p.shape, generator=g, device=p.device))
+    for m in model.modules():           # in-place copies do not invalidate the packed fp16 weights by themselves
+        if hasattr(m, "_drop_packed"):
+            m._drop_packed()
     return model

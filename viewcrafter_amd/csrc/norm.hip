@@ -11,11 +11,23 @@ constexpr int MAXC = 4096;  // C/8 * pixel lanes must fit one block (<= 512 thre
 // blockDim = CW * PL, so a wave reads whole pixel rows back to back, the per-channel constants (8 partial sums /
 // 8 scale+shift pairs) live in registers, and the pixel loop is 4-way unrolled to keep four 16-byte loads in flight.
 // ---------------------------------------------------------------------------------------
+// Chan/Welford merge of two (count, mean, M2) triples in a fixed order: b is folded into a.
+__device__ __forceinline__ void gn_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+    if (nb == 0.f) return;
+    if (na == 0.f) { na = nb; ma = mb; qa = qb; return; }
+    const float n = na + nb, d = mb - ma, f = nb / n;
+    ma = ma + d * f;
+    qa = qa + qb + d * d * na * f;
+    na = n;
+}
+
 __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ partials, int64_t pixels, int C, int groups,
                                 int64_t pix_per_block, int cw, int pl) {
-    // Deterministic reduction (no atomics): per-thread channel sums -> LDS -> fixed-order sum over the pixel lanes ->
-    // fixed-order sum over a group's channels -> partials[n][chunk][group][2]; gn_finalize_kernel adds the chunks in order.
-    extern __shared__ float red[];                      // [pl][C][2] then reused as [C][2]
+    // Numerically robust and deterministic (no atomics).  A thread sums x - K and (x - K)^2 with K = the first value it sees
+    // (so |mean| >> std does not cancel: torch's GroupNorm is Welford too), turns that into (count, mean, M2) and from
+    // there everything is merged Chan-style in a fixed order: pixel lanes -> a group's channels -> partials[n][chunk]
+    // [group][3]; gn_finalize_kernel merges the chunks in order.
+    extern __shared__ float red[];                      // [pl][C][2] (mean, M2) + [pl] counts
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
@@ -23,11 +35,18 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
     const int cpg = C / groups;
     const int c8 = tid % cw, plane = tid / cw;
     const half_t* xp = x + ((int64_t)n * pixels) * C + c8 * 8;
-    float s[8], ss[8];
+    float* cnts = red + (size_t)pl * C * 2;
+    float s[8], ss[8], K[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; K[e] = 0.f; }
     int64_t pix = p0 + plane;
     const int64_t step = pl;
+    const int64_t mine = pix < p1 ? (p1 - pix + step - 1) / step : 0;       // pixels this thread owns
+    if (mine > 0) {
+        const h8 v = *reinterpret_cast<const h8*>(xp + pix * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) K[e] = (float)v[e];
+    }
     for (; pix + 3 * step < p1; pix += 4 * step) {
         h8 v[4];
 #pragma unroll
@@ -36,7 +55,7 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = (float)v[u][e];
+                const float f = (float)v[u][e] - K[e];
                 s[e] += f;
                 ss[e] += f * f;
             }
@@ -45,55 +64,60 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
         const h8 v = *reinterpret_cast<const h8*>(xp + pix * C);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float f = (float)v[e];
+            const float f = (float)v[e] - K[e];
             s[e] += f;
             ss[e] += f * f;
         }
     }
+    const float cnt = (float)mine, inv = mine > 0 ? 1.0f / cnt : 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        red[((size_t)plane * C + c8 * 8 + e) * 2 + 0] = s[e];
-        red[((size_t)plane * C + c8 * 8 + e) * 2 + 1] = ss[e];
+        const float m = s[e] * inv;
+        red[((size_t)plane * C + c8 * 8 + e) * 2 + 0] = K[e] + m;
+        const float q = ss[e] - s[e] * m;
+        red[((size_t)plane * C + c8 * 8 + e) * 2 + 1] = q > 0.f ? q : 0.f;
     }
+    if (c8 == 0) cnts[plane] = cnt;
     __syncthreads();
     for (int c = tid; c < C; c += blockDim.x) {          // pixel lanes, in order
-        float a = red[(size_t)c * 2], q = red[(size_t)c * 2 + 1];
-        for (int p = 1; p < pl; ++p) {
-            a += red[((size_t)p * C + c) * 2];
-            q += red[((size_t)p * C + c) * 2 + 1];
-        }
+        float na = cnts[0], a = red[(size_t)c * 2], q = red[(size_t)c * 2 + 1];
+        for (int p = 1; p < pl; ++p) gn_merge(na, a, q, cnts[p], red[((size_t)p * C + c) * 2], red[((size_t)p * C + c) * 2 + 1]);
         red[(size_t)c * 2] = a;
         red[(size_t)c * 2 + 1] = q;
     }
     __syncthreads();
-    if (tid < groups) {                                   // channels of the group, in order
-        float a = 0.f, q = 0.f;
-        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-            a += red[(size_t)c * 2];
-            q += red[(size_t)c * 2 + 1];
-        }
-        float* dst = partials + (((int64_t)n * gridDim.x + blockIdx.x) * groups + tid) * 2;
-        dst[0] = a;
-        dst[1] = q;
+    if (tid < groups) {                                   // channels of the group, in order (equal counts)
+        const float nc = (float)(p1 - p0);
+        float na = 0.f, a = 0.f, q = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) gn_merge(na, a, q, nc, red[(size_t)c * 2], red[(size_t)c * 2 + 1]);
+        float* dst = partials + (((int64_t)n * gridDim.x + blockIdx.x) * groups + tid) * 3;
+        dst[0] = na;
+        dst[1] = a;
+        dst[2] = q;
     }
 }
 
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int chunks,
                                                           int groups) {
-    // fixed summation tree: wave q adds the chunks c = q, q+4, q+8, ... in order, then the four wave sums are added in order
-    __shared__ float red[4][128];
-    const int n = blockIdx.x, q = threadIdx.x >> 6, j = threadIdx.x & 63;   // j indexes (group, sum|sumsq) in steps of 64
-    for (int jj = j; jj < groups * 2; jj += 64) {
-        const float* src = partials + (int64_t)n * chunks * groups * 2 + jj;
-        float a = 0.f;
-#pragma unroll 8
-        for (int c = q; c < chunks; c += 4) a += src[(int64_t)c * groups * 2];
-        red[q][jj] = a;
+    // fixed merge tree: wave q folds the chunks c = q, q+4, q+8, ... in order, then the four wave results are folded in order.
+    // stats[n][g] = (mean, biased variance).
+    __shared__ float red[4][64][3];
+    const int n = blockIdx.x, q = threadIdx.x >> 6, g = threadIdx.x & 63;
+    if (g < groups) {
+        const float* src = partials + ((int64_t)n * chunks * groups + g) * 3;
+        float na = 0.f, a = 0.f, m2 = 0.f;
+        for (int c = q; c < chunks; c += 4) {
+            const float* t = src + (int64_t)c * groups * 3;
+            gn_merge(na, a, m2, t[0], t[1], t[2]);
+        }
+        red[q][g][0] = na; red[q][g][1] = a; red[q][g][2] = m2;
     }
     __syncthreads();
-    if (threadIdx.x < groups * 2) {
-        const int jj = threadIdx.x;
-        stats[(int64_t)n * groups * 2 + jj] = ((red[0][jj] + red[1][jj]) + red[2][jj]) + red[3][jj];
+    if (threadIdx.x < groups) {
+        float na = red[0][g][0], a = red[0][g][1], m2 = red[0][g][2];
+        for (int w = 1; w < 4; ++w) gn_merge(na, a, m2, red[w][g][0], red[w][g][1], red[w][g][2]);
+        stats[((int64_t)n * groups + g) * 2 + 0] = a;
+        stats[((int64_t)n * groups + g) * 2 + 1] = na > 0.f ? m2 / na : 0.f;
     }
 }
 
@@ -103,21 +127,16 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int cpg = C / groups;
-    const float cnt = (float)((double)pixels * cpg);
     const int c8 = tid % cw, plane = tid / cw;
-    float sc[8], sh[8];
+    float sc[8], sh[8], mu[8];      // (x - mean) * sc + beta: subtracting first keeps |mean| >> std exact
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = c8 * 8 + e;
         const int g = c / cpg;
-        const float su = stats[((int64_t)n * groups + g) * 2 + 0];
-        const float sq = stats[((int64_t)n * groups + g) * 2 + 1];
-        const float mean = su / cnt;
-        float var = sq / cnt - mean * mean;
-        var = var > 0.f ? var : 0.f;
-        const float a = rsqrtf(var + eps) * gamma[c];
-        sc[e] = a;
-        sh[e] = beta[c] - mean * a;
+        mu[e] = stats[((int64_t)n * groups + g) * 2 + 0];
+        const float var = stats[((int64_t)n * groups + g) * 2 + 1];
+        sc[e] = rsqrtf(var + eps) * gamma[c];
+        sh[e] = beta[c];
     }
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = (p0 + pix_per_block < pixels) ? p0 + pix_per_block : pixels;
@@ -133,7 +152,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float f = (float)v[u][e] * sc[e] + sh[e];
+                float f = ((float)v[u][e] - mu[e]) * sc[e] + sh[e];
                 if (silu) f = vcx_silu(f);
                 v[u][e] = (half_t)f;
             }
@@ -144,7 +163,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
         h8 v = *reinterpret_cast<const h8*>(xp + pix * C);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = (float)v[e] * sc[e] + sh[e];
+            float f = ((float)v[e] - mu[e]) * sc[e] + sh[e];
             if (silu) f = vcx_silu(f);
             v[e] = (half_t)f;
         }
@@ -243,7 +262,7 @@ extern "C" size_t vcx_groupnorm_ws_bytes(int n_outer, int64_t pixels, int groups
     if (n_outer <= 0 || pixels <= 0 || groups <= 0) return 0;
     const int64_t ppb = pick_pix_per_block(n_outer, pixels);
     const int64_t chunks = (pixels + ppb - 1) / ppb;
-    return sizeof(float) * 2 * (size_t)n_outer * (size_t)chunks * (size_t)groups;
+    return sizeof(float) * 3 * (size_t)n_outer * (size_t)chunks * (size_t)groups;
 }
 
 extern "C" int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, int n_outer, int64_t pixels, int C, int groups,
@@ -260,7 +279,7 @@ extern "C" int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, in
     dim3 grid((unsigned)chunks, n_outer);
     int cw, pl;
     gn_geometry(C, cw, pl);
-    const size_t smem = sizeof(float) * 2 * (size_t)pl * C;
+    const size_t smem = sizeof(float) * (2 * (size_t)pl * C + pl);
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(cw * pl), smem, s, (const half_t*)x, (float*)ws, pixels, C, groups, ppb, cw, pl);
     int rc = vcx_check_launch("vcx_groupnorm_stats_f16");
     if (rc) return rc;

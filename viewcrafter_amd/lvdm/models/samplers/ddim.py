@@ -23,6 +23,7 @@ class DDIMSampler(object):
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
         self.counter = 0
+        self._cfg_cache = None          # p_sample_ddim is public (decode() and bench.py call it without ddim_sampling)
 
     def register_buffer(self, name, attr):
         if isinstance(attr, torch.Tensor):
@@ -194,9 +195,10 @@ class DDIMSampler(object):
         if self.model.parameterization != "v":
             # eps-parameterisation reads the DDIM tables instead (ddim.py:259-260)
             coef[0], coef[1] = float(np.sqrt(h["a"][index])), float(np.sqrt(1. - h["a"][index]))
-        noise = None
-        if sigma != 0.0:
-            noise = noise_like(x.shape, device, repeat_noise) * temperature
+        # the reference draws the noise unconditionally (ddim.py:275), also when sigma_t = 0 (eta = 0): draw it too, so that a
+        # fixed seed leaves the generator in the same state (the x_T of a following sample() call); the kernel skips it
+        noise = noise_like(x.shape, device, repeat_noise)
+        noise = noise * temperature if sigma != 0.0 else None
         x_prev, pred_x0 = ops.ddim_step(x, v_c.contiguous(), v_u.contiguous() if v_u is not None else None, noise, coef,
                                         v_img=v_i.contiguous() if v_i is not None else None, cfg_img=cfg_img)
         return x_prev, pred_x0

@@ -68,6 +68,9 @@ class CrossAttention(PackedModule):
             raise NotImplementedError("image_cross_attention_scale_learnable is not used by the ViewCrafter configs")
         if dim_head != 64:
             raise NotImplementedError(f"libvcx attention kernels are built for head dim 64 (got {dim_head})")
+        if image_cross_attention and image_cross_attention_scale != 1.0:
+            raise NotImplementedError("image_cross_attention_scale != 1.0 (the dual-softmax kernel sums the two outputs unweighted; "
+                                      "the ViewCrafter configs keep the constant 1.0, attention.py:62)")
         inner_dim = dim_head * heads
         self.is_self = context_dim is None
         context_dim = default(context_dim, query_dim)
@@ -160,7 +163,7 @@ class BasicTransformerBlock(PackedModule):
 class ContextKV:
     """Projected cross-attention keys/values of one SpatialTransformer block for one conditioning tensor.  They depend
     only on the context, i.e. they are constant over all DDIM steps and are cached by UNetModel."""
-    __slots__ = ("k_txt", "vt_txt", "k_img", "vt_img", "n_txt_rows", "n_img", "img_per_frame")
+    __slots__ = ("k_txt", "vt_txt", "k_img", "vt_img", "n_txt_rows", "n_txt", "n_img", "img_per_frame")
 
 
 def project_context(attn2, ctx):
@@ -173,6 +176,7 @@ def project_context(attn2, ctx):
     kv.k_txt = ops.linear(txt, pk["wk"])                                        # [B*80, C]
     kv.vt_txt = ops.gemm(pk["wv"], txt, M=C, N=txt.shape[0], K=D, lda=D)        # [C, B*80]  (V^T for the flash kernel)
     kv.n_txt_rows = txt.shape[0]
+    kv.n_txt = int(ctx.get("n_txt", attn2.text_context_len))      # real text tokens (a context shorter than 77 is zero-padded to 80 rows)
     kv.k_img = kv.vt_img = None
     kv.n_img, kv.img_per_frame = ctx.get("n_img", 0), ctx.get("per_frame", False)
     if attn2.image_cross_attention and ctx.get("img") is not None:
@@ -247,11 +251,11 @@ class SpatialTransformer(PackedModule):
             nb = kv.n_txt_rows // 80
             if kv.k_img is not None:     # text (+) image in one pass over q2 / o2
                 ops.flash_attn_dual(q2, kv.k_txt, kv.vt_txt, kv.k_img, kv.vt_img, o2, n_groups=n, heads=heads, nq=N,
-                                    nk1=blk.attn2.text_context_len, kv_rows1=80, kv_div1=frames_per_video, ldk1=D, ldvt1=nb * 80,
+                                    nk1=kv.n_txt, kv_rows1=80, kv_div1=frames_per_video, ldk1=D, ldvt1=nb * 80,
                                     nk2=kv.n_img, kv_rows2=kv.n_img, kv_div2=1 if kv.img_per_frame else frames_per_video,
                                     ldk2=D, ldvt2=kv.vt_img.shape[1], ldq=D, ldo=D, scale=blk.attn2.scale, log2_logits=True)
             else:
-                ops.flash_attn(q2, kv.k_txt, kv.vt_txt, o2, n_groups=n, heads=heads, nq=N, nk=blk.attn2.text_context_len,
+                ops.flash_attn(q2, kv.k_txt, kv.vt_txt, o2, n_groups=n, heads=heads, nq=N, nk=kv.n_txt,
                                kv_rows=80, kv_div=frames_per_video, ldq=D, ldk=D, ldvt=nb * 80, ldo=D, scale=blk.attn2.scale,
                                log2_logits=True)
             t = ops.linear(o2, a2["wo"], a2["bo"], residual=t)

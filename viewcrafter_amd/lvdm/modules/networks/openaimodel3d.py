@@ -324,6 +324,7 @@ class UNetModel(PackedModule):
                 if n_img % 8 != 0:
                     raise ValueError(f"image context length {n_img} must be a multiple of 8")
                 ctx.update(img=ctx16[:, 77:].reshape(b * n_img, D).contiguous(), n_img=n_img, per_frame=False)
+        ctx["n_txt"] = ntxt
         kv = {id(st): st.project_context(ctx) for st in self.spatial_transformers()}
         if len(self._ctx_cache) >= 4:
             self._ctx_cache.clear()
@@ -371,8 +372,10 @@ class UNetModel(PackedModule):
                     out = self._forward(static["parts"], static["t"], context=context, fs=static["fs"])
             if len(self._graphs) >= 4:
                 self._graphs.clear()
-            ent = self._graphs[key] = (graph, static, out, context)
-        graph, static, out, _ = ent
+            # the captured launches bake in the addresses of the projected context K/V (allocated by the warm-up in the
+            # ordinary caching allocator): the entry owns them, so clearing _ctx_cache cannot free what a replay reads
+            ent = self._graphs[key] = (graph, static, out, context, self._context_kv(context, static["parts"][0].shape[2]))
+        graph, static, out = ent[:3]
         for dst, src in zip(static["parts"], parts):
             dst.copy_(src)
         static["t"].copy_(timesteps)

@@ -68,10 +68,16 @@ def broadcast_module_(module, src=0, bucket_bytes=256 << 20):
                 b.copy_(flat[off:off + b.numel()].view_as(b))
                 off += b.numel()
             bucket, size = ([t], t.numel() * t.element_size()) if t is not None else ([], 0)
-    if hasattr(module, "_drop_packed"):
-        for m in module.modules():
-            if hasattr(m, "_drop_packed"):
-                m._drop_packed()
+    drop_packed_copies(module)
+    return module
+
+
+def drop_packed_copies(module):
+    """Parameters were overwritten in place: every PackedModule below `module` (the root usually is a plain nn.Module)
+    must forget its kernel-layout fp16 copies, and the UNet its cached context K/V and captured graphs."""
+    for m in module.modules():
+        if hasattr(m, "_drop_packed"):
+            m._drop_packed()
     return module
 
 
