@@ -9,9 +9,13 @@ x_{t-1} update, eta = 1 (fresh noise every step), fp16 storage with fp32 accumul
 checkpoints offline), data is synthetic of the real shapes; inputs are resident in HBM before the timed region.
 
 Printed JSON (rank 0): the driver contract + `roofline` (dominant kernel = the MFMA GEMM/conv engine, measured with HIP
-events on the launch stream over the timed region) + `cpu_baseline` (the fp32 oracle = a port of the reference's
-algorithm, timed on the host cores on a bounded sample of the same workload and FLOP-scaled) + extras
-(`sec_per_video_est` = 50 steps + 25-frame VAE decode, per-family kernel time).
+events on the launch stream over the timed region) + `roofline_flash` (second family, same method) + `cpu_baseline` (the
+fp32 oracle = a port of the reference's algorithm, timed on the host cores at BASELINE configs[0]'s shapes 16x40x64 and
+FLOP-scaled) + `gpu_eager_baseline` (the same oracle graph as plain PyTorch-ROCm eager ops under fp16 autocast on this
+MI355X: what the hand-written kernels buy over the libraries) + `parity` (HIP path vs the fp32 oracle run on the GPU at the
+bench's own latent) + `sec_per_video` (a real 50-step sample() + 25-frame decode after the timed region, N = 1).
+N > 1: rank 0 initialises the weights, the others receive them by RCCL broadcast (`broadcast_s`), all ranks assert equal
+checksums, and the decoded clips are gathered on rank 0 (`gather_s`) - both outside the timed region.
 """
 import argparse
 import json
@@ -34,6 +38,16 @@ WORKLOADS = {
 }
 
 
+def csrc_hash():
+    """sha256 over the GEMM kernel sources: profiles/pmc_traffic.json records the hash it was measured on."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for name in ("gemm_dma.hip", "gemm.hip", "gemm_args.h"):
+        with open(os.path.join(ROOT, "viewcrafter_amd", "csrc", name), "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()
+
+
 def synth_conditioning(T, h, w, device, seed=123, B=1):
     """CPU generator with the reference's default seed, then moved to the device."""
     g = torch.Generator().manual_seed(seed)
@@ -47,38 +61,82 @@ def synth_conditioning(T, h, w, device, seed=123, B=1):
     return x_T.to(device), cond, uc
 
 
-def cpu_baseline(model, hp, device, flops_per_step_full, threads=None):
-    """Time the fp32 oracle (oracle/lvdm_oracle.py, a port of the reference algorithm) on the host cores for one DDIM
-    step (= 2 UNet forwards) at a bounded latent size, check the GPU path against it, and FLOP-scale to the full
-    workload.  Only this function touches oracle/ (as checker and as reported baseline)."""
+def cpu_baseline(model, hp, flops_per_step_full, budget_s=60.0):
+    """The fp32 oracle (oracle/lvdm_oracle.py, a port of the reference algorithm) timed on the host cores for one UNet forward
+    at BASELINE configs[0]'s shapes (16 frames, 40x64 latent, the full 1.44 B-parameter width), after a
+    small warm-up call; one DDIM step = 2 forwards; FLOP-scaled to the bench workload (labelled extrapolated).  A host too
+    slow for that within `budget_s` (predicted from the warm-up) gets the same 16 frames at 24x40.  Only this function, the
+    two legs below and nothing in the timed region touch oracle/."""
     from oracle import lvdm_oracle as O
-    from viewcrafter_amd import ops
-    T, h, w = 2, 16, 32
-    if threads:
-        torch.set_num_threads(threads)
     unet = model.model.diffusion_model
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
     g = torch.Generator().manual_seed(7)
-    x = torch.randn(1, 8, T, h, w, generator=g)
-    ctx = torch.randn(1, 77 + 256, 1024, generator=g)
     ts, fs = torch.tensor([499]), torch.tensor([10])
-    with torch.no_grad():
-        ops.profile_begin(1 << 14)
-        y_gpu = unet(x.to(device), ts.to(device), context=ctx.to(device), fs=fs.to(device))
-        torch.cuda.synchronize()
-        prof = ops.profile_end()
-        flops_small = sum(v["flops"] for v in prof.values())
-        sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
-        O.unet_forward(sd, hp, x[:, :, :1], ts, ctx, fs)          # warm-up (threads, allocator)
+
+    def run(T, h, w):
+        x = torch.randn(1, 8, T, h, w, generator=g)
+        ctx = torch.randn(1, 77 + 256, 1024, generator=g)
         t0 = time.perf_counter()
-        y_cpu = O.unet_forward(sd, hp, x, ts, ctx, fs)
-        dt = time.perf_counter() - t0
-    rel = float((y_gpu.cpu().double() - y_cpu.double()).norm() / y_cpu.double().norm())
-    step_s_small = 2.0 * dt                                       # one DDIM step = cond + uncond forward
-    scale = flops_per_step_full / (2.0 * flops_small)
-    return dict(value=1.0 / (step_s_small * scale), unit="DDIM steps/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"fp32 oracle UNet forward, full 1.44B-param width, latent {T}x{h}x{w}: {dt:.2f} s/forward "
-                       f"({flops_small/1e12:.3f} TFLOP) -> x{scale:.0f} FLOP-scaled to the full workload (extrapolated)",
-                gpu_vs_oracle_rel_l2=rel)
+        with torch.no_grad():
+            y = O.unet_forward(sd, hp, x, ts, ctx, fs)
+        assert torch.isfinite(y).all()
+        return time.perf_counter() - t0
+    run(2, 8, 8)                                         # threads, allocator, oneDNN primitives
+    t_small = run(16, 8, 16)                             # 1/20 of the pixels of 40x64: predicts the real call
+    T, h, w = 16, 40, 64
+    if t_small * 20 * 1.3 > budget_s:
+        h, w = 24, 40
+    dt = run(T, h, w)
+    flops = UNET_TFLOP.get((T, h, w))
+    step_s = 2.0 * dt
+    scale = flops_per_step_full / (2.0 * flops * 1e12) if flops else None
+    return dict(value=(1.0 / (step_s * scale)) if scale else None, unit="DDIM steps/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"fp32 oracle UNet forward on the host, full 1.44B-param width, latent {T}x{h}x{w} (BASELINE configs[0] shapes"
+                       f"{'' if (h, w) == (40, 64) else ' reduced to fit the time budget'}): {dt:.1f} s/forward = {step_s:.1f} s per DDIM "
+                       f"step there ({flops} TFLOP/forward) -> x{scale:.1f} FLOP-scaled to the bench workload (extrapolated)",
+                sec_per_step_at_sample=step_s, sample_latent=[T, h, w])
+
+
+# UNet forward TFLOP of the reference graph by latent (SURVEY.md §8d, torch.utils.flop_counter on meta tensors; 16x24x40
+# counted the same way)
+UNET_TFLOP = {(25, 72, 128): 82.761, (16, 72, 128): 52.336, (25, 40, 64): 20.187, (16, 40, 64): 12.603, (16, 24, 40): 4.595}
+
+
+def gpu_legs(model, hp, dd, T, h, w, device, x, ts, ctx, fs, z_dec):
+    """On the MI355X, outside the timed region: (a) parity of the HIP path against the fp32 oracle at the bench's own
+    latent (UNet forward; VAE decode of 2 frames), (b) the oracle graph as PyTorch eager ops under fp16 autocast =
+    the un-accelerated same-GPU baseline (hipBLASLt / rocBLAS / MIOpen kernels, vanilla attention, NCHW)."""
+    from oracle import lvdm_oracle as O
+    unet = model.model.diffusion_model
+    sd = {k: v.detach() for k, v in unet.state_dict().items()}
+    out = {}
+    with torch.no_grad():
+        y = unet(x, ts, context=ctx, fs=fs)
+        ref = O.unet_forward(sd, hp, x, ts, ctx, fs)
+        rel = float((y.double() - ref.double()).norm() / ref.double().norm())
+        vsd = {k: v.detach() for k, v in model.first_stage_model.state_dict().items()}
+        dec = model.decode_first_stage(z_dec)
+        dref = O.decode_first_stage(vsd, dd, z_dec, scale_factor=model.scale_factor)
+        drel = float((dec.double() - dref.double()).norm() / dref.double().norm())
+        del dec, dref
+        out["parity"] = {"unet_forward_rel_l2": rel, "vae_decode_rel_l2": drel, "latent": [T, h, w],
+                         "oracle": "fp32 oracle/lvdm_oracle.py run on the same MI355X, same weights and inputs",
+                         "bounds": {"unet_forward": 8e-3, "vae_decode": 8e-3}}
+        with torch.autocast("cuda", dtype=torch.float16):
+            O.unet_forward(sd, hp, x, ts, ctx, fs)                       # warm-up: MIOpen find, hipBLASLt heuristics
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):                                          # cond + uncond = one DDIM step of the reference
+                ye = O.unet_forward(sd, hp, x, ts, ctx, fs)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        erel = float((ye.double() - ref.double()).norm() / ref.double().norm())
+        out["gpu_eager_baseline"] = {"value": 1.0 / dt, "unit": "DDIM steps/s", "ms_per_step": 1e3 * dt,
+                                     "kind": "oracle graph as PyTorch-ROCm eager ops under torch.autocast(fp16) on this MI355X "
+                                             "(2 sequential B=1 forwards, vanilla attention in batch-head chunks, no DDIM update)",
+                                     "rel_l2_vs_fp32": erel}
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -92,6 +150,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the UNet forward as a hipGraph in the timed region "
                     "(HIP-event profiling cannot run inside a graph: the roofline is then measured on extra eager steps)")
     ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the timed region")
+    ap.add_argument("--no-gpu-legs", action="store_true", help="skip parity-vs-oracle and the eager fp16 baseline on the GPU")
+    ap.add_argument("--no-video", action="store_true", help="skip the measured 50-step video after the timed region")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,7 +185,24 @@ def main():
     cfg_name, T, h, w = WORKLOADS[args.workload]
     torch.manual_seed(123)
     model = build_diffusion_model(os.path.join(ROOT, "configs", cfg_name), device=device, conditioners="identity")
-    randomize_parameters(model, seed=0)
+    bcast_s = None
+    if world == 1 or rank == 0:
+        randomize_parameters(model, seed=0)
+    if world > 1:
+        # the product's start-up: rank 0 owns the weights, the others receive them in 256 MB RCCL broadcasts over xGMI
+        from viewcrafter_amd import parallel
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        parallel.broadcast_module_(model, src=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        bcast_s = time.perf_counter() - t0
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        chk = chk.to(device if dist.get_backend() == "nccl" else "cpu")
+        allc = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        assert all(torch.equal(allc[0], c) for c in allc), f"rank weights differ after the broadcast: {[float(c) for c in allc]}"
     # independent trajectory per rank (batch-sharded: no data-path collective)
     x, cond, uc = synth_conditioning(T, h, w, device, seed=123 + rank)
     fs = torch.tensor([10], device=device)
@@ -183,6 +260,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    gather_s = None
+    if world > 1 and not args.no_decode:
+        # the product's end: every rank decodes its own trajectory, rank 0 receives all clips in one all_gather (uint8 frames)
+        from viewcrafter_amd import parallel
+        with torch.no_grad():
+            clip = model.decode_first_stage(x)
+        clip = ((clip[0].permute(1, 2, 3, 0).clamp(-1, 1) + 1) * 127.5).round().to(torch.uint8)
+        if dist.get_backend() != "nccl":
+            clip = clip.cpu()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        clips = parallel.gather_results({rank: clip}, world)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gather_s = time.perf_counter() - t0
+        if rank == 0:
+            assert len(clips) == world and all(c.shape == clip.shape for c in clips)
+        del clips, clip
     steps_per_s = world * args.steps / elapsed
     out = {
         "metric": "DDIM steps/sec (576x1024x25f latent 25x72x128, CFG 7.5, 50-step schedule)" if "576x1024x25" in args.workload
@@ -205,12 +301,28 @@ def main():
                            "launches_per_step": gemm["launches"] / args.steps,
                            "avg_launch_ms": gemm["ms"] / max(gemm["launches"], 1),
                            "algorithmic_tflop_per_launch_avg": gemm["flops"] / max(gemm["launches"], 1) / 1e12}
-        try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (bench.py cannot run rocprofv3 itself)
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (bench.py cannot run rocprofv3 itself).  The
+        # file records a hash of the GEMM sources it was measured on: a number measured on other kernels is not reported.
+        try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = tr["source"]
-        except Exception:
-            pass
+            now = csrc_hash()
+            if tr.get("csrc_sha256") == now:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tr["source"]
+                out["roofline"]["traffic_measured_at"] = {"csrc_sha256": now[:12], "commit": tr.get("commit")}
+            else:
+                print(f"[bench] profiles/pmc_traffic.json is STALE (measured on csrc {str(tr.get('csrc_sha256'))[:12]}, kernels are "
+                      f"now {now[:12]}): roofline.traffic = null; re-run tools/pmc_passes.sh", file=sys.stderr)
+                out["roofline"]["traffic_note"] = "stale PMC file: kernels changed since it was measured"
+        except Exception as e:
+            print(f"[bench] no usable profiles/pmc_traffic.json: {e}", file=sys.stderr)
+        fl = prof["flash_attn"]
+        fach = fl["flops"] / (fl["ms"] * 1e-3) / 1e12 if fl["ms"] > 0 else 0.0
+        out["roofline_flash"] = {"bound": "mfma", "achieved": fach, "peak": MI355X_FP16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": fach / MI355X_FP16_DENSE_TFLOPS, "traffic": None,
+                                 "kernel": "flash_d64_kernel<2,...> / xattn_resident_d64_kernel (csrc/attention.hip); FLOP = 4 N_q N_k d per head",
+                                 "launches_per_step": fl["launches"] / args.steps, "avg_launch_ms": fl["ms"] / max(fl["launches"], 1),
+                                 "algorithmic_tflop_per_launch_avg": fl["flops"] / max(fl["launches"], 1) / 1e12}
         out["kernel_families"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
                                       "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None,
                                       "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
@@ -233,11 +345,39 @@ def main():
             out["sec_per_video_est"] = 50.0 / (steps_per_s / world) + dec_s
             out["reference_published"] = "120 s/video on A100-40G (README.md:117-119), scope of that timer unstated"
             del frames
+            if world == 1 and not args.no_video:
+                # BASELINE.json's metric is steps/s AND sec/video: one real 50-step sample() (eta = 1, CFG 7.5, rescale 0.7) + the
+                # 25-frame decode, measured; the once-per-video conditioners (CLIP towers, Resampler, VAE encode: 0.15 s in
+                # tools/video_e2e.py) are fed as synthetic tensors here and are not in this number
+                with torch.no_grad():
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    smp, _ = sampler.sample(S=50, conditioning=cond, batch_size=1, shape=[4, T, h, w], verbose=False,
+                                            unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0, cfg_img=None,
+                                            mask=None, x0=None, fs=fs, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                                            unconditional_conditioning_img_nonetext=None)
+                    vid = model.decode_first_stage(smp)
+                    torch.cuda.synchronize()
+                    out["sec_per_video"] = time.perf_counter() - t0
+                assert torch.isfinite(vid).all() and vid.shape == (1, 3, T, 8 * h, 8 * w)
+                out["sec_per_video_scope"] = "measured: DDIMSampler.sample(S=50) + decode_first_stage of all frames, one trajectory on one GPU"
+                del vid, smp
+        from viewcrafter_amd.config import load_yaml
+        mp_ = load_yaml(os.path.join(ROOT, "configs", cfg_name))["model"]["params"]
+        hp = dict(mp_["unet_config"]["params"])
+        if not args.no_gpu_legs:
+            g = torch.Generator().manual_seed(99)
+            xg = torch.randn(1, 8, T, h, w, generator=g).to(device)
+            cg = torch.randn(1, 77 + 256, 1024, generator=g).to(device)
+            zg = torch.randn(1, 4, 2, h, w, generator=g).to(device)
+            out.update(gpu_legs(model, hp, dict(mp_["first_stage_config"]["params"]["ddconfig"]), T, h, w, device, xg,
+                                torch.tensor([499], device=device), cg, fs, zg))
+        if bcast_s is not None:
+            out["broadcast_s"] = bcast_s
+        if gather_s is not None:
+            out["gather_s"] = gather_s
         if not args.no_cpu_baseline:
-            hp = dict(model.model.diffusion_model_hp) if hasattr(model.model, "diffusion_model_hp") else None
-            from viewcrafter_amd.config import load_yaml
-            hp = dict(load_yaml(os.path.join(ROOT, "configs", cfg_name))["model"]["params"]["unet_config"]["params"])
-            out["cpu_baseline"] = cpu_baseline(model, hp, device, flops_per_step)
+            out["cpu_baseline"] = cpu_baseline(model, hp, flops_per_step)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

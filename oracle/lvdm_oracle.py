@@ -118,9 +118,23 @@ def _unheads(t, h):
     return t.view(bh // h, h, n, d).permute(0, 2, 1, 3).reshape(bh // h, n, h * d)
 
 
+SDPA_MAX_SCORES = 1 << 31      # scores materialised at once (8 GiB of fp32); larger problems are walked in batch-head chunks
+
+
 def _sdpa(q, k, v, scale):
-    sim = torch.einsum("bid,bjd->bij", q, k) * scale
-    return torch.einsum("bij,bjd->bid", sim.softmax(dim=-1), v)
+    """attention.py:101-125 (vanilla): the full score matrix per (batch, head).  Batch-heads are independent, so a problem
+    whose scores would not fit comfortably (N = 9216: 42 GB in fp32) is evaluated chunk by chunk - same arithmetic."""
+    per = q.shape[1] * k.shape[1]
+    step = max(1, min(q.shape[0], SDPA_MAX_SCORES // max(per, 1)))
+    if step >= q.shape[0]:
+        sim = torch.einsum("bid,bjd->bij", q, k) * scale
+        return torch.einsum("bij,bjd->bid", sim.softmax(dim=-1), v)
+    out = torch.empty((q.shape[0], q.shape[1], v.shape[2]), dtype=q.dtype, device=q.device)
+    for i in range(0, q.shape[0], step):
+        sim = torch.einsum("bid,bjd->bij", q[i:i + step], k[i:i + step]) * scale
+        out[i:i + step] = torch.einsum("bij,bjd->bid", sim.softmax(dim=-1), v[i:i + step])
+        del sim
+    return out
 
 
 def cross_attention(sd, p, x, context, heads, image_cross_attention, text_len=77):
@@ -280,9 +294,10 @@ def _run_layers(sd, prefix, layers, h, emb, context, batch):
     return h
 
 
-def unet_forward(sd, hp, x, timesteps, context, fs=None):
+def unet_forward(sd, hp, x, timesteps, context, fs=None, taps=None):
     """UNetModel.forward, openaimodel3d.py:548-603.  sd keys are relative to the UNet ('input_blocks.0.0.weight'...).
-    x [b, in_ch, t, h, w]; timesteps [b] int64; context [b, L, ctx_dim]; fs [b] int64."""
+    x [b, in_ch, t, h, w]; timesteps [b] int64; context [b, L, ctx_dim]; fs [b] int64.  `taps`: optional dict that
+    receives every block's output [(b t), C, h, w] under its module name (per-block error tables in the tests)."""
     b, _, t, _, _ = x.shape
     mc = hp["model_channels"]
     emb = _lin(sd, "time_embed.2", F.silu(_lin(sd, "time_embed.0", timestep_embedding(timesteps, mc))))
@@ -297,7 +312,7 @@ def unet_forward(sd, hp, x, timesteps, context, fs=None):
     h = x.permute(0, 2, 1, 3, 4).reshape(b * t, x.shape[1], x.shape[3], x.shape[4])
     if hp.get("fs_condition", False):
         if fs is None:
-            fs = torch.full((b,), hp.get("default_fs", 4), dtype=torch.long)
+            fs = torch.full((b,), hp.get("default_fs", 4), dtype=torch.long, device=x.device)
         fe = _lin(sd, "fps_embedding.2", F.silu(_lin(sd, "fps_embedding.0", timestep_embedding(fs, mc))))
         emb = emb + fe.repeat_interleave(t, dim=0)
     inputs, middle, outputs = unet_layout(hp)
@@ -310,10 +325,16 @@ def unet_forward(sd, hp, x, timesteps, context, fs=None):
             h5 = temporal_transformer(sd, "init_attn.0", h5, 8)
             h = h5.permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)
         hs.append(h)
+        if taps is not None:
+            taps[f"input_blocks.{i}"] = h
     h = _run_layers(sd, "middle_block", middle, h, emb, context, b)
+    if taps is not None:
+        taps["middle_block"] = h
     for i, layers in enumerate(outputs):
         h = torch.cat([h, hs.pop()], dim=1)
         h = _run_layers(sd, f"output_blocks.{i}", layers, h, emb, context, b)
+        if taps is not None:
+            taps[f"output_blocks.{i}"] = h
     y = F.conv2d(F.silu(_gn(sd, "out.0", h, 1e-5)), sd["out.2.weight"], sd["out.2.bias"], padding=1)
     return y.view(b, t, -1, y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
 
@@ -460,8 +481,8 @@ def ddim_sample(apply_model, tables, scale_arr, x_T, cond, uncond, steps, eta=0.
                 out = v_u + cfg_scale * (v_c - v_u)
             if guidance_rescale > 0.0:
                 out = rescale_noise_cfg(out, v_c, guidance_rescale)
-        sa = tables["sqrt_alphas_cumprod"][t].view(b, *([1] * (x.ndim - 1)))
-        s1 = tables["sqrt_one_minus_alphas_cumprod"][t].view(b, *([1] * (x.ndim - 1)))
+        sa = tables["sqrt_alphas_cumprod"][t].view(b, *([1] * (x.ndim - 1))).to(x.device)
+        s1 = tables["sqrt_one_minus_alphas_cumprod"][t].view(b, *([1] * (x.ndim - 1))).to(x.device)
         a_t = torch.tensor(float(alphas[index]))
         a_prev = torch.tensor(float(alphas_prev[index]))
         sigma = torch.tensor(float(sigmas[index]))

@@ -38,3 +38,21 @@ def synth_state_dict(shapes, seed=0, skip=()):
 def synth_input(name, shape, seed=0, scale=1.0):
     rng = np.random.default_rng((seed * 1000003) ^ zlib.crc32(("input:" + name).encode()))
     return torch.from_numpy(rng.standard_normal(tuple(shape), dtype=np.float32) * np.float32(scale))
+
+
+class NamedRandn:
+    """Drop-in for `torch.randn` while a fixture is generated / replayed: the k-th call returns synth_input(f"{prefix}_{k}").
+    The reference and the product draw their Gaussians in the same order (posterior sample of the condition clip, x_T, one
+    noise tensor per DDIM step), so patching both with this makes `image_guided_synthesis` comparable end to end."""
+
+    def __init__(self, prefix):
+        self.prefix, self.calls = prefix, 0
+
+    def __call__(self, *size, device=None, dtype=None, generator=None, **kwargs):
+        if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+            size = tuple(size[0])
+        self.calls += 1
+        t = synth_input(f"{self.prefix}_{self.calls}", size)
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(device) if device is not None else t

@@ -290,6 +290,53 @@ def gen_clip(out):
             print("clip image", tag, tuple(y.shape), float(y.abs().mean()))
 
 
+def gen_igs(out):
+    """The driver function itself: reference utils/diffusion_utils.py:117-201 `image_guided_synthesis` on the tiny graph with
+    the reference's own embedder / Resampler / sampler / VAE code (cond + uncond assembly, get_latent_z, CFG 7.5, hybrid
+    conditioning, n_samples stacking, and the multi-condition variant).  Every Gaussian draw is replaced by a named tensor
+    (oracle.weights.NamedRandn); perframe_ae is switched off so that the posterior noise is ONE draw of [(b t), 4, h, w] -
+    the per-frame loop of ddpm3d.py:634-639 computes the same thing frame by frame."""
+    install_clip_stand_ins()
+    from lvdm.models.ddpm3d import VIPLatentDiffusion
+    from lvdm.models.samplers.ddim import DDIMSampler
+    from lvdm.models.samplers.ddim_multiplecond import DDIMSampler as DDIMSamplerMulti
+    from utils.diffusion_utils import image_guided_synthesis
+    from oracle.weights import NamedRandn
+    from tests.tiny_config import IGS_H, IGS_T, IGS_W, igs_model_params
+
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+    DDIMSampler.register_buffer = register_buffer
+    DDIMSamplerMulti.register_buffer = register_buffer
+    R = "lvdm.modules.encoders."
+    params = AttrDict.wrap(igs_model_params("lvdm.modules.networks.openaimodel3d.UNetModel", "lvdm.models.autoencoder.AutoencoderKL",
+                                            R + "condition.FrozenOpenCLIPEmbedder", R + "condition.FrozenOpenCLIPImageEmbedderV2",
+                                            R + "resampler.Resampler", device="cpu"))
+    torch.manual_seed(0)
+    model = VIPLatentDiffusion(**params).eval()
+    shapes = load_synth(model, skip=SCHEDULE_BUFFERS)
+    model.perframe_ae = False
+    out["igs_model_keys"] = np.array(sorted(shapes.keys()))
+    out["igs_model_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    videos = torch.tanh(synth_input("igs_videos", (1, 3, IGS_T, IGS_H, IGS_W)))
+    noise_shape = [1, 4, IGS_T, IGS_H // 8, IGS_W // 8]
+    real_randn = torch.randn
+    for tag, kw in (("cfg", dict(n_samples=2, multiple_cond_cfg=False, cfg_img=None)),
+                    ("multicond", dict(n_samples=1, multiple_cond_cfg=True, cfg_img=3.0))):
+        torch.randn = NamedRandn(f"igs_{tag}_randn")
+        try:
+            with torch.no_grad():
+                vid = image_guided_synthesis(model, [""], videos, noise_shape, ddim_steps=5, ddim_eta=1.0,
+                                             unconditional_guidance_scale=7.5, fs=10, text_input=False,
+                                             timestep_spacing="uniform_trailing", guidance_rescale=0.7, condition_index=[0], **kw)
+            out[f"igs_{tag}_randn_calls"] = np.asarray(torch.randn.calls)
+        finally:
+            torch.randn = real_randn
+        assert tuple(vid.shape) == (1, kw["n_samples"], 3, IGS_T, IGS_H, IGS_W)
+        out[f"igs_{tag}_sub4"] = vid.numpy()[..., ::4, ::4]
+        print("igs", tag, tuple(vid.shape), float(vid.abs().mean()), "randn calls", int(out[f"igs_{tag}_randn_calls"]))
+
+
 def main():
     try:      # condition.py imports these; resolve transformers' lazy modules before the torchvision stub confuses its probes
         from transformers import T5Tokenizer, T5EncoderModel, CLIPTokenizer, CLIPTextModel  # noqa: F401
@@ -298,7 +345,7 @@ def main():
     import_reference()
     torch.set_num_threads(8)
     for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
-                     ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip)):
+                     ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         out = {}

@@ -1,0 +1,150 @@
+"""The entry points on the host side: `python inference.py` (BASELINE configs[0] plumbing) and its multi-GPU trajectory sharding.
+
+No GPU here, and deliberately no CPU compute path: the CLI must construct the model from the YAML, strict-load the
+checkpoint, build `noise_shape` and then fail loudly at the first kernel launch.  The torchrun path is driven with two
+gloo ranks and a stub diffusion model (the same `inference.main` the GPUs run).
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.util import write_tiny_entry_files
+
+
+def test_inference_cli_plumbing_until_the_first_kernel(tmp_path, monkeypatch):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_entry_gpu.py runs the command to the end")
+    import inference
+    import viewcrafter
+    from viewcrafter_amd._lib import VcxError
+    ypath, cpath, rpath, (T, H, W) = write_tiny_entry_files(tmp_path)
+    built = {}
+    real_init = viewcrafter.ViewCrafter.setup_diffusion
+
+    def spy(self):
+        real_init(self)
+        built["noise_shape"], built["model"] = self.noise_shape, self.diffusion
+    monkeypatch.setattr(viewcrafter.ViewCrafter, "setup_diffusion", spy)
+    argv = ["--renderings", rpath, "--config", ypath, "--ckpt_path", cpath, "--out_dir", str(tmp_path / "out"), "--exp_name", "e",
+            "--device", "cpu", "--ddim_steps", "5", "--video_length", str(T), "--height", str(H), "--width", str(W), "--prompt", ""]
+    with pytest.raises(VcxError, match="no CPU fallback"):
+        inference.main(argv)
+    assert built["noise_shape"] == [1, 4, T, H // 8, W // 8]                      # viewcrafter.py:399-404
+    m = built["model"]
+    assert m.perframe_ae is True and m.model.conditioning_key == "hybrid" and not m.training
+    # the checkpoint really went in (strict): a synthetic tensor, not the constructor's initialisation
+    from oracle.weights import synth_tensor
+    w = m.model.diffusion_model.out[2].weight
+    assert torch.equal(w, synth_tensor("model.diffusion_model.out.2.weight", w.shape))
+    assert os.path.isdir(tmp_path / "out" / "e")
+
+
+def test_invalid_mode_and_missing_reference_are_reported(tmp_path, monkeypatch):
+    import inference
+    import viewcrafter
+    monkeypatch.setattr(viewcrafter.ViewCrafter, "setup_diffusion", lambda self: None)
+    monkeypatch.delenv("VIEWCRAFTER_REFERENCE", raising=False)
+    with pytest.raises(RuntimeError, match="reference"):     # geometry stages need a reference checkout
+        inference.main(["--out_dir", str(tmp_path), "--exp_name", "x", "--mode", "single_view_txt"])
+
+
+# ------------------------------------------------------------------ torchrun path, two gloo ranks, stub model
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _StubModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.model = torch.nn.Module()
+        self.model.diffusion_model = torch.nn.Module()
+        self.model.diffusion_model.out_channels = 4
+        self.cond_stage_model = None
+        self.w = torch.nn.Parameter(torch.randn(7))
+
+
+def _worker(rank, world, port, tmp, q, sparse):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import inference
+    import viewcrafter
+
+    def build(config, device="cpu", ckpt_path=None, **kw):
+        assert (ckpt_path is not None) == (rank == 0), "only rank 0 reads the checkpoint"
+        torch.manual_seed(1000 + rank)                   # every rank starts with different "weights"
+        return _StubModel()
+
+    def synth(model, prompts, videos, noise_shape, *a, **kw):
+        # depends on the clip, on the (broadcast) weights and on the per-clip seed -> [B, n_samples, 3, T, H, W]
+        tag = 0.1 * videos.mean() + 0.01 * model.w.detach().sum() + 0.01 * torch.randn(())
+        return (videos * 0 + tag).unsqueeze(1)
+    viewcrafter.build_diffusion_model = build
+    viewcrafter.image_guided_synthesis = synth
+    argv = ["--config", "none.yaml", "--ckpt_path", os.path.join(tmp, "ckpt"), "--out_dir", os.path.join(tmp, "out"), "--exp_name", "e",
+            "--device", "cpu", "--video_length", "3", "--height", "16", "--width", "16", "--seed", "11"]
+    if sparse:     # a stand-in "reference checkout" whose nvs_sparse_view_interp loops over run_diffusion like viewcrafter.py:272-276
+        argv += ["--mode", "sparse_view_interp", "--reference_root", os.path.join(tmp, "ref")]
+    else:
+        argv += ["--renderings", ",".join(os.path.join(tmp, f"r{i}.pt") for i in range(2)) + "," + os.path.join(tmp, "r_many.pt")]
+    out = inference.main(argv)
+    q.put((rank, None if out is None else [float(o.flatten()[0]) for o in (out if isinstance(out, list) else list(out.view(-1, 3, 16, 16, 3)))]))
+
+
+_FAKE_REFERENCE = '''
+import torch
+class ViewCrafter:
+    def __init__(self, opts, gradio=False):
+        self.opts = opts
+        self.setup_diffusion()
+    def nvs_sparse_view_interp(self):
+        renders = torch.arange(5 * 2 + 1, dtype=torch.float32).view(-1, 1, 1, 1).expand(-1, 16, 16, 3) / 100      # 5 clips of 3 frames sharing ends
+        res = [self.run_diffusion(renders[i * 2: 3 + i * 2]) for i in range(5)]
+        return torch.cat(res)
+'''
+
+
+def _expected(clip_means, w_sum, seed):
+    out = []
+    for i, m in enumerate(clip_means):
+        torch.manual_seed(seed + i)
+        out.append(float(0.1 * (torch.tensor(m) * 2 - 1) + 0.01 * w_sum + 0.01 * torch.randn(())))
+    return out
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_inference_main_shards_trajectories_over_two_ranks(tmp_path, sparse):
+    tmp = str(tmp_path)
+    open(os.path.join(tmp, "ckpt"), "w").write("x")
+    os.makedirs(os.path.join(tmp, "ref"))
+    open(os.path.join(tmp, "ref", "viewcrafter.py"), "w").write(_FAKE_REFERENCE)
+    means = [0.1, 0.2, 0.3, 0.4, 0.5]
+    for i in range(2):
+        torch.save(torch.full((3, 16, 16, 3), means[i]), os.path.join(tmp, f"r{i}.pt"))
+    torch.save(torch.stack([torch.full((3, 16, 16, 3), m) for m in means[2:]]), os.path.join(tmp, "r_many.pt"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, q, sparse)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[1] is None and len(outs[0]) == 5           # results live on rank 0 only, in clip order
+    torch.manual_seed(1000)
+    w_sum = float(_StubModel().w.detach().sum())                     # rank 0's weights, which rank 1 must have received
+    if sparse:
+        clip_means = [sum(range(i * 2, i * 2 + 3)) / 3 / 100 for i in range(5)]
+    else:
+        clip_means = means
+    exp = _expected(clip_means, w_sum, 11)
+    assert outs[0] == pytest.approx(exp, abs=1e-5), (outs[0], exp)
+    assert os.path.exists(os.path.join(tmp, "out", "e", "diffusion.avi" if sparse else "diffusion4.avi")) or \
+        os.path.exists(os.path.join(tmp, "out", "e", "diffusion.mp4" if sparse else "diffusion4.mp4"))

@@ -1,0 +1,93 @@
+"""The driver function and the command line on the MI355X.
+
+  * `image_guided_synthesis` (reference utils/diffusion_utils.py:117-201) against a fixture written by the reference's
+    own function (tests/golden/gen_golden.py::gen_igs): cond / uncond assembly from the CLIP towers and the Resampler,
+    get_latent_z, CFG 7.5 with hybrid conditioning, two n_samples variants, decode - and the multi-condition variant;
+  * `python inference.py --renderings ...` end to end as a subprocess: YAML -> instantiate_from_config -> strict checkpoint
+    load -> setup_diffusion -> run_diffusion -> save_video (BASELINE configs[0] with the GPU in the loop).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.weights import NamedRandn, synth_input
+from tests.util import SCHEDULE_BUFFERS, golden, load_synth, psnr, rel_l2, write_tiny_entry_files
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def igs_model():
+    from tests.tiny_config import CLIP_TINY, CLIP_TINY_CFG, igs_model_params
+    from viewcrafter_amd.config import Config
+    from viewcrafter_amd.lvdm.modules.encoders import condition as cond
+    from viewcrafter_amd.utils.diffusion_utils import instantiate_from_config
+    cond.CLIP_CONFIGS[CLIP_TINY] = CLIP_TINY_CFG
+    R = "lvdm.modules.encoders."
+    params = Config.wrap(igs_model_params("lvdm.modules.networks.openaimodel3d.UNetModel", "lvdm.models.autoencoder.AutoencoderKL",
+                                          R + "condition.FrozenOpenCLIPEmbedder", R + "condition.FrozenOpenCLIPImageEmbedderV2",
+                                          R + "resampler.Resampler"))
+    m = instantiate_from_config(Config(target="lvdm.models.ddpm3d.VIPLatentDiffusion", params=params)).eval()
+    sd = load_synth(m, skip=SCHEDULE_BUFFERS)
+    g = golden("igs_tiny")
+    have = sorted(k for k in m.state_dict().keys())
+    assert have == [str(k) for k in g["igs_model_keys"]], "state-dict names differ from the reference's hybrid model"
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("tag,kw", [("cfg", dict(n_samples=2, multiple_cond_cfg=False, cfg_img=None)),
+                                    ("multicond", dict(n_samples=1, multiple_cond_cfg=True, cfg_img=3.0))])
+def test_image_guided_synthesis_vs_reference_golden(igs_model, tag, kw, monkeypatch):
+    from tests.tiny_config import IGS_H, IGS_T, IGS_W
+    from viewcrafter_amd.utils.diffusion_utils import image_guided_synthesis
+    g = golden("igs_tiny")
+    videos = torch.tanh(synth_input("igs_videos", (1, 3, IGS_T, IGS_H, IGS_W))).to(DEV)
+    noise_shape = [1, 4, IGS_T, IGS_H // 8, IGS_W // 8]
+    fake = NamedRandn(f"igs_{tag}_randn")
+    monkeypatch.setattr(torch, "randn", fake)
+    with torch.no_grad():
+        vid = image_guided_synthesis(igs_model, [""], videos, noise_shape, ddim_steps=5, ddim_eta=1.0,
+                                     unconditional_guidance_scale=7.5, fs=10, text_input=False,
+                                     timestep_spacing="uniform_trailing", guidance_rescale=0.7, condition_index=[0], **kw)
+    monkeypatch.undo()
+    assert fake.calls == int(g[f"igs_{tag}_randn_calls"]), "Gaussian draws differ from the reference (count or order)"
+    assert tuple(vid.shape) == (1, kw["n_samples"], 3, IGS_T, IGS_H, IGS_W) and vid.dtype == torch.float32
+    ref = g[f"igs_{tag}_sub4"]
+    sub = vid[..., ::4, ::4]
+    e, p = rel_l2(sub, ref), psnr(sub, ref)
+    print(f"image_guided_synthesis[{tag}]: decoded video rel-L2 vs the reference's own run = {e:.3e}, PSNR {p:.1f} dB")
+    assert e <= 3e-2 and p >= 30.0
+    if kw["n_samples"] == 2:
+        assert not torch.equal(vid[:, 0], vid[:, 1])          # two variants, two noise streams
+
+
+def test_inference_cli_end_to_end(tmp_path):
+    from viewcrafter_amd.utils.video_io import read_avi
+    ypath, cpath, rpath, (T, H, W) = write_tiny_entry_files(tmp_path)
+    out_dir = str(tmp_path / "out")
+    cmd = [sys.executable, os.path.join(ROOT, "inference.py"), "--renderings", rpath, "--config", ypath, "--ckpt_path", cpath,
+           "--out_dir", out_dir, "--exp_name", "e", "--device", "cuda:0", "--ddim_steps", "5", "--video_length", str(T),
+           "--height", str(H), "--width", str(W), "--prompt", "", "--seed", "123"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert ">>> model checkpoint loaded." in r.stdout
+    res = torch.load(os.path.join(out_dir, "e", "diffusion0.pt"))
+    assert tuple(res.shape) == (T, H, W, 3) and torch.isfinite(res).all()
+    assert float(res.min()) >= -1.0 and float(res.max()) <= 1.0 and float(res.std()) > 1e-3       # viewcrafter.py:106 clamp
+    vids = [f for f in os.listdir(os.path.join(out_dir, "e")) if f.startswith("diffusion0.") and f != "diffusion0.pt"]
+    assert len(vids) == 1
+    if vids[0].endswith(".avi"):
+        frames, fps = read_avi(os.path.join(out_dir, "e", vids[0]))
+        assert frames.shape == (T, H, W, 3) and fps == 10
+        expect = ((res + 1.0) / 2.0).clamp(0, 1).mul(255).round().to(torch.uint8).numpy()
+        assert np.array_equal(frames, expect)
+    # same seed, same command: the run is reproducible bit for bit (fixed summation orders everywhere)
+    r2 = subprocess.run(cmd[:cmd.index("e")] + ["e2"] + cmd[cmd.index("e") + 1:], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-4000:]
+    assert torch.equal(torch.load(os.path.join(out_dir, "e2", "diffusion0.pt")), res)

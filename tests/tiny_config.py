@@ -45,3 +45,19 @@ CLIP_TINY = "vcx-tiny-test"
 CLIP_TINY_CFG = dict(embed_dim=64,
                      vision=dict(image_size=224, layers=3, width=160, head_width=80, patch_size=56, mlp_ratio=2.0),
                      text=dict(context_length=77, vocab_size=49408, width=128, heads=2, layers=3, mlp_ratio=2.0))
+
+
+# image_guided_synthesis fixture (tests/golden/igs_tiny.npz): 4 frames of 256x128 (latent 32x16), the tiny UNet / VAE, the tiny
+# OpenCLIP towers as cond_stage / embedder and a Resampler sized for them (vision width 160 in, 16 queries x 4 frames = 64 image
+# tokens out = the per-frame branch 77 + 16 T of openaimodel3d.py:556)
+IGS_T, IGS_H, IGS_W = 4, 256, 128
+IGS_RESAMPLER = dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=16, embedding_dim=160, output_dim=128, ff_mult=4,
+                     video_length=IGS_T)
+
+
+def igs_model_params(unet_target, vae_target, clip_text_target, clip_image_target, resampler_target, arch=CLIP_TINY, **embedder_kw):
+    p = tiny_model_params(unet_target, vae_target)
+    p["cond_stage_config"] = {"target": clip_text_target, "params": dict(arch=arch, freeze=True, layer="penultimate", **embedder_kw)}
+    p["img_cond_stage_config"] = {"target": clip_image_target, "params": dict(arch=arch, freeze=True, **embedder_kw)}
+    p["image_proj_stage_config"] = {"target": resampler_target, "params": dict(IGS_RESAMPLER)}
+    return copy.deepcopy(p)

@@ -34,3 +34,29 @@ def psnr(a, b, peak=2.0):
     b = torch.as_tensor(np.asarray(b)).double() if not torch.is_tensor(b) else b.detach().double().cpu()
     mse = float(((a - b) ** 2).mean())
     return 10 * np.log10(peak * peak / max(mse, 1e-30))
+
+
+def write_tiny_entry_files(tmp_path, device_for_build="cpu"):
+    """What `python inference.py --renderings ...` needs, for the tiny graph: a model YAML (the reference's class paths as
+    targets, the tiny OpenCLIP towers given inline), a synthetic Lightning checkpoint with every key of the strict load,
+    and point-cloud renders [T, H, W, 3] in [0, 1].  Returns (yaml path, ckpt path, renders path, (T, H, W))."""
+    import yaml
+    from tests.tiny_config import CLIP_TINY_CFG, IGS_H, IGS_T, IGS_W, igs_model_params
+    from viewcrafter_amd.config import Config
+    from viewcrafter_amd.utils.diffusion_utils import instantiate_from_config
+    R = "lvdm.modules.encoders."
+    params = igs_model_params("lvdm.modules.networks.openaimodel3d.UNetModel", "lvdm.models.autoencoder.AutoencoderKL",
+                              R + "condition.FrozenOpenCLIPEmbedder", R + "condition.FrozenOpenCLIPImageEmbedderV2",
+                              R + "resampler.Resampler", arch=CLIP_TINY_CFG)
+    cfg = {"model": {"target": "lvdm.models.ddpm3d.VIPLatentDiffusion", "params": params}}
+    ypath = os.path.join(str(tmp_path), "tiny_inference.yaml")
+    with open(ypath, "w") as f:
+        yaml.safe_dump(cfg, f)
+    model = instantiate_from_config(Config.wrap(cfg["model"]))
+    load_synth(model, skip=SCHEDULE_BUFFERS)
+    cpath = os.path.join(str(tmp_path), "tiny.ckpt")
+    torch.save({"state_dict": model.state_dict(), "global_step": 0}, cpath)      # Lightning layout (diffusion_utils.py:85-88)
+    rpath = os.path.join(str(tmp_path), "renders.pt")
+    g = torch.Generator().manual_seed(5)
+    torch.save(torch.rand(IGS_T, IGS_H, IGS_W, 3, generator=g), rpath)
+    return ypath, cpath, rpath, (IGS_T, IGS_H, IGS_W)

@@ -1,8 +1,16 @@
 """HBM-side traffic per kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB units).
 FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads on gfx950
-(checked here on the 460800x320x320+residual GEMM: 2 x 288 MB raw = 576 MB vs 590 MB algorithmic).
-    python tools/pmc_traffic.py fetch.db write.db [steps_in_fetch_run] [steps_in_write_run]"""
-import collections, sqlite3, sys
+(checked in round 1 on the 460800x320x320+residual GEMM: 2 x 288 MB raw = 576 MB vs 590 MB algorithmic).
+    python tools/pmc_traffic.py fetch.db write.db [--json out.json --algo-bytes-per-step B --gemm-calls-per-step N --commit C]
+The number of DDIM steps in each pass is read from the trace itself (one ddim_update_kernel dispatch per step)."""
+import argparse, collections, hashlib, json, os, sqlite3
+
+ap = argparse.ArgumentParser()
+ap.add_argument("fetch_db"); ap.add_argument("write_db")
+ap.add_argument("--json"); ap.add_argument("--algo-bytes-per-step", type=float, default=None)
+ap.add_argument("--gemm-calls-per-step", type=float, default=460.0); ap.add_argument("--commit", default=None)
+a = ap.parse_args()
+
 
 def per_kernel(path, counter):
     db = sqlite3.connect(path)
@@ -13,17 +21,33 @@ def per_kernel(path, counter):
             join {T('rocpd_info_kernel_symbol')} s on d.kernel_id = s.id where p.name = '{counter}' group by s.kernel_name"""
     return {k: (n, v) for k, n, v in db.execute(q)}
 
-fam = lambda k: ("gemm" if "gemm_" in k else "flash_attn" if "flash_d64" in k else "temporal_attn" if "tattn" in k else
+
+fam = lambda k: ("gemm" if "gemm_" in k else "flash_attn" if ("flash_d64" in k or "xattn_resident" in k) else "temporal_attn" if "tattn" in k else
                  "groupnorm" if "gn_" in k else "layernorm" if "layernorm" in k else None)
-f = per_kernel(sys.argv[1], "FETCH_SIZE")
-w = per_kernel(sys.argv[2], "WRITE_SIZE")
-sf = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
-sw = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+f = per_kernel(a.fetch_db, "FETCH_SIZE")
+w = per_kernel(a.write_db, "WRITE_SIZE")
+steps = lambda d: max(1.0, float(sum(n for k, (n, _) in d.items() if "ddim_update" in k)))
+sf, sw = steps(f), steps(w)
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for k, (n, v) in f.items():
     if fam(k): agg[fam(k)][0] += n / sf; agg[fam(k)][1] += 2.0 * v * 1024 / sf
 for k, (n, v) in w.items():
     if fam(k): agg[fam(k)][2] += v * 1024 / sw
+print(f"# DDIM steps in the FETCH pass: {sf:.0f}, in the WRITE pass: {sw:.0f}")
 print(f"{'family':14s} {'launches/step':>13s} {'read GB/step (2x FETCH)':>24s} {'write GB/step':>14s} {'bytes/launch':>14s}")
 for k, (n, r, wr) in agg.items():
     print(f"{k:14s} {n:13.0f} {r/1e9:24.1f} {wr/1e9:14.1f} {(r+wr)/max(n,1):14.3e}")
+if a.json:
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for name in ("gemm_dma.hip", "gemm.hip", "gemm_args.h"):
+        h.update(open(os.path.join(root, "viewcrafter_amd", "csrc", name), "rb").read())
+    n, r, wr = agg["gemm"]
+    out = {"family": "gemm", "hbm_bytes_per_launch": (r + wr) / a.gemm_calls_per_step, "hbm_read_gb_per_step": r / 1e9,
+           "hbm_write_gb_per_step": wr / 1e9, "kernel_dispatches_per_step": n, "launches_per_step": a.gemm_calls_per_step,
+           "algorithmic_bytes_per_launch": (a.algo_bytes_per_step / a.gemm_calls_per_step) if a.algo_bytes_per_step else None,
+           "note": "per vcx_gemm_f16 call; FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE as reported; separate --pmc passes",
+           "source": "tools/pmc_passes.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 1 --warmup 0 ...)",
+           "csrc_sha256": h.hexdigest(), "commit": a.commit,
+           "families": {k: {"launches_per_step": v[0], "read_gb_per_step": v[1] / 1e9, "write_gb_per_step": v[2] / 1e9} for k, v in agg.items()}}
+    json.dump(out, open(a.json, "w"), indent=1)

@@ -13,6 +13,7 @@ import sys
 import numpy as np
 import torch
 
+from viewcrafter_amd import parallel
 from viewcrafter_amd.builder import build_diffusion_model
 from viewcrafter_amd.utils.diffusion_utils import image_guided_synthesis
 
@@ -42,9 +43,15 @@ class ViewCrafter:
         root = _reference_root(self.opts)
         if root and root not in sys.path:
             sys.path.append(root)           # lets the YAML's CLIP / Resampler targets resolve to the reference
-        assert os.path.exists(self.opts.ckpt_path), "Error: checkpoint Not Found!"
-        model = build_diffusion_model(self.opts.config, device=self.device, ckpt_path=self.opts.ckpt_path,
+        rank, world = parallel.rank_world()
+        # one process per GPU (torchrun): rank 0 reads the checkpoint, the others receive the weights in a few large RCCL
+        # broadcasts over xGMI (parallel.broadcast_module_) instead of W reads of the same 10 GB file
+        if rank == 0:
+            assert os.path.exists(self.opts.ckpt_path), "Error: checkpoint Not Found!"
+        model = build_diffusion_model(self.opts.config, device=self.device, ckpt_path=self.opts.ckpt_path if rank == 0 else None,
                                       perframe_ae=self.opts.perframe_ae, conditioners="config", init_on_device=False)
+        if world > 1:
+            parallel.broadcast_module_(model, src=0)
         if model.cond_stage_model is not None:
             model.cond_stage_model.device = self.device
         self.diffusion = model
@@ -66,15 +73,40 @@ class ViewCrafter:
                 condition_index)
         return torch.clamp(batch_samples[0][0].permute(1, 2, 3, 0), -1., 1.)
 
+    def run_diffusion_many(self, clips):
+        """Independent trajectories / clips (each one `run_diffusion` call = one image_guided_synthesis) sharded over the
+        ranks: rank r runs clips r, r + W, ... with NO collective inside the DDIM loop; the decoded clips are gathered on
+        rank 0 with one all_gather.  Returns the list of results on rank 0, None elsewhere; with one
+        process it is a plain loop.  Clip i is seeded with opts.seed + i, so the result does not depend on the world size
+        (clip 0 equals the single-process run; later clips differ from the reference's sequential generator stream)."""
+        _, world = parallel.rank_world()
+
+        def one(clip, index):
+            if world > 1 or index > 0:
+                torch.manual_seed(self.opts.seed + index)
+            return self.run_diffusion(clip)
+        return parallel.run_sharded(one, list(clips), gather=True)
+
     def nvs_from_renderings(self, path):
-        """Diffusion leg only: `path` holds point-cloud renders [T, H, W, 3] in [0, 1] (.pt or .npy)."""
-        r = torch.load(path) if path.endswith(".pt") else torch.from_numpy(np.load(path))
-        out = self.run_diffusion(r.float())
-        torch.save(out.cpu(), os.path.join(self.opts.save_dir, "diffusion0.pt"))
-        # like the reference's nvs_single_view (viewcrafter.py:118-121): write the generated clip as a video as well
+        """Diffusion leg only: `path` holds point-cloud renders [T, H, W, 3] in [0, 1] (.pt or .npy) - or several
+        trajectories, as a comma-separated list of such files or one [N, T, H, W, 3] tensor; those are sharded over the
+        ranks of a torchrun launch (run_diffusion_many).  Rank 0 writes diffusion<i>.pt / .mp4."""
         from viewcrafter_amd.utils.video_io import save_video
-        save_video((out + 1.0) / 2.0, os.path.join(self.opts.save_dir, "diffusion0.mp4"), fps=10, value_range=(0.0, 1.0))
-        return out
+
+        def load(p):
+            return (torch.load(p) if p.endswith(".pt") else torch.from_numpy(np.load(p))).float()
+        clips = []
+        for p in path.split(","):
+            r = load(p.strip())
+            clips.extend(list(r) if r.dim() == 5 else [r])
+        rank, _ = parallel.rank_world()
+        outs = self.run_diffusion_many(clips)
+        if rank == 0:
+            for i, out in enumerate(outs):
+                torch.save(out.cpu(), os.path.join(self.opts.save_dir, f"diffusion{i}.pt"))
+                # like the reference's nvs_single_view (viewcrafter.py:118-121): write the generated clip as a video as well
+                save_video((out + 1.0) / 2.0, os.path.join(self.opts.save_dir, f"diffusion{i}.mp4"), fps=10, value_range=(0.0, 1.0))
+        return outs[0] if (rank == 0 and len(clips) == 1) else outs
 
     # ------------------------------------------------------------------ geometry stages (reference)
     def _attach_reference_geometry(self):
@@ -92,10 +124,15 @@ class ViewCrafter:
         ours = self
 
         class _Geometry(mod.ViewCrafter):
+            _record = None                      # a list: run_diffusion only records its clips (multi-GPU sparse-view mode)
+
             def setup_diffusion(self):          # the diffusion model is ours
                 self.diffusion, self.noise_shape = ours.diffusion, ours.noise_shape
 
             def run_diffusion(self, renderings):
+                if self._record is not None:
+                    self._record.append(renderings)
+                    return torch.zeros_like(renderings)
                 return ours.run_diffusion(renderings)
         self._ref = _Geometry(self.opts, gradio=self.gradio)
 
@@ -103,7 +140,26 @@ class ViewCrafter:
         return self._ref.nvs_single_view(gradio)
 
     def nvs_sparse_view_interp(self):
-        return self._ref.nvs_sparse_view_interp()
+        """Reference viewcrafter.py:196-277.  Its (N - 1) clips are independent `run_diffusion` calls (:272-274): under a
+        torchrun launch the reference's method runs in recording mode on every rank (DUSt3R and the render are the
+        reference's and deterministic; the clips are only collected), then the clips are sharded over the GPUs and rank 0
+        writes diffusion.mp4 - instead of (N - 1) sequential 11 s generations on one GPU."""
+        rank, world = parallel.rank_world()
+        if world == 1:
+            return self._ref.nvs_sparse_view_interp()
+        from viewcrafter_amd.utils.video_io import save_video
+        clips = []
+        self._ref._record = clips
+        try:
+            self._ref.nvs_sparse_view_interp()
+        finally:
+            self._ref._record = None
+        outs = self.run_diffusion_many(clips)
+        if rank != 0:
+            return None
+        result = torch.cat(outs)
+        save_video((result + 1.0) / 2.0, os.path.join(self.opts.save_dir, "diffusion.mp4"), fps=10, value_range=(0.0, 1.0))
+        return result
 
     def nvs_single_view_eval(self):
         return self._ref.nvs_single_view_eval()

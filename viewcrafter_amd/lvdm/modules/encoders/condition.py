@@ -90,9 +90,12 @@ class _CLIP(nn.Module):
 
     def __init__(self, arch, keep):
         super().__init__()
-        if arch not in CLIP_CONFIGS:
+        if isinstance(arch, dict):          # an open_clip model_config given inline (YAML `params: {arch: {...}}`; the tests' tiny towers)
+            cfg = arch
+        elif arch in CLIP_CONFIGS:
+            cfg = CLIP_CONFIGS[arch]
+        else:
             raise KeyError(f"unknown CLIP arch {arch!r}; known: {sorted(CLIP_CONFIGS)}")
-        cfg = CLIP_CONFIGS[arch]
         v, t = cfg["vision"], cfg["text"]
         if keep == "visual":
             self.visual = _Visual(v["image_size"], v["patch_size"], v["width"], v["layers"], v["width"] // v["head_width"],

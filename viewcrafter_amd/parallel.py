@@ -35,6 +35,11 @@ def init_distributed(backend=None):
     return dist.get_rank(), dist.get_world_size()
 
 
+def rank_world():
+    """(rank, world size) of the current process group, (0, 1) without one."""
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+
+
 def shard_indices(n_items, rank, world):
     """Round-robin ownership: rank r owns items r, r+W, ...  (balanced to within one item)."""
     return list(range(rank, n_items, world))
@@ -115,3 +120,13 @@ def run_sharded(fn, items, gather=True):
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     local = {i: fn(items[i], i) for i in shard_indices(len(items), rank, world)}
     return gather_results(local, len(items)) if gather else local
+
+
+def shutdown(barrier=True):
+    """(Barrier +) destroy_process_group when a group exists (end of a torchrun launch)."""
+    if dist.is_initialized():
+        try:
+            if barrier:
+                dist.barrier()
+        finally:
+            dist.destroy_process_group()
