@@ -35,8 +35,24 @@ tconv(320, 9216); tconv(1280, 576)
 lin(460800, 320, 320, res=True); lin(460800, 960, 320); lin(460800, 320, 1280, res=True)
 lin(115200, 640, 640, res=True); lin(28800, 1280, 5120, res=True); lin(28800, 3840, 1280)
 geglu(460800, 320); geglu(115200, 640); geglu(28800, 1280)
-tot = 0
-for name, fn, fl in cases:
-    ms = timeit(fn); tot += ms
-    print(f"{name:34s} {ms:8.3f} ms {fl/ms/1e9:8.0f} TF/s")
-print(f"sum {tot:.3f} ms")
+lin(28800, 1280, 1280, res=True); lin(115200, 640, 2560, res=True); lin(460800, 640, 320)
+conv(1280, 9, 16); tconv(640, 2304)
+# A/B of VCX_GEMM_TUNE values given on the command line (read per call by vcx_gemm_f16), interleaved rounds, median and min
+tunes = [int(a) for a in sys.argv[1:]] or [0]
+rounds = 3
+res = {t: [[] for _ in cases] for t in tunes}
+for r in range(rounds):
+    for t in tunes:
+        os.environ["VCX_GEMM_TUNE"] = str(t)
+        for i, (name, fn, fl) in enumerate(cases):
+            res[t][i].append(timeit(fn, iters=6))
+med = lambda v: sorted(v)[len(v) // 2]
+print(f"{'problem':34s} " + " ".join(f"{'tune ' + str(t) + ' ms (min)':>22s} {'TF/s':>6s}" for t in tunes))
+tot = {t: 0.0 for t in tunes}
+for i, (name, fn, fl) in enumerate(cases):
+    row = f"{name:34s} "
+    for t in tunes:
+        m = med(res[t][i]); tot[t] += m
+        row += f"{m:12.3f} ({min(res[t][i]):7.3f}) {fl/m/1e9:6.0f} "
+    print(row)
+print(f"{'sum':34s} " + " ".join(f"{tot[t]:12.3f} {'':17s}" for t in tunes))

@@ -458,8 +458,9 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const int bn = use160 ? 160 : 128;
     a.tiles_m = (d->M + BM - 1) / BM;
     a.tiles_n = (d->N + bn - 1) / bn;
-    static const int tune = []() { const char* e = getenv("VCX_GEMM_TUNE"); return e ? atoi(e) : 0; }();
-    a.tune = tune;
+    // experiment bits, read per call so that one process can A/B variants (tools/gemm_quick.py): 1 = lock-step gemm_dma.hip
+    // main loop for the 256-row tiles instead of the phase-split gemm_pp.hip one, 2 = s_setprio around the MFMA slots
+    { const char* e = getenv("VCX_GEMM_TUNE"); a.tune = e ? atoi(e) : 0; }
     a.m_begin = 0;
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * (double)d->N * d->K;
@@ -496,6 +497,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
         const int tbm = cfg >= 2 ? 256 : 128, tbn = cfg == 0 ? 128 : cfg == 1 ? 160 : cfg == 2 ? 256 : 320;
         a.tiles_m = (d->M + tbm - 1) / tbm;
         a.tiles_n = (d->N + tbn - 1) / tbn;
+        auto big = [&](GemmArgs& g, int c) { return (g.tune & 1) ? launch_dma(g, c, conv, geglu, f32, s) : launch_pp(g, c, conv, geglu, f32, s); };
         if (cfg >= 2) {
             // Large tiles run one block per CU: a partial last round of 256-row tiles costs a full tile time.  When the
             // remainder is small, finish the full rounds with large tiles and hand the tail rows to the small-tile config.
@@ -509,7 +511,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
                     GemmArgs b = a;
                     b.M = m1;
                     b.tiles_m = tm1;
-                    int rc = launch_dma(b, cfg, conv, geglu, f32, s);
+                    int rc = big(b, cfg);
                     if (rc) return rc;
                     GemmArgs c = a;
                     const int scfg = (geglu || d->N % 160 != 0) ? 0 : 1;
@@ -521,7 +523,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
                 }
             }
         }
-        return launch_dma(a, cfg, conv, geglu, f32, s);
+        return cfg >= 2 ? big(a, cfg) : launch_dma(a, cfg, conv, geglu, f32, s);
     }
     return use160 ? dispatch<160>(a, conv, geglu, f32, s) : dispatch<128>(a, conv, geglu, f32, s);
 }

@@ -73,5 +73,6 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
 
 int persistent_grid(int ntiles, int blocks_per_cu = 2);
 int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);
+int launch_pp(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);   // gemm_pp.hip: phase-split main loop, cfg 2 / 3
 
 }  // namespace vcxgemm

@@ -15,7 +15,7 @@
 // Eligibility (checked by vcx_gemm_f16, which falls back to gemm.hip otherwise): K % 64 == 0, N % 8 == 0 (N % 4 for the
 // GEGLU and fp32 epilogues), operand / output extents < 4 GiB (32-bit buffer offsets), convolutions with cin % 64 == 0 (a
 // K-step then lies inside one tap, so the tap is block-uniform); stride-2, (3,1,1) and fused nearest-2x taps included.
-#include "gemm_args.h"
+#include "gemm_epilogue.h"
 
 using namespace vcxgemm;
 
@@ -191,7 +191,6 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
     __builtin_amdgcn_s_waitcnt(0x0f70 | 0);   // vmcnt(0) (lgkmcnt/expcnt untouched): first tile landed in LDS
     __syncthreads();
     int cur = 0;
-    const int flags = p.flags;
     for (;;) {
         if (++lkt == nk) {
             lkt = 0;
@@ -238,205 +237,8 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
             }
         }
         if (ckt == nk - 1) {
-            // ---- epilogue: acc[a][b][r] = out[m][n], m = tile_m*BM + wm*64 + b*16 + lr, n = tile_n*BN + wn*(BN/2) + a*16 + lg*4 + r
-            const int mbase = p.m_begin + tile_m * TBM + wm * WM + lr;
-            const int nbase = tile_n * BN + wn * WN + lg * 4;
-            if (GEGLU) {
-                // Packed GEGLU weights come in 64-column blocks [32 value | 32 gate] (packing.py): of a wave's fragments, 4j and
-                // 4j + 1 are values, 4j + 2 and 4j + 3 their gates; output fragment a = 2j + i pairs xfrag(a) with xfrag(a) + 2.
-                auto xfrag = [](int a) { return 4 * (a >> 1) + (a & 1); };
-                f4 bx[NFRAG / 2 + 1], bg[NFRAG / 2 + 1];
-#pragma unroll
-                for (int a = 0; a < NFRAG / 2; ++a) {
-                    const int nx = min(nbase + xfrag(a) * 16, p.N - 36);
-                    bx[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nx) : f4{0.f, 0.f, 0.f, 0.f};
-                    bg[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nx + 32) : f4{0.f, 0.f, 0.f, 0.f};
-                }
-                // output through a buffer descriptor (rows >= M dropped by the range check), fragment pairs widened to dwordx4
-                // with v_permlane16_swap exactly as in the plain epilogue below
-                typedef unsigned u2v __attribute__((ext_vector_type(2)));
-                typedef unsigned u4v __attribute__((ext_vector_type(4)));
-                const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
-                constexpr int NOUT = NFRAG / 2;                       // output fragments per wave (value x gate pairs)
-                const int jstrip = tile_n * (BN / 2) + wn * (WN / 2);    // first output column of the wave
-                const unsigned coff0 = ((unsigned)mbase * (unsigned)p.ldc + (unsigned)jstrip) * 2u;
-                const unsigned cstep = 32u * (unsigned)p.ldc;
-                const unsigned odd = lg & 1, half = lg >> 1;
-#pragma unroll
-                for (int b = 0; b < MFRAG; ++b) {
-                    u2v packed[NOUT];
-#pragma unroll
-                    for (int a = 0; a < NOUT; ++a) {
-                        half_t o[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float xv = acc[xfrag(a)][b][r] * p.alpha + bx[a][r];
-                            const float gv = acc[xfrag(a) + 2][b][r] * p.alpha + bg[a][r];
-                            o[r] = (half_t)(xv * gelu_erf(gv));
-                        }
-                        packed[a] = __builtin_bit_cast(u2v, h4{o[0], o[1], o[2], o[3]});
-                    }
-                    const unsigned crow = coff0 + (unsigned)b * cstep;
-#pragma unroll
-                    for (int a = 0; a < NOUT; a += 2) {
-                        if (a + 1 < NOUT) {
-                            const unsigned a0 = packed[a][0], a1 = packed[a][1], b0 = packed[a + 1][0], b1 = packed[a + 1][1];
-                            const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-                            const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                            const int col = (a + (int)odd) * 16 + (int)half * 8;             // 8 output columns of this lane
-                            const int nx = tile_n * BN + wn * WN + xfrag(a + (int)odd) * 16;  // packed-space column of the fragment's values
-                            const unsigned voff = nx + 48 <= p.N ? crow + (unsigned)col * 2u : OOB;
-                            __builtin_amdgcn_raw_buffer_store_b128(u4v{s0[0], s1[0], s0[1], s1[1]}, srd_c, voff, 0, 0);
-                        } else {
-                            const int nx = tile_n * BN + wn * WN + xfrag(a) * 16;
-                            const unsigned voff = nx + 48 <= p.N ? crow + (unsigned)(a * 16 + lg * 4) * 2u : OOB;
-                            __builtin_amdgcn_raw_buffer_store_b64(packed[a], srd_c, voff, 0, 0);
-                        }
-                    }
-                }
-            } else {
-                // Output and residual are addressed through buffer descriptors: rows >= M fall outside the extent (stores
-                // dropped, loads return 0), columns >= N get an out-of-range offset - no exec-mask branches, one 32-bit
-                // VALU add per access.  Column-fragment outer / 16-row group inner keeps one bias vector (4 registers) live,
-                // and the residual fetch runs RD accesses ahead of its use (C may alias R, so the compiler cannot hoist
-                // loads above earlier stores by itself; issuing them early here hides the memory round trip).
-                constexpr int ES = OUT_F32 ? 4 : 2;
-                const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
-                const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.R), 0, (int)p.r_bytes, 0x00020000);
-                const unsigned cstep = 16u * (unsigned)p.ldc * ES, rstep = 32u * (unsigned)p.ldr;
-                const bool has_res = flags & VCX_GEMM_RESIDUAL;
-                // a row-indexed addend (time embedding) is one row for the whole tile except where a tile straddles two frames
-                const int m_first = p.m_begin + tile_m * TBM;
-                const int radd_row = m_first / p.rowadd_div;
-                const bool radd_tile = (flags & VCX_GEMM_ROWADD) && (min(m_first + TBM, p.M) - 1) / p.rowadd_div == radd_row;
-                const bool per_row = (flags & VCX_GEMM_BIAS_M) || ((flags & VCX_GEMM_ROWADD) && !radd_tile);
-                typedef unsigned u2v __attribute__((ext_vector_type(2)));
-                typedef unsigned u4v __attribute__((ext_vector_type(4)));
-                // Wide accesses.  Lane (lr, lg) holds 4 columns (8 bytes of fp16) of row lr per fragment, the lanes lg = 0..3 of a
-                // row four adjacent such pieces.  v_permlane16_swap exchanges the odd 16-lane rows of one register with the even
-                // rows of another: applied to the packed words of fragments a (vdst) and a+1 (src) it leaves the even-lg lanes with
-                // 8 contiguous columns of fragment a and the odd-lg lanes with 8 contiguous columns of fragment a+1 - one dwordx4
-                // store (and, run backwards, one dwordx4 residual fetch) per lane and fragment PAIR instead of a dwordx2 per
-                // fragment.  The store tail of a tile is issue-bound (MI355X_MICROARCH.md / T21 of the HIP guide): fewer,
-                // wider instructions shorten it.  An odd last fragment keeps the dwordx2 form.
-                constexpr int NPAIRF = OUT_F32 ? 0 : NFRAG / 2;                 // fragment pairs handled wide (fp16 output only)
-                constexpr int UNITS = NPAIRF + (NFRAG - 2 * NPAIRF);            // accesses per 16-row group
-                constexpr int NUNIT = UNITS * MFRAG;
-                constexpr int RDU = UNITS;                                       // residual prefetch distance: one 16-row group
-                const unsigned odd = lg & 1, half = lg >> 1;
-                // byte offset (within the row, relative to the wave's strip) of this lane's access for unit u
-                auto unit_col = [&](int u) { return u < NPAIRF ? (2 * u + (int)odd) * 16 + (int)half * 8 : (2 * NPAIRF + (u - NPAIRF)) * 16 + lg * 4; };
-                const int nstrip = tile_n * BN + wn * WN;
-                const unsigned coff0 = ((unsigned)mbase * (unsigned)p.ldc + (unsigned)nstrip) * ES;
-                const unsigned roff0 = ((unsigned)mbase * (unsigned)p.ldr + (unsigned)nstrip) * 2u;
-                u4v rr[RDU];                 // residual ring, one entry per unit (a narrow unit uses the first two words)
-                // unit i = b * UNITS + u: all units of one 16-row group back to back, so that every 128-byte line of C is
-                // completed within a few consecutive stores (half-written lines that linger get evicted from L2; measured 1.5x
-                // slower with the loops the other way round).  The residual fetch runs one row group ahead of its use: C may
-                // alias R, so the compiler cannot hoist loads above earlier stores by itself.
-                auto fetch = [&](int i) {
-                    const int u = i % UNITS;
-                    const unsigned o = roff0 + (unsigned)(i / UNITS) * rstep + (unsigned)unit_col(u) * 2u;
-                    if (u < NPAIRF) rr[i % RDU] = __builtin_amdgcn_raw_buffer_load_b128(srd_r, o, 0, 0);
-                    else {
-                        const u2v t = __builtin_amdgcn_raw_buffer_load_b64(srd_r, o, 0, 0);
-                        const unsigned t0 = t[0], t1 = t[1];
-                        rr[i % RDU] = u4v{t0, t1, 0u, 0u};
-                    }
-                };
-                if (has_res) {
-#pragma unroll
-                    for (int i = 0; i < RDU; ++i) fetch(i);
-                }
-                // Column addends (bias, plus the tile's time-embedding row when it is uniform over the tile) live in a private
-                // LDS strip of the wave, not in registers: a 160-column strip would pin 40 VGPRs through the whole epilogue.
-                float* sB = reinterpret_cast<float*>(smem_raw + Cfg::STAGES) + wave * WN;
-                if (lane < WN / 4) {
-                    const int nc = min(nstrip + lane * 4, p.N - 4);
-                    f4 t = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nc) : f4{0.f, 0.f, 0.f, 0.f};
-                    if (radd_tile) {
-                        const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)radd_row * p.N + nc);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) t[r] += rv[r];
-                    }
-                    *reinterpret_cast<f4*>(sB + lane * 4) = t;
-                }
-                int bopaque = 0;     // re-read per 16-row group (an address the compiler cannot prove loop-invariant)
-                // value of accumulator fragment (a, b) with bias / addend applied (everything but the residual)
-                auto finish = [&](int a, int b, float (&v)[4]) {
-                    if (per_row) {      // rare: V^T projections (per-row bias) and tiles that straddle two addend rows
-                        // same arithmetic as the tile-uniform case, (bias + addend) first and one fma: a row's result must
-                        // not depend on how the batch happens to align tiles with frames (bit-exact batch invariance)
-                        const int mc = min(mbase + b * 16, p.M - 1);
-                        f4 t = *reinterpret_cast<const f4*>(sB + bopaque + a * 16 + lg * 4);
-                        if (flags & VCX_GEMM_ROWADD) {
-                            const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)(mc / p.rowadd_div) * p.N + min(nbase + a * 16, p.N - 4));
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) t[r] += rv[r];
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[a][b][r], p.alpha, t[r]);
-                        if (flags & VCX_GEMM_BIAS_M) {
-                            const float bm = p.bias[mc];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += bm;
-                        }
-                    } else {
-                        const f4 t = *reinterpret_cast<const f4*>(sB + bopaque + a * 16 + lg * 4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[a][b][r], p.alpha, t[r]);
-                    }
-                };
-#pragma unroll
-                for (int b = 0; b < MFRAG; ++b) {
-                    const unsigned crow = coff0 + (unsigned)b * cstep;
-                    asm volatile("" : "+v"(bopaque));
-#pragma unroll
-                    for (int u = 0; u < UNITS; ++u) {
-                        const int i = b * UNITS + u;
-                        const bool wide = u < NPAIRF;
-                        const int a = wide ? 2 * u : 2 * NPAIRF + (u - NPAIRF);
-                        const unsigned voff = nstrip + unit_col(u) < p.N ? crow + (unsigned)unit_col(u) * ES : OOB;
-                        float v0[4], v1[4] = {0.f, 0.f, 0.f, 0.f};
-                        finish(a, b, v0);
-                        if (wide) finish(a + 1, b, v1);
-                        if (has_res) {
-                            const u4v raw = rr[i % RDU];
-                            if (i + RDU < NUNIT) fetch(i + RDU);
-                            unsigned w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
-                            if (wide) {
-                                // the fetched 8 columns are [piece of the even lane | piece of the odd lane] of ONE fragment: undo
-                                // the exchange so that each lane gets its own pieces of fragments a (w0, w1) and a + 1 (w2, w3)
-                                const auto s0 = __builtin_amdgcn_permlane16_swap(w0, w2, false, false);
-                                const auto s1 = __builtin_amdgcn_permlane16_swap(w1, w3, false, false);
-                                w0 = s0[0]; w2 = s0[1]; w1 = s1[0]; w3 = s1[1];
-                            }
-                            const h4 r0 = __builtin_bit_cast(h4, u2v{w0, w1});
-                            const h4 r1 = __builtin_bit_cast(h4, u2v{w2, w3});
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { v0[r] += (float)r0[r]; v1[r] += (float)r1[r]; }
-                        }
-                        if (OUT_F32) {
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, f4{v0[0], v0[1], v0[2], v0[3]}), srd_c, voff, 0, 0);
-                        } else {
-                            const h4 o0 = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]};
-                            const u2v p0 = __builtin_bit_cast(u2v, o0);
-                            if (wide) {
-                                const h4 o1 = {(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
-                                const u2v p1 = __builtin_bit_cast(u2v, o1);
-                                const unsigned a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1];
-                                // vdst = fragment a, src = fragment a + 1: even lanes end up with [own a | odd lane's a],
-                                // odd lanes with [even lane's a+1 | own a+1]
-                                const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-                                const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                                __builtin_amdgcn_raw_buffer_store_b128(u4v{s0[0], s1[0], s0[1], s1[1]}, srd_c, voff, 0, 0);
-                            } else {
-                                __builtin_amdgcn_raw_buffer_store_b64(p0, srd_c, voff, 0, 0);
-                            }
-                        }
-                    }
-                }
-            }
+            float* sB = reinterpret_cast<float*>(smem_raw + Cfg::STAGES) + wave * WN;   // the wave's private strip of column addends
+            gemm_epilogue<Cfg, GEGLU, OUT_F32>(p, acc, tile_m, tile_n, wm, wn, lane, sB);
 #pragma unroll
             for (int a = 0; a < NFRAG; ++a)
 #pragma unroll

@@ -23,30 +23,29 @@ __device__ __forceinline__ void gn_merge(float& na, float& ma, float& qa, float 
 
 __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ partials, int64_t pixels, int C, int groups,
                                 int64_t pix_per_block, int cw, int pl) {
-    // Numerically robust and deterministic (no atomics).  A thread sums x - K and (x - K)^2 with K = the first value it sees
-    // (so |mean| >> std does not cancel: torch's GroupNorm is Welford too), turns that into (count, mean, M2) and from
-    // there everything is merged Chan-style in a fixed order: pixel lanes -> a group's channels -> partials[n][chunk]
-    // [group][3]; gn_finalize_kernel merges the chunks in order.
-    extern __shared__ float red[];                      // [pl][C][2] (mean, M2) + [pl] counts
+    // Numerically robust and deterministic (no atomics).  Inside a block everything is summed relative to a shift K_g that
+    // is uniform per (block, group) - the group's first channel at the block's first pixel, i.e. a sample of the data - so
+    // |mean| >> std does not cancel (torch's GroupNorm is Welford too) while the partial sums of the pixel lanes and of a
+    // group's channels still simply add, in a fixed order: per-thread channel sums -> LDS -> pixel lanes -> channels of the
+    // group -> (count, mean, M2) of the block in partials[n][chunk][group][3]; gn_finalize_kernel merges the chunks
+    // Chan-style in order.
+    extern __shared__ float red[];                      // [pl][C][2] then reused as [C][2]
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = (p0 + pix_per_block < pixels) ? p0 + pix_per_block : pixels;
     const int cpg = C / groups;
     const int c8 = tid % cw, plane = tid / cw;
-    const half_t* xp = x + ((int64_t)n * pixels) * C + c8 * 8;
-    float* cnts = red + (size_t)pl * C * 2;
+    const half_t* xn = x + ((int64_t)n * pixels) * C;
+    const half_t* xp = xn + c8 * 8;
     float s[8], ss[8], K[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; K[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) {
+        s[e] = 0.f; ss[e] = 0.f;
+        K[e] = (float)xn[p0 * C + ((c8 * 8 + e) / cpg) * cpg];
+    }
     int64_t pix = p0 + plane;
     const int64_t step = pl;
-    const int64_t mine = pix < p1 ? (p1 - pix + step - 1) / step : 0;       // pixels this thread owns
-    if (mine > 0) {
-        const h8 v = *reinterpret_cast<const h8*>(xp + pix * C);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) K[e] = (float)v[e];
-    }
     for (; pix + 3 * step < p1; pix += 4 * step) {
         h8 v[4];
 #pragma unroll
@@ -69,53 +68,58 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
             ss[e] += f * f;
         }
     }
-    const float cnt = (float)mine, inv = mine > 0 ? 1.0f / cnt : 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float m = s[e] * inv;
-        red[((size_t)plane * C + c8 * 8 + e) * 2 + 0] = K[e] + m;
-        const float q = ss[e] - s[e] * m;
-        red[((size_t)plane * C + c8 * 8 + e) * 2 + 1] = q > 0.f ? q : 0.f;
+        red[((size_t)plane * C + c8 * 8 + e) * 2 + 0] = s[e];
+        red[((size_t)plane * C + c8 * 8 + e) * 2 + 1] = ss[e];
     }
-    if (c8 == 0) cnts[plane] = cnt;
     __syncthreads();
     for (int c = tid; c < C; c += blockDim.x) {          // pixel lanes, in order
-        float na = cnts[0], a = red[(size_t)c * 2], q = red[(size_t)c * 2 + 1];
-        for (int p = 1; p < pl; ++p) gn_merge(na, a, q, cnts[p], red[((size_t)p * C + c) * 2], red[((size_t)p * C + c) * 2 + 1]);
+        float a = red[(size_t)c * 2], q = red[(size_t)c * 2 + 1];
+        for (int p = 1; p < pl; ++p) {
+            a += red[((size_t)p * C + c) * 2];
+            q += red[((size_t)p * C + c) * 2 + 1];
+        }
         red[(size_t)c * 2] = a;
         red[(size_t)c * 2 + 1] = q;
     }
     __syncthreads();
-    if (tid < groups) {                                   // channels of the group, in order (equal counts)
-        const float nc = (float)(p1 - p0);
-        float na = 0.f, a = 0.f, q = 0.f;
-        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) gn_merge(na, a, q, nc, red[(size_t)c * 2], red[(size_t)c * 2 + 1]);
+    if (tid < groups) {                                   // channels of the group, in order
+        float a = 0.f, q = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+            a += red[(size_t)c * 2];
+            q += red[(size_t)c * 2 + 1];
+        }
+        const float cnt = (float)((p1 - p0) * cpg);
+        const float m = a / cnt;
+        const float m2 = q - a * m;
         float* dst = partials + (((int64_t)n * gridDim.x + blockIdx.x) * groups + tid) * 3;
-        dst[0] = na;
-        dst[1] = a;
-        dst[2] = q;
+        dst[0] = cnt;
+        dst[1] = (float)xn[p0 * C + tid * cpg] + m;
+        dst[2] = m2 > 0.f ? m2 : 0.f;
     }
 }
 
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int chunks,
                                                           int groups) {
-    // fixed merge tree: wave q folds the chunks c = q, q+4, q+8, ... in order, then the four wave results are folded in order.
-    // stats[n][g] = (mean, biased variance).
-    __shared__ float red[4][64][3];
-    const int n = blockIdx.x, q = threadIdx.x >> 6, g = threadIdx.x & 63;
-    if (g < groups) {
+    // fixed merge tree: thread (q, g), q < nq = 256 / groups, folds the chunks c = q, q + nq, q + 2 nq, ... of group g in
+    // order (Chan), then the nq results of a group are folded in order.  stats[n][g] = (mean, biased variance).
+    __shared__ float red[256][3];
+    const int n = blockIdx.x, nq = 256 / groups;
+    const int g = threadIdx.x % groups, q = threadIdx.x / groups;
+    if (q < nq) {
         const float* src = partials + ((int64_t)n * chunks * groups + g) * 3;
         float na = 0.f, a = 0.f, m2 = 0.f;
-        for (int c = q; c < chunks; c += 4) {
+        for (int c = q; c < chunks; c += nq) {
             const float* t = src + (int64_t)c * groups * 3;
             gn_merge(na, a, m2, t[0], t[1], t[2]);
         }
-        red[q][g][0] = na; red[q][g][1] = a; red[q][g][2] = m2;
+        red[q * groups + g][0] = na; red[q * groups + g][1] = a; red[q * groups + g][2] = m2;
     }
     __syncthreads();
     if (threadIdx.x < groups) {
-        float na = red[0][g][0], a = red[0][g][1], m2 = red[0][g][2];
-        for (int w = 1; w < 4; ++w) gn_merge(na, a, m2, red[w][g][0], red[w][g][1], red[w][g][2]);
+        float na = red[g][0], a = red[g][1], m2 = red[g][2];
+        for (int w = 1; w < nq; ++w) gn_merge(na, a, m2, red[w * groups + g][0], red[w * groups + g][1], red[w * groups + g][2]);
         stats[((int64_t)n * groups + g) * 2 + 0] = a;
         stats[((int64_t)n * groups + g) * 2 + 1] = na > 0.f ? m2 / na : 0.f;
     }
@@ -128,15 +132,16 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
     const int n = blockIdx.y;
     const int cpg = C / groups;
     const int c8 = tid % cw, plane = tid / cw;
-    float sc[8], sh[8], mu[8];      // (x - mean) * sc + beta: subtracting first keeps |mean| >> std exact
-#pragma unroll
+    float sc[8], sh[8];             // x * sc + (beta - mean * sc): one fma per element; the rounding of mean * sc costs
+#pragma unroll                      // 1e-7 |mean| / std of the output scale - below the fp16 output step up to |mean| ~ 1000 std
     for (int e = 0; e < 8; ++e) {
         const int c = c8 * 8 + e;
         const int g = c / cpg;
-        mu[e] = stats[((int64_t)n * groups + g) * 2 + 0];
+        const float mean = stats[((int64_t)n * groups + g) * 2 + 0];
         const float var = stats[((int64_t)n * groups + g) * 2 + 1];
-        sc[e] = rsqrtf(var + eps) * gamma[c];
-        sh[e] = beta[c];
+        const float a = rsqrtf(var + eps) * gamma[c];
+        sc[e] = a;
+        sh[e] = beta[c] - mean * a;
     }
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = (p0 + pix_per_block < pixels) ? p0 + pix_per_block : pixels;
@@ -152,7 +157,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float f = ((float)v[u][e] - mu[e]) * sc[e] + sh[e];
+                float f = (float)v[u][e] * sc[e] + sh[e];
                 if (silu) f = vcx_silu(f);
                 v[u][e] = (half_t)f;
             }
@@ -163,7 +168,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
         h8 v = *reinterpret_cast<const h8*>(xp + pix * C);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = ((float)v[e] - mu[e]) * sc[e] + sh[e];
+            float f = (float)v[e] * sc[e] + sh[e];
             if (silu) f = vcx_silu(f);
             v[e] = (half_t)f;
         }
@@ -279,7 +284,7 @@ extern "C" int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, in
     dim3 grid((unsigned)chunks, n_outer);
     int cw, pl;
     gn_geometry(C, cw, pl);
-    const size_t smem = sizeof(float) * (2 * (size_t)pl * C + pl);
+    const size_t smem = sizeof(float) * 2 * (size_t)pl * C;
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(cw * pl), smem, s, (const half_t*)x, (float*)ws, pixels, C, groups, ppb, cw, pl);
     int rc = vcx_check_launch("vcx_groupnorm_stats_f16");
     if (rc) return rc;
