@@ -61,7 +61,7 @@ def synth_conditioning(T, h, w, device, seed=123, B=1):
     return x_T.to(device), cond, uc
 
 
-def cpu_baseline(model, hp, flops_per_step_full, budget_s=60.0):
+def cpu_baseline(model, hp, flops_per_step_full, budget_s=100.0):
     """The fp32 oracle (oracle/lvdm_oracle.py, a port of the reference algorithm) timed on the host cores for one UNet forward
     at BASELINE configs[0]'s shapes (16 frames, 40x64 latent, the full 1.44 B-parameter width), after a
     small warm-up call; one DDIM step = 2 forwards; FLOP-scaled to the bench workload (labelled extrapolated).  A host too
