@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the timed region")
     ap.add_argument("--no-gpu-legs", action="store_true", help="skip parity-vs-oracle and the eager fp16 baseline on the GPU")
     ap.add_argument("--no-video", action="store_true", help="skip the measured 50-step video after the timed region")
+    ap.add_argument("--no-shared-prefix", action="store_true", help="evaluate cond and uncond as a plain B=2 forward (A/B of the "
+                    "shared CFG prefix: the layers ahead of the first cross-attention see identical inputs and run once by default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,6 +211,7 @@ def main():
     sampler = DDIMSampler(model)
     sampler.make_schedule(ddim_num_steps=50, ddim_discretize="uniform_trailing", ddim_eta=1.0, verbose=False)
     sampler._cfg_cache = None
+    sampler.share_cfg_prefix = not args.no_shared_prefix
     n_sched = len(sampler.ddim_timesteps)
     assert args.warmup + args.steps <= n_sched, "warmup + steps must fit the 50-step schedule"
 
@@ -288,7 +291,8 @@ def main():
         "dtype": "f16", "data": "synthetic", "launch_mode": "hipGraph replay" if args.graph else "eager",
         "roofline_measured_on": "the timed region" if profile_in_region else "extra eager steps after the timed region",
         "config": {"workload": args.workload, "trajectories_per_gpu": 1, "frames": T, "latent": [T, h, w],
-                   "guidance": "CFG 7.5 + rescale 0.7, cond/uncond batched as B=2", "eta": 1.0,
+                   "guidance": "CFG 7.5 + rescale 0.7, cond/uncond batched as B=2" + ("" if args.no_shared_prefix else
+                               "; layers ahead of the first cross-attention (identical inputs in both evaluations) computed once"), "eta": 1.0,
                    "parallelism": f"trajectory-sharded x{world} (no in-step collective)"},
     }
     if rank == 0:

@@ -83,6 +83,46 @@ def test_unet_forward_vs_oracle_fresh_inputs_and_cfg_batching(unet):
     assert torch.equal(m(x, ts, context=ctx, fs=fs), y), "forward is not run-to-run reproducible"
     
 
+@pytest.mark.parametrize("r,t,L", [(2, 4, 77 + 64), (2, 3, 77 + 40), (3, 5, 77 + 24)])
+def test_cfg_shared_prefix_is_bit_identical(unet, r, t, L):
+    """Classifier-free guidance evaluates the denoiser on the same x / t / fs under r conditionings.  With cfg_repeat = r the
+    layers ahead of the first cross-attention run once and the activations are replicated where the conditionings enter
+    (UNetModel._forward): the result must equal the forward of the r-fold replicated batch bit for bit (per-frame and shared
+    image-token branches, r = 2 and the multi-condition r = 3)."""
+    m, _ = unet
+    h, w = 16, 32
+    x = synth_input(f"share_x{r}{t}", (1, 8, t, h, w)).to(DEV)
+    ctx = synth_input(f"share_ctx{r}{t}", (r, L, TINY_UNET["context_dim"])).to(DEV)
+    ts, fs = torch.tensor([659], device=DEV), torch.tensor([10], device=DEV)
+    with torch.no_grad():
+        full = m(torch.cat([x] * r), torch.cat([ts] * r), context=ctx, fs=torch.cat([fs] * r))
+        shared = m(x, ts, context=ctx, fs=fs, cfg_repeat=r)
+        split = m([x[:, :4].contiguous(), x[:, 4:].contiguous()], ts, context=ctx, fs=fs, cfg_repeat=r)   # DiffusionWrapper's [x] + c_concat
+    assert shared.shape == full.shape == (r, 4, t, h, w)
+    assert torch.equal(shared, full) and torch.equal(split, full)
+    assert not torch.equal(full[0], full[1])
+
+
+def test_sampler_uses_the_shared_prefix_only_when_the_conditionings_allow_it(model):
+    from viewcrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    s = DDIMSampler(model)
+    cat = torch.zeros(1, 4, 2, 8, 8, device=DEV)
+    c = {"c_crossattn": [torch.zeros(1, 77, 128, device=DEV)], "c_concat": [cat]}
+    uc_same = {"c_crossattn": [torch.ones(1, 77, 128, device=DEV)], "c_concat": [cat]}
+    uc_other = {"c_crossattn": [torch.ones(1, 77, 128, device=DEV)], "c_concat": [cat.clone()]}
+    assert s._shares_prefix((c, uc_same)) and not s._shares_prefix((c, uc_other))
+    s.share_cfg_prefix = False
+    assert not s._shares_prefix((c, uc_same))
+    # both routes give the same denoiser outputs
+    x, t = synth_input("share_s_x", (1, 4, 2, 8, 8)).to(DEV), torch.tensor([500], device=DEV)
+    fs = torch.tensor([10], device=DEV)
+    with torch.no_grad():
+        a = s._apply_batched(x, t, (c, uc_same), {"fs": fs})
+        s.share_cfg_prefix, s._cfg_cache = True, None
+        b = s._apply_batched(x, t, (c, uc_same), {"fs": fs})
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+
+
 def test_unet_hip_graph_replay_is_bit_identical_to_eager(unet):
     """UNetModel.forward_graphed captures the whole forward (hundreds of ctypes launches into libvcx) in one hipGraph and
     replays it with the inputs copied into static buffers: same bits as the eager launch sequence, also on the second replay

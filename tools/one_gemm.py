@@ -20,6 +20,11 @@ elif kind == "lin":
     w = (torch.randn(320, 320, device=dev) / math.sqrt(320)).half()
     b = torch.randn(320, device=dev)
     fn = lambda: ops.linear(x, w, b, residual=x)
+elif kind == "conv640":
+    x = (torch.randn(50, 36, 64, 640, device=dev)).half()
+    w = pack_conv((torch.randn(640, 640, 3, 3, device=dev) / math.sqrt(5760)).half())
+    b = torch.randn(640, device=dev)
+    fn = lambda: ops.conv2d(x, w, b, kh=3, kw=3)
 elif kind == "big":
     x = torch.randn(28800, 5120, device=dev).half()
     w = (torch.randn(1280, 5120, device=dev) / math.sqrt(5120)).half()

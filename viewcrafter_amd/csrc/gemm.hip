@@ -458,8 +458,9 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const int bn = use160 ? 160 : 128;
     a.tiles_m = (d->M + BM - 1) / BM;
     a.tiles_n = (d->N + bn - 1) / bn;
-    // experiment bits, read per call so that one process can A/B variants (tools/gemm_quick.py): 1 = lock-step gemm_dma.hip
-    // main loop for the 256-row tiles instead of the phase-split gemm_pp.hip one, 2 = s_setprio around the MFMA slots
+    // experiment bits, read per call so that one process can A/B variants (tools/gemm_quick.py): 1 = phase-split gemm_pp.hip
+    // main loop for the 256-row tiles instead of the lock-step gemm_dma.hip one (parity-green, 7 % slower on the model's
+    // shapes: profiles/r02_gemm_experiments.md), 2 = s_setprio around its MFMA slots
     { const char* e = getenv("VCX_GEMM_TUNE"); a.tune = e ? atoi(e) : 0; }
     a.m_begin = 0;
     hipStream_t s = (hipStream_t)stream;
@@ -497,7 +498,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
         const int tbm = cfg >= 2 ? 256 : 128, tbn = cfg == 0 ? 128 : cfg == 1 ? 160 : cfg == 2 ? 256 : 320;
         a.tiles_m = (d->M + tbm - 1) / tbm;
         a.tiles_n = (d->N + tbn - 1) / tbn;
-        auto big = [&](GemmArgs& g, int c) { return (g.tune & 1) ? launch_dma(g, c, conv, geglu, f32, s) : launch_pp(g, c, conv, geglu, f32, s); };
+        auto big = [&](GemmArgs& g, int c) { return (g.tune & 1) ? launch_pp(g, c, conv, geglu, f32, s) : launch_dma(g, c, conv, geglu, f32, s); };
         if (cfg >= 2) {
             // Large tiles run one block per CU: a partial last round of 256-row tiles costs a full tile time.  When the
             // remainder is small, finish the full rounds with large tiles and hand the tail rows to the small-tile config.

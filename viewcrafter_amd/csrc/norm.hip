@@ -15,7 +15,7 @@ constexpr int MAXC = 4096;  // C/8 * pixel lanes must fit one block (<= 512 thre
 __device__ __forceinline__ void gn_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
     if (nb == 0.f) return;
     if (na == 0.f) { na = nb; ma = mb; qa = qb; return; }
-    const float n = na + nb, d = mb - ma, f = nb / n;
+    const float n = na + nb, d = mb - ma, f = nb * __builtin_amdgcn_rcpf(n);    // 1-ulp reciprocal: a weight, not a sum
     ma = ma + d * f;
     qa = qa + qb + d * d * na * f;
     na = n;
@@ -23,33 +23,38 @@ __device__ __forceinline__ void gn_merge(float& na, float& ma, float& qa, float 
 
 __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ partials, int64_t pixels, int C, int groups,
                                 int64_t pix_per_block, int cw, int pl) {
-    // Numerically robust and deterministic (no atomics).  Inside a block everything is summed relative to a shift K_g that
-    // is uniform per (block, group) - the group's first channel at the block's first pixel, i.e. a sample of the data - so
-    // |mean| >> std does not cancel (torch's GroupNorm is Welford too) while the partial sums of the pixel lanes and of a
-    // group's channels still simply add, in a fixed order: per-thread channel sums -> LDS -> pixel lanes -> channels of the
-    // group -> (count, mean, M2) of the block in partials[n][chunk][group][3]; gn_finalize_kernel merges the chunks
-    // Chan-style in order.
-    extern __shared__ float red[];                      // [pl][C][2] then reused as [C][2]
+    // Numerically robust and deterministic (no atomics).  A thread sums x - K_t and (x - K_t)^2 with K_t = the first value it
+    // loads (a sample of the data: |mean| >> std does not cancel - torch's GroupNorm is Welford too - and no load has to be
+    // waited for before the streaming loop starts).  After the loop the sums are re-based algebraically to a shift that is
+    // uniform per (block, group) - the group's first channel at the block's first pixel, handed round through LDS - so that
+    // the partial sums of the pixel lanes and of a group's channels simply add, in a fixed order: per-thread channel sums ->
+    // LDS -> pixel lanes -> channels of the group -> (count, mean, M2) of the block in partials[n][chunk][group][3];
+    // gn_finalize_kernel merges the chunks Chan-style in order.
+    extern __shared__ float red[];                      // [pl][C][2] then reused as [C][2]; + [C] block shifts
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = (p0 + pix_per_block < pixels) ? p0 + pix_per_block : pixels;
     const int cpg = C / groups;
     const int c8 = tid % cw, plane = tid / cw;
-    const half_t* xn = x + ((int64_t)n * pixels) * C;
-    const half_t* xp = xn + c8 * 8;
+    const half_t* xp = x + ((int64_t)n * pixels) * C + c8 * 8;
+    float* kshare = red + (size_t)pl * C * 2;           // x[p0][c] for every channel c (written by pixel lane 0)
     float s[8], ss[8], K[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        s[e] = 0.f; ss[e] = 0.f;
-        K[e] = (float)xn[p0 * C + ((c8 * 8 + e) / cpg) * cpg];
-    }
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; K[e] = 0.f; }
     int64_t pix = p0 + plane;
     const int64_t step = pl;
+    const int64_t mine = pix < p1 ? (p1 - pix + step - 1) / step : 0;       // pixels this thread owns
+    bool first = true;
     for (; pix + 3 * step < p1; pix += 4 * step) {
         h8 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8*>(xp + (pix + u * step) * C);
+        if (first) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) K[e] = (float)v[0][e];
+            first = false;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -61,6 +66,11 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
     }
     for (; pix < p1; pix += step) {
         const h8 v = *reinterpret_cast<const h8*>(xp + pix * C);
+        if (first) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) K[e] = (float)v[e];
+            first = false;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float f = (float)v[e] - K[e];
@@ -68,10 +78,19 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
             ss[e] += f * f;
         }
     }
+    if (plane == 0) {                                    // pixel lane 0 always owns pixel p0: K_t = x[p0][c]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kshare[c8 * 8 + e] = K[e];
+    }
+    __syncthreads();
+    const float cnt_t = (float)mine;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        red[((size_t)plane * C + c8 * 8 + e) * 2 + 0] = s[e];
-        red[((size_t)plane * C + c8 * 8 + e) * 2 + 1] = ss[e];
+        // re-base from K_t to the group's block shift K_b: sum(x - K_b) = S + n d, sum((x - K_b)^2) = Q + 2 d S + n d^2, d = K_t - K_b
+        const float kb = kshare[((c8 * 8 + e) / cpg) * cpg];
+        const float d = K[e] - kb;
+        red[((size_t)plane * C + c8 * 8 + e) * 2 + 0] = s[e] + cnt_t * d;
+        red[((size_t)plane * C + c8 * 8 + e) * 2 + 1] = ss[e] + d * (2.f * s[e] + cnt_t * d);
     }
     __syncthreads();
     for (int c = tid; c < C; c += blockDim.x) {          // pixel lanes, in order
@@ -95,7 +114,7 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
         const float m2 = q - a * m;
         float* dst = partials + (((int64_t)n * gridDim.x + blockIdx.x) * groups + tid) * 3;
         dst[0] = cnt;
-        dst[1] = (float)xn[p0 * C + tid * cpg] + m;
+        dst[1] = kshare[tid * cpg] + m;
         dst[2] = m2 > 0.f ? m2 : 0.f;
     }
 }
@@ -284,7 +303,7 @@ extern "C" int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, in
     dim3 grid((unsigned)chunks, n_outer);
     int cw, pl;
     gn_geometry(C, cw, pl);
-    const size_t smem = sizeof(float) * 2 * (size_t)pl * C;
+    const size_t smem = sizeof(float) * (2 * (size_t)pl * C + C);
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(cw * pl), smem, s, (const half_t*)x, (float*)ws, pixels, C, groups, ppb, cw, pl);
     int rc = vcx_check_launch("vcx_groupnorm_stats_f16");
     if (rc) return rc;

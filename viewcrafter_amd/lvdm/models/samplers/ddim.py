@@ -24,6 +24,9 @@ class DDIMSampler(object):
         self.schedule = schedule
         self.counter = 0
         self._cfg_cache = None          # p_sample_ddim is public (decode() and bench.py call it without ddim_sampling)
+        # classifier-free guidance evaluates the denoiser on the SAME x / t / c_concat under several c_crossattn: the layers
+        # ahead of the first cross-attention are computed once (UNetModel._forward, cfg_repeat) - bit-identical results
+        self.share_cfg_prefix = True
 
     def register_buffer(self, name, attr):
         if isinstance(attr, torch.Tensor):
@@ -142,12 +145,21 @@ class DDIMSampler(object):
                     return False
         return True
 
-    def _cfg_cond(self, *conds):
+    def _shares_prefix(self, conds):
+        """True if the conditionings differ only in c_crossattn (every other entry is the very same tensor object), the
+        denoiser is the native UNet and the optimisation is enabled."""
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        if not self.share_cfg_prefix or not hasattr(unet, "spatial_transformers"):
+            return False
+        return all(all(a is b_ for a, b_ in zip(conds[0][k], c[k])) for c in conds[1:] for k in c if k != "c_crossattn")
+
+    def _cfg_cond(self, *conds, shared=False):
         """[cond ; uncond (; uncond_img)] stacked on the batch axis, built once per sample() call (so that the UNet's
-        context-K/V cache, keyed on tensor identity, hits on every later step)."""
-        key = tuple(id(c) for c in conds)
+        context-K/V cache, keyed on tensor identity, hits on every later step).  shared: only c_crossattn is stacked."""
+        key = tuple(id(c) for c in conds) + (shared,)
         if self._cfg_cache is None or self._cfg_cache[0] != key:
-            both = {k: [torch.cat(parts, dim=0) for parts in zip(*[c[k] for c in conds])] for k in conds[0]}
+            both = {k: (list(conds[0][k]) if (shared and k != "c_crossattn") else
+                        [torch.cat(parts, dim=0) for parts in zip(*[c[k] for c in conds])]) for k in conds[0]}
             self._cfg_cache = (key, both, conds)
         return self._cfg_cache[1]
 
@@ -155,9 +167,12 @@ class DDIMSampler(object):
         """One UNet forward over len(conds) stacked conditionings; returns the per-conditioning outputs."""
         n, b = len(conds), x.shape[0]
         kw = dict(kwargs)
-        if torch.is_tensor(kw.get("fs")):
-            kw["fs"] = torch.cat([kw["fs"]] * n, 0)
-        out = self.model.apply_model(torch.cat([x] * n, 0), torch.cat([t] * n, 0), self._cfg_cond(*conds), **kw)
+        if self._shares_prefix(conds):
+            out = self.model.apply_model(x, t, self._cfg_cond(*conds, shared=True), cfg_repeat=n, **kw)
+        else:
+            if torch.is_tensor(kw.get("fs")):
+                kw["fs"] = torch.cat([kw["fs"]] * n, 0)
+            out = self.model.apply_model(torch.cat([x] * n, 0), torch.cat([t] * n, 0), self._cfg_cond(*conds), **kw)
         return [out[i * b:(i + 1) * b] for i in range(n)]
 
     def _model_outputs(self, x, t, c, unconditional_conditioning, unconditional_guidance_scale, kwargs):

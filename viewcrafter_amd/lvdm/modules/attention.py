@@ -219,8 +219,13 @@ class SpatialTransformer(PackedModule):
     def project_context(self, ctx):
         return [project_context(blk.attn2, ctx) for blk in self.transformer_blocks]
 
-    def forward(self, x, context_kv=None, frames_per_video=1, **kwargs):
-        """x [n, H, W, C] fp16 channels-last, n = b*t frames; context_kv from project_context()."""
+    def forward(self, x, context_kv=None, frames_per_video=1, cfg_repeat=1, **kwargs):
+        """x [n, H, W, C] fp16 channels-last, n = b*t frames; context_kv from project_context().
+        cfg_repeat = r > 1: x holds ONE copy of a batch whose r conditionings (classifier-free guidance: cond / uncond / ...)
+        share everything up to here; everything that does not depend on the context - GroupNorm, proj_in, the whole
+        self-attention of the first block, LayerNorm and the Q projection of its cross-attention - is computed once and the
+        token stream is replicated r times right before the first cross-attention (context_kv holds r * b videos).  The
+        result [r * n, H, W, C] equals the forward of the r-fold replicated input bit for bit."""
         n, H, W, C = x.shape
         N = H * W
         if N % 8 != 0:
@@ -231,7 +236,7 @@ class SpatialTransformer(PackedModule):
         a = ops.group_norm(x.view(n, N, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False)
         t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
         D, heads = t.shape[1], self.n_heads
-        for blk, kv in zip(self.transformer_blocks, context_kv):
+        for bi, (blk, kv) in enumerate(zip(self.transformer_blocks, context_kv)):
             ln = blk.ln_params()
             a1, a2 = blk.attn1.packed(), blk.attn2.packed()
             # ---- self-attention over the h*w tokens of each frame
@@ -247,6 +252,9 @@ class SpatialTransformer(PackedModule):
             # ---- cross-attention: softmax(Q K_txt) V_txt + softmax(Q K_img) V_img
             h2 = ops.layer_norm(t, *ln[1])
             q2 = ops.linear(h2, a2["wq"], alpha=blk.attn2.scale * ops.LOG2E)
+            if bi == 0 and cfg_repeat > 1:      # from here on the r conditionings differ
+                t, q2, xin = ops.repeat_rows(t, cfg_repeat), ops.repeat_rows(q2, cfg_repeat), ops.repeat_rows(xin, cfg_repeat)
+                n, tokens = n * cfg_repeat, tokens * cfg_repeat
             o2 = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
             nb = kv.n_txt_rows // 80
             if kv.k_img is not None:     # text (+) image in one pass over q2 / o2

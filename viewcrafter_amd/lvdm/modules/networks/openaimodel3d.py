@@ -29,12 +29,16 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """Reference openaimodel3d.py:30-48: routes (emb | context | 5-D view) to each child by type.
     x is channels-last [n = b*t, H, W, C]."""
 
-    def forward(self, x, emb, context=None, batch_size=None):
+    def forward(self, x, emb, context=None, batch_size=None, cfg_repeat=1):
+        """cfg_repeat = r > 1 (only for a block that holds the first SpatialTransformer of the graph): the input is one copy
+        of an r-fold replicated batch; the transformer replicates it where the conditionings start to differ and the
+        layers after it see batch_size * r videos."""
         for layer in self:
             if isinstance(layer, ResBlock):
                 x = layer(x, emb, batch_size=batch_size)
             elif isinstance(layer, SpatialTransformer):
-                x = layer(x, context_kv=context[id(layer)], frames_per_video=x.shape[0] // batch_size)
+                x = layer(x, context_kv=context[id(layer)], frames_per_video=x.shape[0] // batch_size, cfg_repeat=cfg_repeat)
+                batch_size, cfg_repeat = batch_size * cfg_repeat, 1
             elif isinstance(layer, TemporalTransformer):
                 n, H, W, C = x.shape
                 x = layer(x.view(batch_size, n // batch_size, H * W, C)).view(n, H, W, C)
@@ -349,27 +353,27 @@ class UNetModel(PackedModule):
 
     def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
         if self.use_hip_graph and features_adapter is None and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
-            return self.forward_graphed(x, timesteps, context, fs)
+            return self.forward_graphed(x, timesteps, context, fs, cfg_repeat=int(kwargs.get("cfg_repeat", 1) or 1))
         return self._forward(x, timesteps, context=context, features_adapter=features_adapter, fs=fs, **kwargs)
 
-    def forward_graphed(self, x, timesteps, context, fs):
+    def forward_graphed(self, x, timesteps, context, fs, cfg_repeat=1):
         """Replay the forward as one hipGraph (captured through torch.cuda.CUDAGraph: every libvcx call is stream-ordered,
         allocation-free and sync-free, so the ctypes launches are captured like any other kernel).  One graph per
         (shapes, conditioning tensor); inputs are copied into static buffers, the output buffer is reused by the next
         replay (the DDIM update consumes it first)."""
         parts = list(x) if isinstance(x, (list, tuple)) else [x]
         key = (tuple(tuple(p.shape) for p in parts), context.data_ptr(), context._version, tuple(context.shape),
-               None if fs is None else tuple(fs.shape))
+               None if fs is None else tuple(fs.shape), cfg_repeat)
         ent = self._graphs.get(key)
         if ent is None:
             static = dict(parts=[p.detach().clone().float() for p in parts], t=timesteps.detach().clone(),
                           fs=None if fs is None else fs.detach().clone())
             with torch.no_grad():
-                self._forward(static["parts"], static["t"], context=context, fs=static["fs"])   # warm-up: packs, caches K/V
+                self._forward(static["parts"], static["t"], context=context, fs=static["fs"], cfg_repeat=cfg_repeat)   # warm-up: packs, caches K/V
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    out = self._forward(static["parts"], static["t"], context=context, fs=static["fs"])
+                    out = self._forward(static["parts"], static["t"], context=context, fs=static["fs"], cfg_repeat=cfg_repeat)
             if len(self._graphs) >= 4:
                 self._graphs.clear()
             # the captured launches bake in the addresses of the projected context K/V (allocated by the warm-up in the
@@ -384,11 +388,19 @@ class UNetModel(PackedModule):
         graph.replay()
         return out
 
-    def _forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
+    def _forward(self, x, timesteps, context=None, features_adapter=None, fs=None, cfg_repeat=1, **kwargs):
         """x [B, in_channels, T, h, w] fp32 (or a list of tensors to be concatenated on channels, which is how
         DiffusionWrapper avoids materialising torch.cat([x] + c_concat)); timesteps [B] int64; context [B, L, D];
         fs [B] int64.  Extra keywords (cfg_img, unconditional_conditioning_img_nonetext, ...) leak in from the
-        sampler exactly as in the reference and are ignored.  Returns [B, out_channels, T, h, w] fp32."""
+        sampler exactly as in the reference and are ignored.  Returns [B, out_channels, T, h, w] fp32.
+
+        cfg_repeat = r > 1 (set by the sampler for classifier-free guidance): context is [r * B, L, D] - r conditionings of
+        the SAME x / timesteps / fs (reference ddim.py:223-224 evaluates them one after the other on identical inputs).
+        Every layer ahead of the first cross-attention (conv_in, init_attn, the first ResBlock with its temporal
+        convolutions, and in the first SpatialTransformer GroupNorm, proj_in and the whole 9216-token self-attention) sees
+        identical data in all r evaluations, so it runs once on B videos and the activations are replicated where the
+        conditionings enter; the output [r * B, ...] is bit-identical to the forward of the r-fold replicated batch
+        (tests/test_model_gpu.py::test_cfg_shared_prefix_is_bit_identical)."""
         ops.require_gpu()
         if features_adapter is not None:
             raise NotImplementedError("features_adapter is not used on the ViewCrafter path")
@@ -398,9 +410,18 @@ class UNetModel(PackedModule):
         cin = sum(p.shape[1] for p in parts)
         if cin != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {cin}")
+        r = int(cfg_repeat or 1)
+        if context.shape[0] != b * r:
+            raise ValueError(f"context batch {context.shape[0]} != {b} videos x cfg_repeat {r}")
         pk = self.packed()
         emb = self._embed(pk, timesteps, fs, b, device)
         ckv = self._context_kv(context, t)
+        # batch currently flowing through the graph: b until the first SpatialTransformer replicated it, b * r afterwards
+        cur_b = b
+
+        def replicate(a):      # [cur_b * t, H, W, C] -> [r * cur_b * t, H, W, C]
+            n_, H_, W_, C_ = a.shape
+            return ops.repeat_rows(a.view(n_ * H_ * W_, C_), r).view(r * n_, H_, W_, C_)
 
         h = torch.empty((b, t, hh, ww, cin), dtype=torch.float16, device=device)
         off = 0
@@ -414,10 +435,18 @@ class UNetModel(PackedModule):
             if i == 0:
                 h = ops.conv2d(h, pk["w_in"], pk["b_in"], kh=3, kw=3)
                 if self.addition_attention:
-                    h = self.init_attn(h, emb, context=ckv, batch_size=b)
+                    h = self.init_attn(h, emb, context=ckv, batch_size=cur_b)
+            elif cur_b != b * r and any(isinstance(layer, SpatialTransformer) for layer in module):
+                h = module(h, emb, context=ckv, batch_size=cur_b, cfg_repeat=r)     # the conditionings enter here
+                cur_b = b * r
+                emb = ops.repeat_rows(emb, r)
+                hs = [replicate(a) for a in hs]                                      # skips recorded so far
             else:
-                h = module(h, emb, context=ckv, batch_size=b)
+                h = module(h, emb, context=ckv, batch_size=cur_b)
             hs.append(h)
+        if cur_b != b * r:     # a graph without attention in the input path: replicate ahead of the middle block
+            h, hs, emb, cur_b = replicate(h), [replicate(a) for a in hs], ops.repeat_rows(emb, r), b * r
+        b = cur_b
         h = self.middle_block(h, emb, context=ckv, batch_size=b)
         for module in self.output_blocks:
             skip = hs.pop()

@@ -218,6 +218,16 @@ def copy2d(src, dst, rows, cols, lds, ldd):
     check(lib().vcx_copy2d_f16(src.data_ptr(), dst.data_ptr(), rows, cols, lds, ldd, _stream()), "copy2d")
 
 
+def repeat_rows(x, r):
+    """[rows, C] (row stride may exceed C) -> [r * rows, C]: r copies stacked (the batch axis of a channels-last activation)."""
+    rows, C = x.shape
+    out = torch.empty((r * rows, C), dtype=x.dtype, device=x.device)
+    assert x.dtype == _f16
+    for i in range(r):
+        copy2d(x, out[i * rows:], rows, C, x.stride(0), C)
+    return out
+
+
 def concat_channels(a, b):
     """[rows, Ca] ++ [rows, Cb] -> [rows, Ca+Cb] (torch.cat(dim=1) of the reference's NCHW tensors)."""
     rows, ca = a.shape
