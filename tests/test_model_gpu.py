@@ -106,7 +106,7 @@ def test_cfg_shared_prefix_is_bit_identical(unet, r, t, L):
 def test_sampler_uses_the_shared_prefix_only_when_the_conditionings_allow_it(model):
     from viewcrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
     s = DDIMSampler(model)
-    cat = torch.zeros(1, 4, 2, 8, 8, device=DEV)
+    cat = torch.zeros(1, 4, 2, 32, 16, device=DEV)
     c = {"c_crossattn": [torch.zeros(1, 77, 128, device=DEV)], "c_concat": [cat]}
     uc_same = {"c_crossattn": [torch.ones(1, 77, 128, device=DEV)], "c_concat": [cat]}
     uc_other = {"c_crossattn": [torch.ones(1, 77, 128, device=DEV)], "c_concat": [cat.clone()]}
@@ -114,7 +114,7 @@ def test_sampler_uses_the_shared_prefix_only_when_the_conditionings_allow_it(mod
     s.share_cfg_prefix = False
     assert not s._shares_prefix((c, uc_same))
     # both routes give the same denoiser outputs
-    x, t = synth_input("share_s_x", (1, 4, 2, 8, 8)).to(DEV), torch.tensor([500], device=DEV)
+    x, t = synth_input("share_s_x", (1, 4, 2, 32, 16)).to(DEV), torch.tensor([500], device=DEV)
     fs = torch.tensor([10], device=DEV)
     with torch.no_grad():
         a = s._apply_batched(x, t, (c, uc_same), {"fs": fs})

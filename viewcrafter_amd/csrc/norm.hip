@@ -13,9 +13,9 @@ constexpr int MAXC = 4096;  // C/8 * pixel lanes must fit one block (<= 512 thre
 // ---------------------------------------------------------------------------------------
 // Chan/Welford merge of two (count, mean, M2) triples in a fixed order: b is folded into a.
 __device__ __forceinline__ void gn_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
-    if (nb == 0.f) return;
-    if (na == 0.f) { na = nb; ma = mb; qa = qb; return; }
-    const float n = na + nb, d = mb - ma, f = nb * __builtin_amdgcn_rcpf(n);    // 1-ulp reciprocal: a weight, not a sum
+    // branch-free: nb = 0 gives f = 0 (a unchanged), na = 0 gives f = 1 (a := b); empty + empty stays (0, m, 0)
+    const float n = na + nb, d = mb - ma;
+    const float f = nb * __builtin_amdgcn_rcpf(fmaxf(n, 1.0f));    // 1-ulp reciprocal: a weight, not a sum
     ma = ma + d * f;
     qa = qa + qb + d * d * na * f;
     na = n;
@@ -45,16 +45,15 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
     int64_t pix = p0 + plane;
     const int64_t step = pl;
     const int64_t mine = pix < p1 ? (p1 - pix + step - 1) / step : 0;       // pixels this thread owns
-    bool first = true;
+    if (mine > 0) {                                      // the same line the loop fetches first: both loads fly together
+        const h8 v0 = *reinterpret_cast<const h8*>(xp + pix * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) K[e] = (float)v0[e];
+    }
     for (; pix + 3 * step < p1; pix += 4 * step) {
         h8 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8*>(xp + (pix + u * step) * C);
-        if (first) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) K[e] = (float)v[0][e];
-            first = false;
-        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -66,11 +65,6 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
     }
     for (; pix < p1; pix += step) {
         const h8 v = *reinterpret_cast<const h8*>(xp + pix * C);
-        if (first) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) K[e] = (float)v[e];
-            first = false;
-        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float f = (float)v[e] - K[e];
@@ -119,10 +113,45 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
     }
 }
 
-__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int chunks,
-                                                          int groups) {
-    // fixed merge tree: thread (q, g), q < nq = 256 / groups, folds the chunks c = q, q + nq, q + 2 nq, ... of group g in
-    // order (Chan), then the nq results of a group are folded in order.  stats[n][g] = (mean, biased variance).
+__global__ void __launch_bounds__(64) gn_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int chunks,
+                                                         int groups) {
+    // one wave per (n, group): lane l folds the chunks l, l + 64, l + 128, ... in order (loads issued up front, Chan merge,
+    // branch-free), then the 64 lane results are folded in a fixed butterfly.  stats[n][g] = (mean, biased variance).
+    const int n = blockIdx.x / groups, g = blockIdx.x % groups, lane = threadIdx.x;
+    const float* src = partials + ((int64_t)n * chunks * groups + g) * 3;
+    float na = 0.f, a = 0.f, m2 = 0.f;
+    for (int c0 = lane; c0 < chunks; c0 += 64 * 4) {
+        float t[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 64 * u;
+            const float* q = src + (int64_t)(c < chunks ? c : 0) * groups * 3;
+            t[u][0] = c < chunks ? q[0] : 0.f;
+            t[u][1] = q[1];
+            t[u][2] = c < chunks ? q[2] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gn_merge(na, a, m2, t[u][0], t[u][1], t[u][2]);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        // lane pairs (l, l ^ o): the lower lane is always the left operand, so both lanes compute the same bits
+        const float nb = __shfl_xor(na, o), b = __shfl_xor(a, o), qb = __shfl_xor(m2, o);
+        const bool low = (lane & o) == 0;
+        float n0 = low ? na : nb, a0 = low ? a : b, q0 = low ? m2 : qb;
+        gn_merge(n0, a0, q0, low ? nb : na, low ? b : a, low ? qb : m2);
+        na = n0; a = a0; m2 = q0;
+    }
+    if (lane == 0) {
+        stats[((int64_t)n * groups + g) * 2 + 0] = a;
+        stats[((int64_t)n * groups + g) * 2 + 1] = na > 0.f ? m2 / na : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_finalize_small_kernel(const float* __restrict__ partials, float* __restrict__ stats, int chunks,
+                                                                int groups) {
+    // few chunks (<= 64): one block per n; thread (q, g), q < nq = 256 / groups, folds the chunks q, q + nq, ... of group g in
+    // order, then the nq results of a group are folded in order.  Same arithmetic (gn_merge) as the wave-per-group kernel.
     __shared__ float red[256][3];
     const int n = blockIdx.x, nq = 256 / groups;
     const int g = threadIdx.x % groups, q = threadIdx.x / groups;
@@ -307,7 +336,9 @@ extern "C" int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, in
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(cw * pl), smem, s, (const half_t*)x, (float*)ws, pixels, C, groups, ppb, cw, pl);
     int rc = vcx_check_launch("vcx_groupnorm_stats_f16");
     if (rc) return rc;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_outer), dim3(256), 0, s, (const float*)ws, stats, chunks, groups);
+    // the choice depends on the pixel count only (never on the batch): same bits for B = 1 and B = 2
+    if (chunks <= 64) hipLaunchKernelGGL(gn_finalize_small_kernel, dim3(n_outer), dim3(256), 0, s, (const float*)ws, stats, chunks, groups);
+    else hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_outer * groups), dim3(64), 0, s, (const float*)ws, stats, chunks, groups);
     return vcx_check_launch("vcx_groupnorm_stats_f16(finalize)");
 }
 
