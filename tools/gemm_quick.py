@@ -38,12 +38,14 @@ geglu(460800, 320); geglu(115200, 640); geglu(28800, 1280)
 lin(28800, 1280, 1280, res=True); lin(115200, 640, 2560, res=True); lin(460800, 640, 320)
 conv(1280, 9, 16); tconv(640, 2304)
 # A/B of VCX_GEMM_TUNE values given on the command line (read per call by vcx_gemm_f16), interleaved rounds, median and min
-tunes = [int(a) for a in sys.argv[1:]] or [0]
+# arguments: VCX_GEMM_TUNE values, or cfgN to force tile configuration N (VCX_GEMM_CFG) with tune 0
+tunes = [a for a in sys.argv[1:]] or ["0"]
 rounds = 3
 res = {t: [[] for _ in cases] for t in tunes}
 for r in range(rounds):
     for t in tunes:
-        os.environ["VCX_GEMM_TUNE"] = str(t)
+        os.environ["VCX_GEMM_TUNE"] = "0" if t.startswith("cfg") else t
+        os.environ["VCX_GEMM_CFG"] = t[3:] if t.startswith("cfg") else ""
         for i, (name, fn, fl) in enumerate(cases):
             res[t][i].append(timeit(fn, iters=6))
 med = lambda v: sorted(v)[len(v) // 2]

@@ -487,7 +487,8 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.r_bytes = (unsigned)r_ext;
     if (dma_ok) {
         // tile choice: the large (256-row, 8-wave) tiles halve the LDS traffic per MFMA but need >= ~1.5 waves of 256 tiles
-        static const int force = []() { const char* e = getenv("VCX_GEMM_CFG"); return e ? atoi(e) : -1; }();
+        int force = -1;      // read per call: tools/gemm_quick.py A/Bs tile configurations inside one process
+        { const char* e = getenv("VCX_GEMM_CFG"); if (e && e[0]) force = atoi(e); }
         int cfg = use160 ? 1 : 0;
         const int big_bn = (d->N % 320 == 0 && !geglu) ? 320 : ((d->N % 256 == 0 || d->N >= 1024) ? 256 : 0);
         if (big_bn) {
