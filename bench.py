@@ -188,9 +188,10 @@ def main():
     torch.manual_seed(123)
     model = build_diffusion_model(os.path.join(ROOT, "configs", cfg_name), device=device, conditioners="identity")
     bcast_s = None
-    if world == 1 or rank == 0:
+    rccl = world > 1 and dist.get_backend() == "nccl"
+    if not rccl or rank == 0:       # (smoke mode on a box with fewer GPUs than ranks: every rank seeds its own identical copy)
         randomize_parameters(model, seed=0)
-    if world > 1:
+    if rccl:
         # the product's start-up: rank 0 owns the weights, the others receive them in 256 MB RCCL broadcasts over xGMI
         from viewcrafter_amd import parallel
         torch.cuda.synchronize()
@@ -201,7 +202,6 @@ def main():
         dist.barrier()
         bcast_s = time.perf_counter() - t0
         chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
-        chk = chk.to(device if dist.get_backend() == "nccl" else "cpu")
         allc = [torch.empty_like(chk) for _ in range(world)]
         dist.all_gather(allc, chk)
         assert all(torch.equal(allc[0], c) for c in allc), f"rank weights differ after the broadcast: {[float(c) for c in allc]}"

@@ -2,6 +2,8 @@
 #include "vcx_common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -56,9 +58,13 @@ struct ProfRec {
     double launches, flops, bytes;
     hipStream_t stream;
 };
+// The profiler is one process-wide recorder (bench.py brackets its timed region with it).  Entry points may be called from
+// several host threads: every access to the recorder below happens under g_prof_mu; calls made while profiling is off only
+// read the atomic flag, so the compute entry points stay lock-free and re-entrant in normal operation.
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_recs;
 static int g_nrec = 0;
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
 static int g_open = -1;         // the run still open (its end event not yet recorded)
 
 static void prof_close_open_run() {
@@ -69,6 +75,7 @@ static void prof_close_open_run() {
 }
 
 extern "C" int vcx_profile_begin(int max_records) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (max_records <= 0) max_records = 1;
     while ((int)g_recs.size() < max_records) {
         ProfRec r;
@@ -84,13 +91,14 @@ extern "C" int vcx_profile_begin(int max_records) {
     }
     g_nrec = 0;
     g_open = -1;
-    g_prof_on = true;
+    g_prof_on.store(true, std::memory_order_release);
     return VCX_OK;
 }
 
 extern "C" int vcx_profile_end(double* out_host) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     prof_close_open_run();
-    g_prof_on = false;
+    g_prof_on.store(false, std::memory_order_release);
     for (int i = 0; i < VCX_PROF_FAMILIES * 4; ++i) out_host[i] = 0.0;
     for (int i = 0; i < g_nrec; ++i) {
         ProfRec& r = g_recs[i];
@@ -115,7 +123,9 @@ extern "C" int vcx_profile_end(double* out_host) {
 }
 
 VcxProfScope::VcxProfScope(int family, hipStream_t stream, double flops, double bytes) : rec(-1), s(stream) {
-    if (!g_prof_on) return;
+    if (!g_prof_on.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
     if (g_open >= 0 && g_recs[g_open].family == family && g_recs[g_open].stream == s) {   // same run: just account
         ProfRec& r = g_recs[g_open];
         r.launches += 1.0;
