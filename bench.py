@@ -61,11 +61,11 @@ def synth_conditioning(T, h, w, device, seed=123, B=1):
     return x_T.to(device), cond, uc
 
 
-def cpu_baseline(model, hp, flops_per_step_full, budget_s=100.0):
+def cpu_baseline(model, hp, flops_per_step_full, budget_s=75.0):
     """The fp32 oracle (oracle/lvdm_oracle.py, a port of the reference algorithm) timed on the host cores for one UNet forward
     at BASELINE configs[0]'s shapes (16 frames, 40x64 latent, the full 1.44 B-parameter width), after a
-    small warm-up call; one DDIM step = 2 forwards; FLOP-scaled to the bench workload (labelled extrapolated).  A host too
-    slow for that within `budget_s` (predicted from the warm-up) gets the same 16 frames at 24x40.  Only this function, the
+    warm-up call; one DDIM step = 2 forwards; FLOP-scaled to the bench workload (labelled extrapolated).  The same 16 frames
+    at 24x40 are timed first; a host too slow for the 40x64 call within `budget_s` (predicted from that run) reports those.  Only this function, the
     two legs below and nothing in the timed region touch oracle/."""
     from oracle import lvdm_oracle as O
     unet = model.model.diffusion_model
@@ -82,11 +82,11 @@ def cpu_baseline(model, hp, flops_per_step_full, budget_s=100.0):
         assert torch.isfinite(y).all()
         return time.perf_counter() - t0
     run(2, 8, 8)                                         # threads, allocator, oneDNN primitives
-    t_small = run(16, 8, 16)                             # 1/20 of the pixels of 40x64: predicts the real call
-    T, h, w = 16, 40, 64
-    if t_small * 20 * 1.3 > budget_s:
-        h, w = 24, 40
-    dt = run(T, h, w)
+    T, h, w = 16, 24, 40
+    dt = run(T, h, w)                                    # 4.6 TFLOP: predicts the 12.6 TFLOP call (FLOP ratio 2.74)
+    if dt * UNET_TFLOP[(16, 40, 64)] / UNET_TFLOP[(16, 24, 40)] <= budget_s:
+        T, h, w = 16, 40, 64
+        dt = run(T, h, w)
     flops = UNET_TFLOP.get((T, h, w))
     step_s = 2.0 * dt
     scale = flops_per_step_full / (2.0 * flops * 1e12) if flops else None
