@@ -310,7 +310,9 @@ def main():
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             now = csrc_hash()
-            if tr.get("csrc_sha256") == now:
+            if args.workload != tr.get("workload", "ViewCrafter_25_576x1024x25"):
+                out["roofline"]["traffic_note"] = f"PMC passes were run on {tr.get('workload', 'ViewCrafter_25_576x1024x25')}, not on this workload"
+            elif tr.get("csrc_sha256") == now:
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr["source"]
                 out["roofline"]["traffic_measured_at"] = {"csrc_sha256": now[:12], "commit": tr.get("commit")}

@@ -48,6 +48,6 @@ if a.json:
            "algorithmic_bytes_per_launch": (a.algo_bytes_per_step / a.gemm_calls_per_step) if a.algo_bytes_per_step else None,
            "note": "per vcx_gemm_f16 call; FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE as reported; separate --pmc passes",
            "source": "tools/pmc_passes.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 1 --warmup 0 ...)",
-           "csrc_sha256": h.hexdigest(), "commit": a.commit,
+           "csrc_sha256": h.hexdigest(), "commit": a.commit, "workload": "ViewCrafter_25_576x1024x25",
            "families": {k: {"launches_per_step": v[0], "read_gb_per_step": v[1] / 1e9, "write_gb_per_step": v[2] / 1e9} for k, v in agg.items()}}
     json.dump(out, open(a.json, "w"), indent=1)
