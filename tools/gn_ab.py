@@ -1,4 +1,9 @@
-"""A/B of the GroupNorm kernels of two builds of libvcx (timing only): python tools/gn_ab.py"""
+"""A/B of the GroupNorm kernels of two builds of libvcx (timing only): python tools/gn_ab.py
+The second build is any other revision of csrc/norm.hip linked into tools/libvcx_oldgn.so, e.g.
+    git show <rev>:viewcrafter_amd/csrc/norm.hip > /tmp/norm_old.hip
+    cd viewcrafter_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -I. -c /tmp/norm_old.hip -o /tmp/norm_old.o
+    hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libvcx_oldgn.so build/{api,gemm,gemm_dma,gemm_pp,attention,elementwise}.o /tmp/norm_old.o
+(the .so is git-ignored; profiles/r02_experiments.md section 4 holds the numbers of the round-2 versions)."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from viewcrafter_amd import _lib
