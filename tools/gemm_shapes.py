@@ -27,9 +27,10 @@ def record_forward(workload):
     model = build_diffusion_model(os.path.join(ROOT, "configs", cfg), device="cuda", conditioners="identity")
     randomize_parameters(model)
     x, cond, uc = synth_conditioning(T, h, w, "cuda")
-    both = {k: [torch.cat([a, b], 0) for a, b in zip(cond[k], uc[k])] for k in cond}
-    ts = torch.full((2,), 499, device="cuda", dtype=torch.long)
-    fs = torch.tensor([10, 10], device="cuda")
+    # the sampler's call: one x / t / fs / c_concat, the two conditionings stacked, shared CFG prefix (cfg_repeat = 2)
+    both = {"c_crossattn": [torch.cat([cond["c_crossattn"][0], uc["c_crossattn"][0]], 0)], "c_concat": cond["c_concat"]}
+    ts = torch.full((1,), 499, device="cuda", dtype=torch.long)
+    fs = torch.tensor([10], device="cuda")
     seen = collections.Counter()
     L = _lib.lib()
     real = L.vcx_gemm_f16
@@ -40,10 +41,10 @@ def record_forward(workload):
             seen[tuple(int(getattr(d, f)) for f in FIELDS)] += 1
             return real(dref, stream)
     with torch.no_grad():
-        model.apply_model(torch.cat([x, x]), ts, both, fs=fs)      # warm (packs weights, caches context K/V)
+        model.apply_model(x, ts, both, fs=fs, cfg_repeat=2)      # warm (packs weights, caches context K/V)
         L.vcx_gemm_f16 = Spy()
         try:
-            model.apply_model(torch.cat([x, x]), ts, both, fs=fs)
+            model.apply_model(x, ts, both, fs=fs, cfg_repeat=2)
         finally:
             L.vcx_gemm_f16 = real
     torch.cuda.synchronize()
@@ -96,17 +97,22 @@ def main():
         d = dict(zip(FIELDS, key))
         ms = time_shape(key)
         fl = 2.0 * d["M"] * d["N"] * d["K"]
-        rows.append(dict(d, count=cnt, ms=ms, total_ms=ms * cnt, tflops=fl / ms / 1e9))
+        taps = d["kh"] * d["kw"] if d["mode"] else 1
+        n_out = d["N"] // 2 if d["flags"] & 16 else d["N"]
+        nbytes = 2.0 * (d["M"] * d["K"] / taps + d["N"] * d["K"] + d["M"] * n_out * (2 if d["flags"] & 32 else 1) + (d["M"] * d["N"] if d["flags"] & 8 else 0))
+        floor = max(fl / 1.35e15, nbytes / 5.5e12) * 1e3       # ms: best isolated MFMA rate seen on this part under load / achievable HBM
+        rows.append(dict(d, count=cnt, ms=ms, total_ms=ms * cnt, tflops=fl / ms / 1e9, floor_ms=floor, hbm_bound=nbytes / 5.5e12 > fl / 1.35e15))
     rows.sort(key=lambda r: -r["total_ms"])
     tot = sum(r["total_ms"] for r in rows)
     tfl = sum(2.0 * r["M"] * r["N"] * r["K"] * r["count"] for r in rows)
     print(f"# {len(rows)} unique GEMM problems, {sum(r['count'] for r in rows)} launches, {tot:.1f} ms, {tfl/1e12:.1f} TFLOP, {tfl/tot/1e9:.0f} TF/s")
-    print(f"{'cnt':>4} {'M':>8} {'N':>6} {'K':>6} {'kind':>10} {'flags':>5} {'ms':>8} {'total':>8} {'TF/s':>7} {'cum%':>6}")
+    print(f"# floor = max(FLOP / 1.35 PFLOP/s, algorithmic bytes / 5.5 TB/s); excess = (ms - floor) * count; sum of excess {sum((r['ms'] - r['floor_ms']) * r['count'] for r in rows):.1f} ms")
+    print(f"{'cnt':>4} {'M':>8} {'N':>6} {'K':>6} {'kind':>10} {'flags':>5} {'ms':>8} {'total':>8} {'TF/s':>7} {'cum%':>6} {'floor':>7} {'bound':>5} {'excess':>7}")
     cum = 0.0
     for r in rows:
         cum += r["total_ms"]
         kind = f"conv{r['kh']}x{r['kw']}" + ("s2" if r["stride"] == 2 else "") + ("u" if r["ups"] else "") if r["mode"] else "linear"
-        print(f"{r['count']:4d} {r['M']:8d} {r['N']:6d} {r['K']:6d} {kind:>10} {r['flags']:5d} {r['ms']:8.3f} {r['total_ms']:8.2f} {r['tflops']:7.0f} {100*cum/tot:6.1f}")
+        print(f"{r['count']:4d} {r['M']:8d} {r['N']:6d} {r['K']:6d} {kind:>10} {r['flags']:5d} {r['ms']:8.3f} {r['total_ms']:8.2f} {r['tflops']:7.0f} {100*cum/tot:6.1f} {r['floor_ms']:7.3f} {'hbm' if r['hbm_bound'] else 'mfma':>5} {(r['ms'] - r['floor_ms']) * r['count']:7.2f}")
     if args.json:
         json.dump(rows, open(args.json, "w"))
 
