@@ -1,5 +1,7 @@
-"""Full-size checks (BASELINE.json configs[3]: 576x1024x25 -> latent 25x72x128, B=2 for CFG) through size-independent
-properties, because the fp32 oracle cannot run these shapes in seconds:
+"""Full-size checks (BASELINE.json configs[3]: 576x1024x25 -> latent 25x72x128, B=2 for CFG) of the individual kernels
+through size-independent properties (the whole-forward comparison with the fp32 oracle at these shapes lives in
+tests/test_fullconfig_gpu.py; here every tile configuration / tail split / walk order is hit with exact or near-exact
+identities):
 linearity / delta-kernel identities for the GEMM-conv engine (all tile configurations, tail split, fused upsample),
 partition-of-unity for attention (V = 1 => O = 1), zero-mean/unit-variance for GroupNorm/LayerNorm, and algebraic identities
 of the DDIM update."""
