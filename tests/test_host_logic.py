@@ -184,6 +184,35 @@ def test_cfg_batching_rules():
     assert DDIMSampler._batchable(c, uc, uc) and s._cfg_cond(c, uc, uc)["c_crossattn"][0].shape == (3, 5, 4)
 
 
+def test_shared_cfg_prefix_routing(tiny_model):
+    """The sampler asks the UNet for the shared prefix (cfg_repeat) exactly when the conditionings differ only in c_crossattn
+    (every other entry the same tensor object, as image_guided_synthesis builds them, diffusion_utils.py:132,151-153), and then
+    passes x / t / fs / c_concat ONCE with the contexts stacked."""
+    from viewcrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    s = DDIMSampler(tiny_model)
+    cat = torch.zeros(1, 4, 2, 8, 8)
+    c = {"c_crossattn": [torch.zeros(1, 77, 128)], "c_concat": [cat]}
+    uc = {"c_crossattn": [torch.ones(1, 77, 128)], "c_concat": [cat]}
+    uc_copy = {"c_crossattn": [torch.ones(1, 77, 128)], "c_concat": [cat.clone()]}
+    assert s._shares_prefix((c, uc)) and s._shares_prefix((c, uc, uc)) and not s._shares_prefix((c, uc_copy))
+    calls = []
+
+    def spy(x, t, cond, **kw):
+        calls.append((tuple(x.shape), tuple(t.shape), tuple(cond["c_crossattn"][0].shape), tuple(cond["c_concat"][0].shape),
+                      kw.get("cfg_repeat"), None if kw.get("fs") is None else tuple(kw["fs"].shape)))
+        return torch.zeros(cond["c_crossattn"][0].shape[0], *x.shape[1:])
+    s.model = type("M", (), {"apply_model": staticmethod(spy), "model": tiny_model.model})()
+    x, t, fs = torch.zeros(1, 4, 2, 8, 8), torch.tensor([5]), torch.tensor([10])
+    out = s._apply_batched(x, t, (c, uc), {"fs": fs})
+    assert calls[-1] == ((1, 4, 2, 8, 8), (1,), (2, 77, 128), (1, 4, 2, 8, 8), 2, (1,)) and len(out) == 2
+    s._cfg_cache = None
+    s._apply_batched(x, t, (c, uc_copy), {"fs": fs})                      # not shareable: plain B = 2 batch
+    assert calls[-1] == ((2, 4, 2, 8, 8), (2,), (2, 77, 128), (2, 4, 2, 8, 8), None, (2,))
+    s.share_cfg_prefix, s._cfg_cache = False, None
+    s._apply_batched(x, t, (c, uc), {"fs": fs})
+    assert calls[-1][4] is None and calls[-1][0] == (2, 4, 2, 8, 8)
+
+
 # ------------------------------------------------------------------ the product has no CPU / oracle fallback
 def test_forward_fails_loudly_without_gpu(tiny_model):
     if torch.cuda.is_available():
