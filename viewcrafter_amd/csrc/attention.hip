@@ -543,16 +543,18 @@ struct TAttnArgs {
 
 // One wave per (pixel, head): S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x16_f16 (T <= 32 keys = one MFMA
 // tile), the same swapped formulation as the flash kernel, so softmax statistics are per-lane and P needs no
-// cross-lane movement.  Q and K fragments are read straight from global memory (a frame row of one head is one
-// 128-byte line); V goes through a wave-private LDS patch [32][72] from which the V^T fragments are gathered with
-// 16-bit reads (rows >= T zero-filled).  Traffic is the algorithmic minimum (q, k, v read once, o written once).
+// cross-lane movement.  Q, K and V rows (a frame row of one head is one 128-byte line) go through a wave-private LDS
+// patch 3 x [32][72]: the Q / K fragments are ds_read_b128 from it, the V^T fragments are gathered with 16-bit reads
+// (rows >= T zero-filled).  Traffic is the algorithmic minimum (q, k, v read once, o written once).
 __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
     constexpr int VLD = 72;                                           // LDS row pitch (halfs): 144 B keeps 16-B alignment
-    __shared__ __attribute__((aligned(16))) half_t sVt[8][32 * VLD];
+    constexpr int WAVES = 8;
+    // wave-private patch: V, Q, K rows of this (pixel, head), 32 x 64 halfs each
+    __shared__ __attribute__((aligned(16))) half_t sVt[WAVES][3 * 32 * VLD];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int lq = lane & 31, hi = lane >> 5;
-    const int64_t pair = (int64_t)blockIdx.x * 8 + wave;
+    const int64_t pair = (int64_t)blockIdx.x * WAVES + wave;
     if (pair >= p.npairs) return;                                     // wave-uniform; no block-level sync below
     const int h = (int)(pair % p.heads);
     const int64_t pix = (pair / p.heads) % p.P;
@@ -562,19 +564,36 @@ __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
     const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool rvalid = lq < p.T;
 
+    // Q, K and V rows all arrive as whole 128-byte lines (8 lanes x 16 B per frame row) and go through the wave-private LDS
+    // patch; the MFMA fragments are ds_read_b128 from there.  (Round 1 loaded the Q / K fragments straight from global memory -
+    // 32 bytes from each of 32 frame rows per instruction: 4.2 TB/s; staged: 4.95 TB/s, profiles/r02_experiments.md.)
     h8 qf[4], kf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const half_t* src = base + (int64_t)lq * fstride + s * 16 + hi * 8;
-        qf[s] = rvalid ? *reinterpret_cast<const h8*>(src) : zero8;
-        kf[s] = rvalid ? *reinterpret_cast<const h8*>(src + p.k_off) : zero8;
-    }
     half_t* sv = sVt[wave];
+    half_t* sq = sv + 32 * VLD;
+    half_t* sk = sv + 64 * VLD;
+    {
+        h8 q4[4], k4[4], v4[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int row = (lane >> 3) + 8 * it, ch = lane & 7;
-        const h8 v = row < p.T ? *reinterpret_cast<const h8*>(base + (int64_t)row * fstride + p.v_off + ch * 8) : zero8;
-        *reinterpret_cast<h8*>(sv + row * VLD + ch * 8) = v;
+        for (int it = 0; it < 4; ++it) {
+            const int row = (lane >> 3) + 8 * it, ch = lane & 7;
+            const half_t* src = base + (int64_t)row * fstride + ch * 8;
+            const bool ok = row < p.T;
+            q4[it] = ok ? *reinterpret_cast<const h8*>(src) : zero8;
+            k4[it] = ok ? *reinterpret_cast<const h8*>(src + p.k_off) : zero8;
+            v4[it] = ok ? *reinterpret_cast<const h8*>(src + p.v_off) : zero8;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = (lane >> 3) + 8 * it, ch = lane & 7;
+            *reinterpret_cast<h8*>(sq + row * VLD + ch * 8) = q4[it];
+            *reinterpret_cast<h8*>(sk + row * VLD + ch * 8) = k4[it];
+            *reinterpret_cast<h8*>(sv + row * VLD + ch * 8) = v4[it];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {     // LDS operations of one wave complete in order: no barrier, the patch is wave-private
+            qf[s] = *reinterpret_cast<const h8*>(sq + lq * VLD + s * 16 + hi * 8);
+            kf[s] = *reinterpret_cast<const h8*>(sk + lq * VLD + s * 16 + hi * 8);
+        }
     }
 
     // S^T[key, q]: lane (q = lq, hi) holds keys (r&3) + 8*(r>>2) + 4*hi
