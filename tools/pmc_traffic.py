@@ -34,6 +34,12 @@ for k, (n, v) in f.items():
 for k, (n, v) in w.items():
     if fam(k): agg[fam(k)][2] += v * 1024 / sw
 print(f"# DDIM steps in the FETCH pass: {sf:.0f}, in the WRITE pass: {sw:.0f}")
+# per kernel (template instantiation) of the GEMM family: which variants carry the read traffic
+import re
+short = lambda k: re.sub(r"^.*?(gemm_\w+kernel)I(?:NS_)?\d*(?:TileCfg|PPCfg)?I?", r"\1<", k)[:90]
+print(f"{'gemm kernel':92s} {'disp/step':>9s} {'read GB/step':>12s} {'write GB/step':>13s}")
+for k in sorted((k for k in f if fam(k) == "gemm"), key=lambda k: -f[k][1]):
+    print(f"{short(k):92s} {f[k][0]/sf:9.0f} {2.0*f[k][1]*1024/sf/1e9:12.1f} {w.get(k,(0,0))[1]*1024/sw/1e9:13.1f}")
 print(f"{'family':14s} {'launches/step':>13s} {'read GB/step (2x FETCH)':>24s} {'write GB/step':>14s} {'bytes/launch':>14s}")
 for k, (n, r, wr) in agg.items():
     print(f"{k:14s} {n:13.0f} {r/1e9:24.1f} {wr/1e9:14.1f} {(r+wr)/max(n,1):14.3e}")
