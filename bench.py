@@ -371,7 +371,7 @@ def main():
         from viewcrafter_amd.config import load_yaml
         mp_ = load_yaml(os.path.join(ROOT, "configs", cfg_name))["model"]["params"]
         hp = dict(mp_["unet_config"]["params"])
-        if not args.no_gpu_legs:
+        if world == 1 and not args.no_gpu_legs:      # N = 1 only: the other ranks would sit in the closing barrier meanwhile
             g = torch.Generator().manual_seed(99)
             xg = torch.randn(1, 8, T, h, w, generator=g).to(device)
             cg = torch.randn(1, 77 + 256, 1024, generator=g).to(device)
@@ -382,7 +382,7 @@ def main():
             out["broadcast_s"] = bcast_s
         if gather_s is not None:
             out["gather_s"] = gather_s
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, hp, flops_per_step)
         print(json.dumps(out))
     if world > 1:
