@@ -91,3 +91,15 @@ def test_inference_cli_end_to_end(tmp_path):
     r2 = subprocess.run(cmd[:cmd.index("e")] + ["e2"] + cmd[cmd.index("e") + 1:], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-4000:]
     assert torch.equal(torch.load(os.path.join(out_dir, "e2", "diffusion0.pt")), res)
+
+
+def test_build_then_smoke_in_one_process():
+    """`__graft_entry__.build()` binds libvcx.so before anything else has imported torch.  PyTorch-ROCm bundles its own HIP / HSA
+    runtime under the same sonames, so `_lib.lib()` must make torch's copy the one in the process (it imports torch first):
+    loaded the other way round every launch fails with "no ROCm-capable device is detected"."""
+    code = ("import sys; import __graft_entry__ as g; g.build(); assert 'torch' in sys.modules; g.smoke(); "
+            "from viewcrafter_amd import _lib; import ctypes; b = ctypes.create_string_buffer(64); "
+            "assert _lib.lib().vcx_device_arch(b, 64) == 0 and b.value.startswith(b'gfx950'), b.value; print('ARCH', b.value.decode())")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "smoke OK" in r.stdout and "ARCH gfx950" in r.stdout

@@ -52,6 +52,12 @@ def lib():
         raise VcxError(
             f"{LIB_PATH} not found: build it with `make -C viewcrafter_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    # Load order matters: PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64.so.1.  libvcx.so must bind to the HIP
+    # runtime the host framework uses (its streams and device pointers come from there), so torch is imported first and the
+    # dynamic loader resolves libvcx's NEEDED libamdhip64.so.7 to the copy already in the process.  The other way round
+    # (/opt/rocm's runtime first, torch's HSA layer second) leaves two half-initialised runtimes: every launch then fails with
+    # "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     L.vcx_abi_version.restype = c_int
     L.vcx_last_error.restype = c_char_p
