@@ -535,3 +535,32 @@ def test_gelu_f16_exact_erf():
     assert y.dtype == torch.float16
     assert float((y.float() - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
     check(y, ref, tol=1e-3, name="gelu")
+
+
+def test_stale_not_ready_status_is_not_a_launch_failure():
+    """hipEventQuery on a pending event leaves hipErrorNotReady as the thread's last error (the host framework's allocator polls
+    events like this); the next libvcx launch must not report it as its own failure."""
+    import ctypes
+    from viewcrafter_amd import ops
+    hip = ctypes.CDLL("libamdhip64.so.7")          # already in the process (torch's copy): same runtime libvcx is bound to
+    ev = ctypes.c_void_p()
+    assert hip.hipEventCreate(ctypes.byref(ev)) == 0
+    big = torch.randn(64, 1024, 1024, device="cuda")
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn(4096, device="cuda")
+    seen = False
+    for _ in range(20):
+        for _ in range(4):
+            big = big * 1.0001 + 0.5
+        assert hip.hipEventRecord(ev, s) == 0
+        rc = hip.hipEventQuery(ev)
+        if rc != 0:                               # pending: hipErrorNotReady is now the sticky last error of this thread
+            seen = True
+            y = ops.silu_f32(x)                   # raises VcxError if the residue were taken for a launch error
+            torch.cuda.synchronize()
+            assert torch.allclose(y, torch.nn.functional.silu(x), atol=1e-6)
+            break
+    torch.cuda.synchronize()
+    hip.hipEventDestroy(ev)
+    if not seen:
+        pytest.skip("the GPU always finished before the query: no pending state produced")

@@ -17,7 +17,9 @@ void vcx_set_error(const char* fmt, ...) {
 
 int vcx_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
+    // hipErrorNotReady is never the result of a launch: it is the sticky residue of a hipEventQuery / hipStreamQuery poll made by
+    // the host framework on this thread (PyTorch's caching allocator polls events when tensors cross streams)
+    if (e != hipSuccess && e != hipErrorNotReady) {
         vcx_set_error("%s: %s", what, hipGetErrorString(e));
         return VCX_ELAUNCH;
     }
