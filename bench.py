@@ -121,7 +121,7 @@ def gpu_legs(model, hp, dd, T, h, w, device, x, ts, ctx, fs, z_dec):
         del dec, dref
         out["parity"] = {"unet_forward_rel_l2": rel, "vae_decode_rel_l2": drel, "latent": [T, h, w],
                          "oracle": "fp32 oracle/lvdm_oracle.py run on the same MI355X, same weights and inputs",
-                         "bounds": {"unet_forward": 8e-3, "vae_decode": 8e-3}}
+                         "bounds": {"unet_forward": 5e-3, "vae_decode": 8e-3}}
         with torch.autocast("cuda", dtype=torch.float16):
             O.unet_forward(sd, hp, x, ts, ctx, fs)                       # warm-up: MIOpen find, hipBLASLt heuristics
             torch.cuda.synchronize()

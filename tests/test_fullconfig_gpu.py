@@ -12,7 +12,7 @@ on, instead of inferring full-size numerics from the tiny graph:
   * a 50-step eta = 0 DDIM trajectory (ddim.py:137-281; CFG 7.5, guidance rescale 0.7, uniform_trailing, dynamic
     rescale, v-prediction) at (25, 40, 64), ours vs the oracle sampler driving the oracle UNet.
 
-Stated fp16 tolerance (rel-L2 against fp32): forward <= 8e-3, decode <= 8e-3, final latent <= 1e-2.  Weights are the
+Stated fp16 tolerance (rel-L2 against fp32): forward <= 5e-3, decode <= 8e-3, final latent <= 1e-2.  Weights are the
 seeded synthetic ones of builder.randomize_parameters (no checkpoints offline); the oracle reads the very same fp32
 tensors.  A per-block error table is printed for every forward (and is what to read first when a bound fails).
 """
@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-FWD_TOL, DEC_TOL, TRAJ_TOL = 8e-3, 8e-3, 1e-2
+FWD_TOL, DEC_TOL, TRAJ_TOL = 5e-3, 8e-3, 1e-2
 _MODELS = {}
 
 

@@ -3,7 +3,7 @@ reference code and (b) the fp32 oracle on fresh seeded inputs.
 
 Stated fp16 tolerance (north_star): activations and GEMM operands are fp16 with fp32 accumulation, the reference
 itself runs fp16 autocast whose measured floor against fp32 is rel-L2 2.8e-3 (UNet forward) / 3.8e-3 (VAE decode)
-(BASELINE.md §4).  Bounds used here: UNet forward rel-L2 <= 8e-3, VAE decode <= 8e-3, 5-step DDIM trajectory
+(BASELINE.md §4).  Bounds used here: UNet forward rel-L2 <= 5e-3, VAE decode <= 8e-3, 5-step DDIM trajectory
 (CFG 7.5 amplifies the denoiser error 7.5x) final latent <= 3e-2 and decoded frames PSNR >= 30 dB vs the fp32 reference.
 """
 import numpy as np
@@ -18,7 +18,7 @@ from tests.util import SCHEDULE_BUFFERS, golden, load_synth, psnr, rel_l2
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-UNET_TOL = 8e-3
+UNET_TOL = 5e-3
 VAE_TOL = 8e-3
 DDIM_TOL = 3e-2
 
