@@ -38,11 +38,11 @@ WORKLOADS = {
 }
 
 
-def csrc_hash():
-    """sha256 over the GEMM kernel sources: profiles/pmc_traffic.json records the hash it was measured on."""
+def csrc_hash(names=("gemm_dma.hip", "gemm.hip", "gemm_args.h")):
+    """sha256 over kernel sources (default: the GEMM engine): profiles/pmc_traffic.json records the hashes it was measured on."""
     import hashlib
     hsh = hashlib.sha256()
-    for name in ("gemm_dma.hip", "gemm.hip", "gemm_args.h"):
+    for name in names:
         with open(os.path.join(ROOT, "viewcrafter_amd", "csrc", name), "rb") as f:
             hsh.update(f.read())
     return hsh.hexdigest()
@@ -307,6 +307,7 @@ def main():
                            "algorithmic_tflop_per_launch_avg": gemm["flops"] / max(gemm["launches"], 1) / 1e12}
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (bench.py cannot run rocprofv3 itself).  The
         # file records a hash of the GEMM sources it was measured on: a number measured on other kernels is not reported.
+        tr = {}
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             now = csrc_hash()
@@ -324,8 +325,15 @@ def main():
             print(f"[bench] no usable profiles/pmc_traffic.json: {e}", file=sys.stderr)
         fl = prof["flash_attn"]
         fach = fl["flops"] / (fl["ms"] * 1e-3) / 1e12 if fl["ms"] > 0 else 0.0
+        ftraffic = None       # same rule as above: only a number measured on the attention kernels as they are now, on this workload
+        try:
+            ff = tr["families"]["flash_attn"]
+            if args.workload == tr.get("workload") and tr.get("attention_sha256") == csrc_hash(("attention.hip",)):
+                ftraffic = ff["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out["roofline_flash"] = {"bound": "mfma", "achieved": fach, "peak": MI355X_FP16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": fach / MI355X_FP16_DENSE_TFLOPS, "traffic": None,
+                                 "frac": fach / MI355X_FP16_DENSE_TFLOPS, "traffic": ftraffic,
                                  "kernel": "flash_d64_kernel<2,...> / xattn_resident_d64_kernel (csrc/attention.hip); FLOP = 4 N_q N_k d per head",
                                  "launches_per_step": fl["launches"] / args.steps, "avg_launch_ms": fl["ms"] / max(fl["launches"], 1),
                                  "algorithmic_tflop_per_launch_avg": fl["flops"] / max(fl["launches"], 1) / 1e12}

@@ -48,12 +48,14 @@ if a.json:
     h = hashlib.sha256()
     for name in ("gemm_dma.hip", "gemm.hip", "gemm_args.h"):
         h.update(open(os.path.join(root, "viewcrafter_amd", "csrc", name), "rb").read())
+    ha = hashlib.sha256(open(os.path.join(root, "viewcrafter_amd", "csrc", "attention.hip"), "rb").read()).hexdigest()
     n, r, wr = agg["gemm"]
     out = {"family": "gemm", "hbm_bytes_per_launch": (r + wr) / a.gemm_calls_per_step, "hbm_read_gb_per_step": r / 1e9,
            "hbm_write_gb_per_step": wr / 1e9, "kernel_dispatches_per_step": n, "launches_per_step": a.gemm_calls_per_step,
            "algorithmic_bytes_per_launch": (a.algo_bytes_per_step / a.gemm_calls_per_step) if a.algo_bytes_per_step else None,
            "note": "per vcx_gemm_f16 call; FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE as reported; separate --pmc passes",
            "source": "tools/pmc_passes.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 1 --warmup 0 ...)",
-           "csrc_sha256": h.hexdigest(), "commit": a.commit, "workload": "ViewCrafter_25_576x1024x25",
-           "families": {k: {"launches_per_step": v[0], "read_gb_per_step": v[1] / 1e9, "write_gb_per_step": v[2] / 1e9} for k, v in agg.items()}}
+           "csrc_sha256": h.hexdigest(), "attention_sha256": ha, "commit": a.commit, "workload": "ViewCrafter_25_576x1024x25",
+           "families": {k: {"launches_per_step": v[0], "read_gb_per_step": v[1] / 1e9, "write_gb_per_step": v[2] / 1e9,
+                                "hbm_bytes_per_launch": (v[1] + v[2]) / max(v[0], 1)} for k, v in agg.items()}}
     json.dump(out, open(a.json, "w"), indent=1)
