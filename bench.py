@@ -336,7 +336,8 @@ def main():
                                  "frac": fach / MI355X_FP16_DENSE_TFLOPS, "traffic": ftraffic,
                                  "kernel": "flash_d64_kernel<2,...> / xattn_resident_d64_kernel (csrc/attention.hip); FLOP = 4 N_q N_k d per head",
                                  "launches_per_step": fl["launches"] / args.steps, "avg_launch_ms": fl["ms"] / max(fl["launches"], 1),
-                                 "algorithmic_tflop_per_launch_avg": fl["flops"] / max(fl["launches"], 1) / 1e12}
+                                 "algorithmic_tflop_per_launch_avg": fl["flops"] / max(fl["launches"], 1) / 1e12,
+                                 "algorithmic_bytes_per_launch_avg": fl["bytes"] / max(fl["launches"], 1)}
         out["kernel_families"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
                                       "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None,
                                       "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
