@@ -103,3 +103,48 @@ def test_build_then_smoke_in_one_process():
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "smoke OK" in r.stdout and "ARCH gfx950" in r.stdout
+
+
+def test_rccl_collectives_of_the_sharded_launch_on_one_gpu(tmp_path):
+    """The torchrun launch's control plane on the RCCL backend (`init_process_group("nccl", device_id=...)`, bucketed weight
+    broadcast of GPU tensors, max-over-ranks timing all_reduce, checksum all_gather, clip gather, barrier) in a ONE-rank group on
+    this box's GPU: the 2-rank tests run on gloo / CPU tensors, and no multi-GPU box is available to the test-suite."""
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from tests.tiny_config import TINY_UNET
+from tests.util import load_synth
+from viewcrafter_amd import parallel
+from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+rank, world = parallel.init_distributed()          # WORLD_SIZE=1 -> no group: build the one-rank RCCL group by hand, as bench.py does
+assert (rank, world) == (0, 1)
+dist.init_process_group("nccl", device_id=dev)
+m = UNetModel(**TINY_UNET).eval(); load_synth(m); m = m.to(dev)
+m.register_buffer("host_side_table", torch.arange(8, dtype=torch.float32))          # a buffer left on the host is staged
+m._buffers["host_side_table"] = m._buffers["host_side_table"].cpu()
+before = [p.detach().clone() for p in m.parameters()]
+x = torch.randn(1, 8, 4, 16, 32, device=dev); ctx = torch.randn(1, 77 + 64, TINY_UNET["context_dim"], device=dev)
+t, fs = torch.tensor([500], device=dev), torch.tensor([10], device=dev)
+with torch.no_grad():
+    y0 = m(x, t, context=ctx, fs=fs)               # packs fp16 copies, which the broadcast must invalidate
+parallel.broadcast_module_(m, src=0, bucket_bytes=1 << 16, _force=True)          # small buckets: several broadcasts per dtype
+assert all(torch.equal(a, b) for a, b in zip(before, m.parameters()))
+assert torch.equal(m.host_side_table, torch.arange(8, dtype=torch.float32)) and m.host_side_table.device.type == "cpu"
+with torch.no_grad():
+    assert torch.equal(m(x, t, context=ctx, fs=fs), y0)
+tmax = torch.tensor([1.25], dtype=torch.float64, device=dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); assert float(tmax) == 1.25
+chk = torch.stack([p.detach().double().sum() for p in m.parameters()]).sum().reshape(1)
+allc = [torch.empty_like(chk)]; dist.all_gather(allc, chk); assert torch.equal(allc[0], chk)
+clip = (torch.rand(3, 16, 24, 3, device=dev) * 255).to(torch.uint8)
+got = parallel.gather_results({0: clip}, 1, _force=True)
+assert len(got) == 1 and torch.equal(got[0], clip)
+torch.cuda.synchronize(); dist.barrier()
+parallel.shutdown()
+print("RCCL-ONE-RANK-OK")
+"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -50,16 +50,20 @@ def owner_of(index, world):
 
 
 @torch.no_grad()
-def broadcast_module_(module, src=0, bucket_bytes=256 << 20):
+def broadcast_module_(module, src=0, bucket_bytes=256 << 20, _force=False):
     """Make every rank's parameters and buffers equal to rank `src`'s with a few large broadcasts (xGMI is
-    point-to-point: few big messages beat thousands of small ones).  Tensors are grouped by dtype into flat buckets."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    point-to-point: few big messages beat thousands of small ones).  Tensors are grouped by (dtype, device) into flat
+    buckets; under RCCL a tensor that lives on the host is staged through the current GPU.
+    `_force`: run the collectives even in a one-rank group (tests/test_entry_gpu.py exercises the RCCL path on one GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _force):
         return module
+    rccl = dist.get_backend() == "nccl"
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
-    by_dtype = {}
+    groups = {}
     for t in tensors:
-        by_dtype.setdefault(t.dtype, []).append(t)
-    for dtype, group in by_dtype.items():
+        groups.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, device), group in groups.items():
+        staged = rccl and device.type != "cuda"
         bucket, size = [], 0
         for t in group + [None]:
             if t is not None and (size + t.numel() * t.element_size() <= bucket_bytes or not bucket):
@@ -67,7 +71,11 @@ def broadcast_module_(module, src=0, bucket_bytes=256 << 20):
                 size += t.numel() * t.element_size()
                 continue
             flat = torch.cat([b.reshape(-1) for b in bucket])
+            if staged:
+                flat = flat.cuda()
             dist.broadcast(flat, src=src)
+            if staged:
+                flat = flat.to(device)
             off = 0
             for b in bucket:
                 b.copy_(flat[off:off + b.numel()].view_as(b))
@@ -92,10 +100,11 @@ def broadcast_tensor(t, src=0):
     return t
 
 
-def gather_results(local, n_items, dst=0):
+def gather_results(local, n_items, dst=0, _force=False):
     """local: {item index: tensor} owned by this rank (all tensors of one shape/dtype).  Returns on rank `dst` the list
-    of all n_items results in item order (None elsewhere).  One all_gather of a padded stack per call."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    of all n_items results in item order (None elsewhere).  One all_gather of a padded stack per call.
+    (`_force`: as in broadcast_module_.)"""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _force):
         return [local[i] for i in range(n_items)]
     rank, world = dist.get_rank(), dist.get_world_size()
     per_rank = (n_items + world - 1) // world
