@@ -337,6 +337,29 @@ def gen_igs(out):
         print("igs", tag, tuple(vid.shape), float(vid.abs().mean()), "randn calls", int(out[f"igs_{tag}_randn_calls"]))
 
 
+def gen_state_dict_full(out):
+    """Parameter / buffer names and shapes of the reference's UNetModel, AutoencoderKL and Resampler at the sizes of the two
+    shipped YAMLs (built on the meta device: no memory, no arithmetic).  `load_state_dict(strict=True)` of a real checkpoint
+    (utils/diffusion_utils.py:88) succeeds exactly when these match."""
+    from viewcrafter_amd.config import load_yaml
+    from lvdm.models.autoencoder import AutoencoderKL
+    from lvdm.modules.encoders.resampler import Resampler
+    from lvdm.modules.networks.openaimodel3d import UNetModel
+    for cfg in ("inference_pvd_1024.yaml", "inference_pvd_512.yaml"):
+        mp = load_yaml(os.path.join(ROOT, "configs", cfg))["model"]["params"]
+        with torch.device("meta"):
+            mods = {"unet": UNetModel(**dict(mp["unet_config"]["params"])),
+                    "vae": AutoencoderKL(**dict(mp["first_stage_config"]["params"])),
+                    "resampler": Resampler(**dict(mp["image_proj_stage_config"]["params"]))}
+        for name, m in mods.items():
+            sd = m.state_dict()
+            keys = sorted(sd.keys())
+            tag = f"{cfg.split('.')[0]}__{name}"
+            out[tag + "__keys"] = np.array(keys)
+            out[tag + "__shapes"] = np.array([",".join(str(d) for d in sd[k].shape) for k in keys])
+            print(tag, len(keys), "entries,", sum(sd[k].numel() for k in keys) / 1e6, "M elements")
+
+
 def main():
     try:      # condition.py imports these; resolve transformers' lazy modules before the torchvision stub confuses its probes
         from transformers import T5Tokenizer, T5EncoderModel, CLIPTokenizer, CLIPTextModel  # noqa: F401
@@ -345,7 +368,8 @@ def main():
     import_reference()
     torch.set_num_threads(8)
     for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
-                     ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs)):
+                     ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs),
+                     ("state_dict_full", gen_state_dict_full)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         out = {}

@@ -106,6 +106,30 @@ def test_state_dict_names_and_shapes_equal_the_reference(tiny_model):
     assert "model.diffusion_model.input_blocks.1.0.temopral_conv.conv2.3.weight" in sd  # (sic) + Dropout index shift
 
 
+@pytest.mark.parametrize("cfg", ["inference_pvd_1024", "inference_pvd_512"])
+def test_full_size_state_dict_contract(cfg):
+    """At the sizes of the shipped YAMLs (1.44 B-parameter UNet: 1516 entries; VAE 248; Resampler 51) every parameter / buffer name
+    and shape equals what the reference's modules register (tests/golden/state_dict_full.npz, written by the imported reference on
+    the meta device): a real ViewCrafter checkpoint loads with strict=True.  Built on the meta device here too (no memory)."""
+    from viewcrafter_amd.lvdm.models.autoencoder import AutoencoderKL
+    from viewcrafter_amd.lvdm.modules.encoders.resampler import Resampler
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    mp = load_yaml(os.path.join(ROOT, "configs", cfg + ".yaml"))["model"]["params"]
+    g = golden("state_dict_full")
+    with torch.device("meta"):
+        mods = {"unet": UNetModel(**dict(mp["unet_config"]["params"])),
+                "vae": AutoencoderKL(**dict(mp["first_stage_config"]["params"])),
+                "resampler": Resampler(**dict(mp["image_proj_stage_config"]["params"]))}
+    counts = {}
+    for name, m in mods.items():
+        ref = {str(k): tuple(int(d) for d in str(s).split(",") if d) for k, s in zip(g[f"{cfg}__{name}__keys"], g[f"{cfg}__{name}__shapes"])}
+        mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert mine == ref, (name, sorted(set(ref) ^ set(mine))[:5], [(k, ref[k], mine[k]) for k in ref if k in mine and ref[k] != mine[k]][:5])
+        counts[name] = (len(mine), sum(int(np.prod(s)) if s else 1 for s in mine.values()))
+    assert counts["unet"][0] == 1516 and abs(counts["unet"][1] / 1e6 - 1438.85) < 0.01
+    assert counts["vae"][0] == 248 and counts["resampler"][0] == 51
+
+
 def test_zero_initialised_layers_like_the_reference():
     from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
     m = UNetModel(**TINY_UNET)
