@@ -20,6 +20,8 @@ def get_parser():
     p.add_argument("--d_theta", nargs="+", type=int, default=10., help="target theta")
     p.add_argument("--d_phi", nargs="+", type=int, default=30., help="target phi")
     p.add_argument("--d_r", nargs="+", type=float, default=-.2, help="target radius change")
+    p.add_argument("--d_x", nargs="+", type=float, default=0., help="pan right (+) / left, single_view_target")
+    p.add_argument("--d_y", nargs="+", type=float, default=0., help="pan up (+) / down, single_view_target")
     p.add_argument("--mask_image", type=bool, default=False)
     p.add_argument("--mask_pc", type=bool, default=True)
     p.add_argument("--reduce_pc", default=False)

@@ -360,6 +360,28 @@ def gen_state_dict_full(out):
             print(tag, len(keys), "entries,", sum(sd[k].numel() for k in keys) / 1e6, "M elements")
 
 
+def parser_surface(parser):
+    """(flag, type name, repr(default), repr(nargs), action class name) of every option of an argparse parser."""
+    rows = []
+    for a in parser._actions:
+        for opt in a.option_strings:
+            if opt.startswith("--") and opt != "--help":
+                rows.append((opt, getattr(a.type, "__name__", str(a.type)), repr(a.default), repr(a.nargs), type(a).__name__))
+    return sorted(rows)
+
+
+def gen_cli(out):
+    """The command-line surface of `python inference.py` (configs/infer_config.py:7-59), read from the reference's own parser."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_infer_config", os.path.join(REF, "configs", "infer_config.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = parser_surface(mod.get_parser())
+    for i, name in enumerate(("flag", "type", "default", "nargs", "action")):
+        out[name] = np.array([r[i] for r in rows])
+    print("cli:", len(rows), "options")
+
+
 def main():
     try:      # condition.py imports these; resolve transformers' lazy modules before the torchvision stub confuses its probes
         from transformers import T5Tokenizer, T5EncoderModel, CLIPTokenizer, CLIPTextModel  # noqa: F401
@@ -369,7 +391,7 @@ def main():
     torch.set_num_threads(8)
     for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
                      ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs),
-                     ("state_dict_full", gen_state_dict_full)):
+                     ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         out = {}

@@ -364,3 +364,23 @@ def test_pack_conv_slab_major_order_for_64_channel_multiples():
     assert torch.allclose(out, ref, atol=1e-4)
     w1 = synth_input("w_1x1", (5, 128, 1, 1))
     assert torch.equal(pack_conv(w1), w1[:, :, 0, 0])
+
+
+def test_cli_surface_equals_the_reference_parser():
+    """Every `python inference.py` option of the reference (configs/infer_config.py:7-59, read from its own argparse parser into
+    tests/golden/cli_flags.npz) exists here with the same type, default, nargs and action; this repo only adds options."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vcx_infer_config", os.path.join(ROOT, "configs", "infer_config.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mine = {}
+    for a in mod.get_parser()._actions:
+        for opt in a.option_strings:
+            if opt.startswith("--") and opt != "--help":
+                mine[opt] = (getattr(a.type, "__name__", str(a.type)), repr(a.default), repr(a.nargs), type(a).__name__)
+    g = golden("cli_flags")
+    ref = {str(f): (str(t), str(d), str(n), str(ac)) for f, t, d, n, ac in zip(g["flag"], g["type"], g["default"], g["nargs"], g["action"])}
+    assert len(ref) == 44
+    assert not [f for f in ref if f not in mine], [f for f in ref if f not in mine]
+    assert not {f: (ref[f], mine[f]) for f in ref if ref[f] != mine[f]}, {f: (ref[f], mine[f]) for f in ref if ref[f] != mine[f]}
+    assert sorted(set(mine) - set(ref)) == ["--reference_root", "--renderings"]
