@@ -382,6 +382,59 @@ def gen_cli(out):
     print("cli:", len(rows), "options")
 
 
+API_SURFACE = {
+    "utils/diffusion_utils.py": ["instantiate_from_config", "get_obj_from_str", "load_model_checkpoint", "image_guided_synthesis",
+                                 "get_latent_z", "count_params", "check_istarget", "setup_dist"],
+    "lvdm/models/samplers/ddim.py": ["DDIMSampler.__init__", "DDIMSampler.make_schedule", "DDIMSampler.sample", "DDIMSampler.ddim_sampling",
+                                     "DDIMSampler.p_sample_ddim", "DDIMSampler.stochastic_encode", "DDIMSampler.decode"],
+    "lvdm/models/samplers/ddim_multiplecond.py": ["DDIMSampler.__init__", "DDIMSampler.make_schedule", "DDIMSampler.sample",
+                                                  "DDIMSampler.ddim_sampling", "DDIMSampler.p_sample_ddim"],
+    "lvdm/modules/networks/openaimodel3d.py": ["UNetModel.__init__", "UNetModel.forward"],
+    "lvdm/models/autoencoder.py": ["AutoencoderKL.__init__", "AutoencoderKL.encode", "AutoencoderKL.decode", "AutoencoderKL.forward"],
+    "lvdm/models/ddpm3d.py": ["DDPM.__init__", "DDPM.q_sample", "DDPM.predict_start_from_z_and_v", "DDPM.predict_eps_from_z_and_v",
+                              "LatentDiffusion.__init__", "LatentDiffusion.apply_model", "LatentDiffusion.decode_first_stage",
+                              "LatentDiffusion.encode_first_stage", "LatentDiffusion.get_learned_conditioning", "LatentDiffusion.decode_core",
+                              "LatentDiffusion.get_first_stage_encoding", "LatentVisualDiffusion.__init__",
+                              "DiffusionWrapper.__init__", "DiffusionWrapper.forward"],
+    "lvdm/modules/encoders/resampler.py": ["Resampler.__init__", "Resampler.forward"],
+    "lvdm/modules/encoders/condition.py": ["FrozenOpenCLIPEmbedder.__init__", "FrozenOpenCLIPEmbedder.forward", "FrozenOpenCLIPEmbedder.encode",
+                                           "FrozenOpenCLIPImageEmbedderV2.__init__", "FrozenOpenCLIPImageEmbedderV2.forward"],
+    "viewcrafter.py": ["ViewCrafter.__init__", "ViewCrafter.run_diffusion", "ViewCrafter.setup_diffusion", "ViewCrafter.nvs_single_view",
+                       "ViewCrafter.nvs_sparse_view_interp", "ViewCrafter.nvs_single_view_eval"],
+    "utils/pvd_utils.py": ["save_video"],
+    "lvdm/common.py": ["gather_data", "extract_into_tensor", "noise_like", "default", "exists"],
+    "lvdm/models/utils_diffusion.py": ["timestep_embedding", "make_beta_schedule", "make_ddim_timesteps", "make_ddim_sampling_parameters",
+                                       "rescale_noise_cfg", "rescale_zero_terminal_snr"],
+}
+
+
+def gen_api(out):
+    """Call signatures (parameter order, default expressions, *args / **kwargs) of the functions and methods on the drop-in boundary
+    (SURVEY.md section 8b), read from the reference's SOURCE with `ast` - viewcrafter.py and pvd_utils.py cannot be imported here."""
+    import ast
+    import json
+    table = {}
+    for rel, wanted in API_SURFACE.items():
+        tree = ast.parse(open(os.path.join(REF, rel)).read())
+        found = {}
+
+        def visit(node, prefix):
+            for n in getattr(node, "body", []):
+                if isinstance(n, ast.ClassDef):
+                    visit(n, prefix + n.name + ".")
+                elif isinstance(n, ast.FunctionDef) and prefix + n.name in wanted:
+                    a = n.args
+                    pos = [x.arg for x in a.posonlyargs + a.args]
+                    dft = [None] * (len(pos) - len(a.defaults)) + [ast.unparse(d) for d in a.defaults]
+                    found[prefix + n.name] = {"args": list(zip(pos, dft)), "vararg": bool(a.vararg), "kwarg": bool(a.kwarg)}
+        visit(tree, "")
+        missing = sorted(set(wanted) - set(found))
+        assert not missing, (rel, missing)
+        table[rel] = found
+    out["json"] = np.array(json.dumps(table, sort_keys=True))
+    print("api:", sum(len(v) for v in table.values()), "callables in", len(table), "files")
+
+
 def main():
     try:      # condition.py imports these; resolve transformers' lazy modules before the torchvision stub confuses its probes
         from transformers import T5Tokenizer, T5EncoderModel, CLIPTokenizer, CLIPTextModel  # noqa: F401
@@ -391,7 +444,7 @@ def main():
     torch.set_num_threads(8)
     for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
                      ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs),
-                     ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli)):
+                     ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli), ("api_signatures", gen_api)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         out = {}

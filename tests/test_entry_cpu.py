@@ -148,3 +148,30 @@ def test_inference_main_shards_trajectories_over_two_ranks(tmp_path, sparse):
     assert outs[0] == pytest.approx(exp, abs=1e-5), (outs[0], exp)
     assert os.path.exists(os.path.join(tmp, "out", "e", "diffusion.avi" if sparse else "diffusion4.avi")) or \
         os.path.exists(os.path.join(tmp, "out", "e", "diffusion.mp4" if sparse else "diffusion4.mp4"))
+
+
+def test_viewcrafter_forwards_the_reference_class_surface(tmp_path, monkeypatch):
+    """Methods and attributes of the reference's ViewCrafter that this repo does not re-implement (run_dust3r, load_initial_images,
+    the scene state its methods leave behind) resolve on the attached reference object; without a checkout the error says so."""
+    import viewcrafter
+    os.makedirs(tmp_path / "ref")
+    (tmp_path / "ckpt").write_text("x")
+    (tmp_path / "ref" / "viewcrafter.py").write_text(_FAKE_REFERENCE + '''
+    def run_dust3r(self, input_images, clean_pc=False):
+        self.scene = ("scene of", len(input_images))
+        return self.scene
+''')
+    monkeypatch.setattr(viewcrafter, "build_diffusion_model", lambda *a, **k: _StubModel())
+    from configs.infer_config import get_parser
+    base = ["--config", "none.yaml", "--ckpt_path", str(tmp_path / "ckpt"), "--out_dir", str(tmp_path / "out"), "--exp_name", "e",
+            "--device", "cpu", "--video_length", "3", "--height", "16", "--width", "16"]
+    opts = get_parser().parse_args(base + ["--mode", "sparse_view_interp", "--reference_root", str(tmp_path / "ref")])
+    opts.save_dir = str(tmp_path / "out")
+    os.makedirs(opts.save_dir, exist_ok=True)
+    vc = viewcrafter.ViewCrafter(opts)
+    assert vc.run_dust3r([1, 2, 3]) == ("scene of", 3) and vc.scene == ("scene of", 3)
+    with pytest.raises(AttributeError):
+        vc.no_such_thing
+    bare = viewcrafter.ViewCrafter.__new__(viewcrafter.ViewCrafter)
+    with pytest.raises(AttributeError, match="no reference checkout attached"):
+        bare.run_dust3r

@@ -384,3 +384,62 @@ def test_cli_surface_equals_the_reference_parser():
     assert not [f for f in ref if f not in mine], [f for f in ref if f not in mine]
     assert not {f: (ref[f], mine[f]) for f in ref if ref[f] != mine[f]}, {f: (ref[f], mine[f]) for f in ref if ref[f] != mine[f]}
     assert sorted(set(mine) - set(ref)) == ["--reference_root", "--renderings"]
+
+
+def test_call_signatures_on_the_boundary_equal_the_reference():
+    """65 functions / methods of the drop-in boundary: every parameter the reference declares (read from its
+    source with `ast` into tests/golden/api_signatures.npz) exists here, in the same position and with the same default, and a
+    reference **kwargs stays a **kwargs; this repo only ever appends parameters.  Inherited methods count (the multi-condition
+    sampler subclasses DDIMSampler here)."""
+    import ast
+    import importlib
+    import inspect
+    import json
+    table = json.loads(str(golden("api_signatures")["json"]))
+    where = {"viewcrafter.py": "viewcrafter", "utils/diffusion_utils.py": "viewcrafter_amd.utils.diffusion_utils",
+             "utils/pvd_utils.py": "viewcrafter_amd.utils.pvd_utils"}
+    # defaults that are deliberately more permissive here (a required argument of the reference has a default)
+    relaxed = {("lvdm/models/autoencoder.py", "AutoencoderKL.__init__"): {"lossconfig", "embed_dim"}}
+    problems, checked = [], 0
+    for rel, funcs in table.items():
+        mod = importlib.import_module(where.get(rel, "viewcrafter_amd." + rel[:-3].replace("/", ".")))
+        for qual, ref in funcs.items():
+            obj = mod
+            try:
+                for part in qual.split("."):
+                    obj = getattr(obj, part)
+            except AttributeError:
+                problems.append(f"{rel}:{qual} missing")
+                continue
+            sig = inspect.signature(obj)
+            mine = list(sig.parameters.values())
+            names = [p.name for p in mine]
+            for pos, (name, dflt) in enumerate(ref["args"]):
+                if name not in names:
+                    problems.append(f"{rel}:{qual} lacks parameter {name}")
+                    continue
+                p = mine[names.index(name)]
+                if names.index(name) != pos:
+                    problems.append(f"{rel}:{qual} parameter {name} at position {names.index(name)} (reference {pos})")
+                if dflt is None:
+                    if p.default is not inspect.Parameter.empty and name not in relaxed.get((rel, qual), ()):
+                        problems.append(f"{rel}:{qual} {name} is required in the reference")
+                    continue
+                if p.default is inspect.Parameter.empty:
+                    problems.append(f"{rel}:{qual} {name} has no default (reference {dflt})")
+                    continue
+                try:
+                    want = ast.literal_eval(dflt)
+                except Exception:
+                    continue                     # a non-literal default expression: presence and position are what is checked
+                have = p.default
+                same = (list(have) == list(want)) if isinstance(want, (list, tuple)) and isinstance(have, (list, tuple)) else (have == want and type(have) is type(want))
+                if not same:
+                    problems.append(f"{rel}:{qual} {name} default {have!r} (reference {want!r})")
+            if ref["kwarg"] and not any(p.kind is inspect.Parameter.VAR_KEYWORD for p in mine):
+                problems.append(f"{rel}:{qual} has no **kwargs")
+            if ref["vararg"] and not any(p.kind is inspect.Parameter.VAR_POSITIONAL for p in mine):
+                problems.append(f"{rel}:{qual} has no *args")
+            checked += 1
+    assert not problems, "\n".join(problems)
+    assert checked == 65

@@ -212,6 +212,30 @@ def test_ddim_trajectory_vs_reference_golden(model, eta):
         assert p >= 30.0
 
 
+def test_sampler_decode_walks_the_same_trajectory_as_ddim_sampling(model):
+    """DDIMSampler.decode (reference ddim.py:284-303) from x_T over all t_start = S steps is ddim_sampling at eta = 0 with the
+    options decode() cannot pass (fs, guidance_rescale) left at their defaults: bit-identical latents."""
+    from viewcrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    cd = TINY_UNET["context_dim"]
+    b, t, h, w = 1, 4, 32, 16
+    cat = synth_input("ddim_cat", (b, 4, t, h, w), scale=0.8).to(DEV)
+    cond = {"c_crossattn": [synth_input("ddim_ctx", (b, 77 + 16 * t, cd)).to(DEV)], "c_concat": [cat]}
+    uc = {"c_crossattn": [synth_input("ddim_uctx", (b, 77 + 16 * t, cd)).to(DEV)], "c_concat": [cat]}
+    x_T = synth_input("ddim_xT", (b, 4, t, h, w)).to(DEV)
+    s = DDIMSampler(model)
+    with torch.no_grad():
+        ref, _ = s.sample(S=4, conditioning=cond, batch_size=b, shape=[4, t, h, w], verbose=False, unconditional_guidance_scale=7.5,
+                          unconditional_conditioning=uc, eta=0.0, timestep_spacing="uniform_trailing", x_T=x_T)
+        calls = []
+        out = s.decode(x_T.clone(), cond, t_start=4, unconditional_guidance_scale=7.5, unconditional_conditioning=uc,
+                       callback=calls.append)
+        part = s.decode(x_T.clone(), cond, t_start=2, unconditional_guidance_scale=7.5, unconditional_conditioning=uc)
+    assert calls == [0, 1, 2, 3] and torch.equal(out, ref)
+    assert torch.isfinite(part).all() and not torch.equal(part, out)
+    with pytest.raises(NotImplementedError):
+        s.decode(x_T, cond, t_start=2, use_original_steps=True)
+
+
 def test_multicond_ddim_trajectory_vs_reference_golden(model):
     """DDIMSampler of ddim_multiplecond.py (3 conditionings run as one B=3 forward, vcx_ddim_step3_f32)."""
     from viewcrafter_amd.lvdm.models.samplers.ddim_multiplecond import DDIMSampler as DDIMSamplerMulti

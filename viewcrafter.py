@@ -136,6 +136,15 @@ class ViewCrafter:
                 return ours.run_diffusion(renderings)
         self._ref = _Geometry(self.opts, gradio=self.gradio)
 
+    def __getattr__(self, name):
+        """Everything else the reference's class offers (run_dust3r, load_initial_images, the scene / image attributes its
+        methods leave behind, ...) lives on the attached reference object."""
+        ref = self.__dict__.get("_ref")
+        if ref is not None and not name.startswith("__"):
+            return getattr(ref, name)
+        raise AttributeError(f"{type(self).__name__!s} has no attribute {name!r}"
+                             + ("" if ref is not None else " (no reference checkout attached: geometry stages unavailable)"))
+
     def nvs_single_view(self, gradio=False):
         return self._ref.nvs_single_view(gradio)
 

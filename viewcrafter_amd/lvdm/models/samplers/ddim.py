@@ -219,6 +219,24 @@ class DDIMSampler(object):
         return x_prev, pred_x0
 
     @torch.no_grad()
+    def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
+               use_original_steps=False, callback=None):
+        """Reference ddim.py:284-303: denoise `x_latent` (a latent noised to schedule index t_start, e.g. by stochastic_encode)
+        through the first t_start DDIM steps.  Needs make_schedule() first, like the reference; extra sampler options
+        (fs, guidance_rescale) are not part of this signature there either."""
+        if use_original_steps:
+            raise NotImplementedError("DDPM-step decoding is not on the ViewCrafter path")
+        steps = np.asarray(self.ddim_timesteps)[:t_start]
+        x = x_latent
+        for done, index in enumerate(range(len(steps) - 1, -1, -1)):
+            ts = torch.full((x.shape[0],), int(steps[index]), device=x.device, dtype=torch.long)
+            x, _ = self.p_sample_ddim(x, cond, ts, index=index, unconditional_guidance_scale=unconditional_guidance_scale,
+                                      unconditional_conditioning=unconditional_conditioning)
+            if callback:
+                callback(done)
+        return x
+
+    @torch.no_grad()
     def stochastic_encode(self, x0, t, use_original_steps=False, noise=None):
         """Reference ddim.py:306-319."""
         if use_original_steps:

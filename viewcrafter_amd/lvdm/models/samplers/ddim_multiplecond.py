@@ -21,6 +21,20 @@ class DDIMSampler(_DDIMSampler):
             self.ddim_scale_arr_prev = torch.cat([self.ddim_scale_arr[0:1], self.ddim_scale_arr[:-1]])
             self._host["ratio"] = (self.ddim_scale_arr_prev / self.ddim_scale_arr).numpy()
 
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                      temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, uc_type=None,
+                      cfg_img=None, mask=None, x0=None, guidance_rescale=0.0, **kwargs):
+        """Reference ddim_multiplecond.py:207-291: the same step with `cfg_img` as a named parameter (in the slot where the plain
+        sampler has conditional_guidance_scale_temporal)."""
+        return super().p_sample_ddim(x, c, t, index, repeat_noise=repeat_noise, use_original_steps=use_original_steps,
+                                     quantize_denoised=quantize_denoised, temperature=temperature, noise_dropout=noise_dropout,
+                                     score_corrector=score_corrector, corrector_kwargs=corrector_kwargs,
+                                     unconditional_guidance_scale=unconditional_guidance_scale,
+                                     unconditional_conditioning=unconditional_conditioning, uc_type=uc_type, mask=mask, x0=x0,
+                                     guidance_rescale=guidance_rescale, cfg_img=cfg_img, **kwargs)
+
     def _model_outputs(self, x, t, c, unconditional_conditioning, unconditional_guidance_scale, kwargs):
         cfg_img = kwargs.pop("cfg_img", None)
         if cfg_img is None:

@@ -20,6 +20,28 @@ TARGET_ALIASES = {
 }
 
 
+def count_params(model, verbose=False):
+    """Reference utils/diffusion_utils.py:12-16."""
+    n = sum(p.numel() for p in model.parameters())
+    if verbose:
+        print(f"{type(model).__name__} has {n * 1e-6:.2f} M params.")
+    return n
+
+
+def check_istarget(name, para_list):
+    """Reference utils/diffusion_utils.py:19-28: does the full parameter name contain any of the partial names?"""
+    return any(part in name for part in para_list)
+
+
+def setup_dist(args):
+    """Reference utils/diffusion_utils.py:74-81 (nccl = RCCL on ROCm, env:// rendezvous); `args.local_rank` selects the GPU."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return
+    torch.cuda.set_device(args.local_rank)
+    dist.init_process_group("nccl", init_method="env://")
+
+
 def get_obj_from_str(string, reload=False):
     string = TARGET_ALIASES.get(string, string)
     module, cls = string.rsplit(".", 1)

@@ -16,6 +16,8 @@ def _to_uint8(data, value_range):
     """[T, H, W, 3] float in value_range -> uint8, like the reference ((x - lo) / (hi - lo) * 255, clamped)."""
     if isinstance(data, np.ndarray):
         data = torch.from_numpy(data)
+    if data.dtype == torch.uint8 or value_range is None:        # already pixel values
+        return data.detach().cpu().to(torch.uint8).numpy()
     data = data.detach().float().cpu()
     lo, hi = value_range
     data = ((data - lo) / (hi - lo)).clamp(0, 1) * 255.0
