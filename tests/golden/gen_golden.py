@@ -91,6 +91,8 @@ def gen_schedules(out):
     betas = ud.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
     out["betas_linear"] = betas
     out["betas_zero_snr"] = ud.rescale_zero_terminal_snr(betas)
+    for other in ("cosine", "sqrt_linear", "sqrt"):          # not used by the ViewCrafter YAMLs; part of make_beta_schedule's contract
+        out[f"betas_{other}"] = np.asarray(ud.make_beta_schedule(other, 1000, linear_start=0.00085, linear_end=0.012), dtype=np.float64)
     for method, n in (("uniform_trailing", 50), ("uniform_trailing", 5), ("uniform_trailing", 10), ("uniform", 50), ("quad", 20)):
         out[f"ddim_timesteps_{method}_{n}"] = np.asarray(ud.make_ddim_timesteps(method, n, 1000, verbose=False))
     acp = torch.tensor(np.cumprod(1.0 - out["betas_zero_snr"]), dtype=torch.float32)

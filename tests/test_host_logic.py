@@ -59,6 +59,11 @@ def test_schedule_functions_match_reference():
     betas = ud.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
     assert np.array_equal(betas, g["betas_linear"])
     assert np.allclose(ud.rescale_zero_terminal_snr(betas), g["betas_zero_snr"], rtol=0, atol=1e-15)
+    for other in ("cosine", "sqrt_linear", "sqrt"):
+        assert np.array_equal(np.asarray(ud.make_beta_schedule(other, 1000, linear_start=0.00085, linear_end=0.012), dtype=np.float64),
+                              g[f"betas_{other}"]), other
+    with pytest.raises(ValueError):
+        ud.make_beta_schedule("nope", 1000)
     for method, n in (("uniform_trailing", 50), ("uniform_trailing", 5), ("uniform_trailing", 10), ("uniform", 50), ("quad", 20)):
         assert np.array_equal(ud.make_ddim_timesteps(method, n, 1000, verbose=False), g[f"ddim_timesteps_{method}_{n}"])
     with pytest.raises(NotImplementedError):
