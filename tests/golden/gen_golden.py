@@ -108,6 +108,12 @@ def gen_schedules(out):
     a = synth_input("cfg_a", (2, 4, 3, 8, 8))
     b = synth_input("cfg_b", (2, 4, 3, 8, 8))
     out["rescale_noise_cfg"] = ud.rescale_noise_cfg(a, b, guidance_rescale=0.7).numpy()
+    # the VAE posterior class (lvdm/distributions.py:24-65)
+    from lvdm.distributions import DiagonalGaussianDistribution
+    moments, moments2 = synth_input("gauss_moments", (2, 8, 4, 6), scale=3.0), synth_input("gauss_moments2", (2, 8, 4, 6), scale=1.5)
+    post, other = DiagonalGaussianDistribution(moments), DiagonalGaussianDistribution(moments2)
+    x = post.sample(noise=synth_input("gauss_noise", (2, 4, 4, 6)))
+    out["gauss_sample"], out["gauss_kl"], out["gauss_kl_other"], out["gauss_nll"] = x.numpy(), post.kl().numpy(), post.kl(other).numpy(), post.nll(x).numpy()
 
 
 def gen_unet(out):

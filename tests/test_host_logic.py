@@ -76,6 +76,15 @@ def test_schedule_functions_match_reference():
     from oracle.weights import synth_input
     a, b = synth_input("cfg_a", (2, 4, 3, 8, 8)), synth_input("cfg_b", (2, 4, 3, 8, 8))
     assert np.allclose(ud.rescale_noise_cfg(a, b, 0.7).numpy(), g["rescale_noise_cfg"], atol=1e-6)
+    # VAE posterior (lvdm/distributions.py:24-65): sample with supplied noise, kl to N(0, 1) and to another posterior, nll
+    from viewcrafter_amd.lvdm.distributions import DiagonalGaussianDistribution
+    post = DiagonalGaussianDistribution(synth_input("gauss_moments", (2, 8, 4, 6), scale=3.0))
+    other = DiagonalGaussianDistribution(synth_input("gauss_moments2", (2, 8, 4, 6), scale=1.5))
+    x = post.sample(noise=synth_input("gauss_noise", (2, 4, 4, 6)))
+    for have, key in ((x, "gauss_sample"), (post.kl(), "gauss_kl"), (post.kl(other), "gauss_kl_other"), (post.nll(x), "gauss_nll")):
+        assert np.allclose(have.numpy(), g[key], rtol=1e-6, atol=1e-6), key
+    det = DiagonalGaussianDistribution(synth_input("gauss_moments", (2, 8, 4, 6)), deterministic=True)
+    assert torch.equal(det.sample(), det.mode()) and float(det.kl()) == 0.0 and float(det.nll(x)) == 0.0
 
 
 def test_model_buffers_and_sampler_tables_match_reference(tiny_model):

@@ -21,3 +21,21 @@ class DiagonalGaussianDistribution(object):
 
     def mode(self):
         return self.mean
+
+    # ---- the two statistics the reference class also offers (distributions.py:42-63); not used by inference
+    def kl(self, other=None):
+        """KL(self || other) summed over (C, H, W); `other` defaults to the standard normal.  A deterministic posterior reports 0."""
+        if self.deterministic:
+            return torch.Tensor([0.])
+        if other is None:
+            terms = self.mean.pow(2) + self.var - 1.0 - self.logvar
+        else:
+            terms = (self.mean - other.mean).pow(2) / other.var + self.var / other.var - 1.0 - self.logvar + other.logvar
+        return 0.5 * terms.sum(dim=[1, 2, 3])
+
+    def nll(self, sample, dims=(1, 2, 3)):
+        """Negative log-likelihood of `sample` under the posterior, summed over `dims`."""
+        if self.deterministic:
+            return torch.Tensor([0.])
+        log_2pi = 1.8378770664093453
+        return 0.5 * (log_2pi + self.logvar + (sample - self.mean).pow(2) / self.var).sum(dim=list(dims))
