@@ -457,3 +457,18 @@ def test_call_signatures_on_the_boundary_equal_the_reference():
             checked += 1
     assert not problems, "\n".join(problems)
     assert checked == 65
+
+
+def test_batched_posterior_noise_is_the_per_frame_stream():
+    """The reference encodes the condition video frame by frame (perframe_ae) and each frame's posterior draws its own CPU noise
+    (ddpm3d.py:630-637, distributions.py:35-40); here frames are encoded in one batch and the noise is ONE torch.randn over all
+    frames.  torch's CPU normal fill works in blocks of 16, so the two consume the generator identically whenever a frame's latent
+    has a multiple of 16 elements (4 * h * w with h * w % 4 == 0: every supported size) - a seeded run sees the reference's noise."""
+    from viewcrafter_amd.lvdm.distributions import DiagonalGaussianDistribution
+    for h, w in ((72, 128), (40, 64), (9, 16), (6, 10)):
+        moments = torch.zeros(3, 8, h, w)
+        torch.manual_seed(123)
+        batched = DiagonalGaussianDistribution(moments).sample()
+        torch.manual_seed(123)
+        per_frame = torch.cat([DiagonalGaussianDistribution(moments[i:i + 1]).sample() for i in range(3)])
+        assert torch.equal(batched, per_frame), (h, w)
