@@ -8,6 +8,7 @@ run_diffusion to it.  `nvs_from_renderings` runs the diffusion leg alone on save
 """
 import importlib
 import os
+import random
 import sys
 
 import numpy as np
@@ -38,8 +39,10 @@ class ViewCrafter:
     # ------------------------------------------------------------------ diffusion leg (this repo)
     def setup_diffusion(self):
         """Reference viewcrafter.py:384-404."""
-        torch.manual_seed(self.opts.seed)
+        # = pytorch_lightning.seed_everything(seed): python, numpy and torch (CPU + every GPU) generators
+        random.seed(self.opts.seed)
         np.random.seed(self.opts.seed)
+        torch.manual_seed(self.opts.seed)
         root = _reference_root(self.opts)
         if root and root not in sys.path:
             sys.path.append(root)           # lets the YAML's CLIP / Resampler targets resolve to the reference
