@@ -151,6 +151,7 @@ def main():
                     "(HIP-event profiling cannot run inside a graph: the roofline is then measured on extra eager steps)")
     ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the timed region")
     ap.add_argument("--no-gpu-legs", action="store_true", help="skip parity-vs-oracle and the eager fp16 baseline on the GPU")
+    ap.add_argument("--no-extra", action="store_true", help="skip the step times of the other two published configurations")
     ap.add_argument("--no-video", action="store_true", help="skip the measured 50-step video after the timed region")
     ap.add_argument("--no-shared-prefix", action="store_true", help="evaluate cond and uncond as a plain B=2 forward (A/B of the "
                     "shared CFG prefix: the layers ahead of the first cross-attention see identical inputs and run once by default)")
@@ -377,6 +378,37 @@ def main():
                 assert torch.isfinite(vid).all() and vid.shape == (1, 3, T, 8 * h, 8 * w)
                 out["sec_per_video_scope"] = "measured: DDIMSampler.sample(S=50) + decode_first_stage of all frames, one trajectory on one GPU"
                 del vid, smp
+        if world == 1 and not args.no_extra:
+            # BASELINE.md publishes three s/video figures (120 / 75 / 50 s on A100-40G); the other two configurations run on the
+            # SAME UNet (the two YAMLs differ in image_size / base_scale only), so their step times are measured here too:
+            # 1 warm-up + 3 timed DDIM steps each, no profiling events, not part of `value`
+            published = {"ViewCrafter_25_576x1024x25": 120.0, "ViewCrafter_16_576x1024x16": 75.0, "ViewCrafter_25_512_320x512x25": 50.0}
+            out["extra"] = {}
+            for name, (_, T2, h2, w2) in WORKLOADS.items():
+                if name == args.workload:
+                    continue
+                x2, cond2, uc2 = synth_conditioning(T2, h2, w2, device, seed=123)
+                sampler._cfg_cache = None
+
+                def step2(xx, i):
+                    index = n_sched - 1 - i
+                    ts = torch.full((1,), int(sampler.ddim_timesteps[index]), device=device, dtype=torch.long)
+                    xx, _ = sampler.p_sample_ddim(xx, cond2, ts, index=index, unconditional_guidance_scale=7.5, unconditional_conditioning=uc2,
+                                                  fs=fs, guidance_rescale=0.7, cfg_img=None, unconditional_conditioning_img_nonetext=None)
+                    return xx
+                with torch.no_grad():
+                    x2 = step2(x2, 0)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(1, 4):
+                        x2 = step2(x2, i)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / 3
+                assert torch.isfinite(x2).all()
+                out["extra"][name] = {"ms_per_step": 1e3 * dt, "steps_per_s": 1.0 / dt, "latent": [T2, h2, w2], "steps_timed": 3,
+                                      "sec_per_50_steps": 50 * dt, "reference_published_sec_per_video_a100": published[name]}
+                del x2, cond2, uc2
+            sampler._cfg_cache = None
         from viewcrafter_amd.config import load_yaml
         mp_ = load_yaml(os.path.join(ROOT, "configs", cfg_name))["model"]["params"]
         hp = dict(mp_["unet_config"]["params"])

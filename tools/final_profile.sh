@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 python bench.py 2>&1 | grep '^{"metric' > gpurun_out/${tag}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_${tag}
-rocprofv3 --kernel-trace --stats -d /tmp/prof_${tag} -o ${tag} -- python ${root}/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-gpu-legs --no-video > /tmp/bench_prof_${tag}.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_${tag} -o ${tag} -- python ${root}/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-gpu-legs --no-video --no-extra > /tmp/bench_prof_${tag}.log 2>&1
 cd ${root}
 grep '^{"metric' /tmp/bench_prof_${tag}.log > gpurun_out/${tag}_bench_under_rocprof.json
 python tools/rocprof_summary.py $(find /tmp/prof_${tag} -name "*.db" | head -1) > gpurun_out/${tag}_kernel_stats.txt 2>&1

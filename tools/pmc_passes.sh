@@ -11,7 +11,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o pmc -- python ${root}/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-decode --no-profile --no-gpu-legs --no-video > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o pmc -- python ${root}/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-decode --no-profile --no-gpu-legs --no-video --no-extra > /tmp/pmc_$c.log 2>&1
   tail -2 /tmp/pmc_$c.log
 done
 cd ${root}
