@@ -472,3 +472,26 @@ def test_batched_posterior_noise_is_the_per_frame_stream():
         torch.manual_seed(123)
         per_frame = torch.cat([DiagonalGaussianDistribution(moments[i:i + 1]).sample() for i in range(3)])
         assert torch.equal(batched, per_frame), (h, w)
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The newest committed bench line (profiles/r02*_bench.json, written by `python bench.py` on an MI355X) has every field of the
+    bench contract with consistent values: value = n_gpus * steps / elapsed, roofline.frac = achieved / peak, inputs HBM-resident
+    synthetic data, a bounded CPU sample."""
+    import glob
+    import json
+    paths = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r02*_bench.json")) if "ViewCrafter" not in os.path.basename(p))
+    assert paths
+    d = json.loads(open(paths[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "DDIM steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f16" and "synthetic" in d["data"] and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["n_gpus"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    assert 3.0 < d["value"] < 8.0           # 576x1024x25 on one MI355X: the measured range of this code base
