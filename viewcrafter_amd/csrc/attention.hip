@@ -800,14 +800,8 @@ extern "C" int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const 
         x.rows_per_block = ((iters + split - 1) / split) * 512;
         x.split = (int)((x.rows_per_unit + x.rows_per_block - 1) / x.rows_per_block);
         constexpr int XSMEM = 6 * 64 * 64 * 2 * 2;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_resident_d64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XSMEM) != hipSuccess) {
-                vcx_set_error("vcx_attn_flash_dual_d64_f16: cannot reserve %d bytes of LDS", XSMEM);
-                return VCX_ELAUNCH;
-            }
-            attr_set = true;
-        }
+        static VcxLdsAttr lds;
+        if (!lds.ensure(reinterpret_cast<const void*>(xattn_resident_d64_kernel), XSMEM, "vcx_attn_flash_dual_d64_f16")) return VCX_ELAUNCH;
         hipLaunchKernelGGL(xattn_resident_d64_kernel, dim3(x.nunits * x.split), dim3(512), XSMEM, s, x);
         return vcx_check_launch("vcx_attn_flash_dual_d64_f16(resident)");
     }

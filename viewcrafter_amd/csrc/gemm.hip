@@ -355,13 +355,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
 
 }  // namespace
 int vcxgemm::persistent_grid(int ntiles, int blocks_per_cu) {
-    static int ncu = 0;
+    static std::atomic<int> cached{0};       // every GPU of a node is the same part: one query per process
+    int ncu = cached.load(std::memory_order_relaxed);
     if (ncu == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         ncu = 256;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             ncu = prop.multiProcessorCount;
+        cached.store(ncu, std::memory_order_relaxed);
     }
     const int slots = blocks_per_cu * ncu;   // resident blocks chip-wide (LDS- and VGPR-limited)
     if (ntiles <= slots) return ntiles;
@@ -375,16 +377,9 @@ namespace {
 template <int BN, bool CONV, bool GEGLU, bool OUT_F32>
 int launch(const GemmArgs& a, hipStream_t s) {
     constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
-    static bool attr_set = false;
+    static VcxLdsAttr lds;
     auto kern = gemm_kernel<BN, CONV, GEGLU, OUT_F32>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess) {
-            vcx_set_error("vcx_gemm_f16: cannot reserve %zu bytes of LDS", smem);
-            return VCX_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)smem, "vcx_gemm_f16")) return VCX_ELAUNCH;
     const int nb = persistent_grid(a.tiles_m * a.tiles_n);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(NTHREADS), smem, s, a);
     return vcx_check_launch("vcx_gemm_f16");

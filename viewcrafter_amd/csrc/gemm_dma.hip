@@ -260,15 +260,9 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
 
 template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32>
 int launch(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static VcxLdsAttr lds;
     auto kern = gemm_dma_kernel<Cfg, CONV, GEGLU, OUT_F32>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::SMEM) != hipSuccess) {
-            vcx_set_error("vcx_gemm_f16(dma): cannot reserve %zu bytes of LDS", Cfg::SMEM);
-            return VCX_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)Cfg::SMEM, "vcx_gemm_f16(dma)")) return VCX_ELAUNCH;
     const int blocks_per_cu = Cfg::SMEM > 80 * 1024 ? 1 : 2;
     const int nb = persistent_grid(a.tiles_m * a.tiles_n, blocks_per_cu);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(Cfg::THREADS), Cfg::SMEM, s, a, a.a_bytes, a.w_bytes);

@@ -269,15 +269,9 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_pp_kernel(GemmArgs p, un
 
 template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32>
 int launch(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static VcxLdsAttr lds;
     auto kern = gemm_pp_kernel<Cfg, CONV, GEGLU, OUT_F32>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::SMEM) != hipSuccess) {
-            vcx_set_error("vcx_gemm_f16(pp): cannot reserve %zu bytes of LDS", Cfg::SMEM);
-            return VCX_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)Cfg::SMEM, "vcx_gemm_f16(pp)")) return VCX_ELAUNCH;
     const int nb = persistent_grid(a.tiles_m * a.tiles_n, 1);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(Cfg::THREADS), Cfg::SMEM, s, a, a.a_bytes, a.w_bytes);
     return vcx_check_launch("vcx_gemm_f16(pp)");

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/vcx.h"
 
 typedef _Float16 half_t;
@@ -23,6 +24,26 @@ int vcx_check_launch(const char* what);
             return VCX_EINVAL;            \
         }                                 \
     } while (0)
+
+// ---- kernels that need more than the default 64 KB of dynamic LDS ----
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device), callable from any host thread: one instance per
+// kernel (function-local static), a bit per device already prepared.  A process that drives several GPUs prepares each of them.
+struct VcxLdsAttr {
+    std::atomic<unsigned> done{0};
+    // returns false (and sets the error text) if the runtime refuses the reservation
+    bool ensure(const void* kernel, int bytes, const char* who) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned bit = 1u << (dev & 31);
+        if (done.load(std::memory_order_acquire) & bit) return true;
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+            vcx_set_error("%s: cannot reserve %d bytes of LDS", who, bytes);
+            return false;
+        }
+        done.fetch_or(bit, std::memory_order_release);
+        return true;
+    }
+};
 
 // ---- profiling (api.hip) ----
 enum { VCX_FAM_GEMM = 0, VCX_FAM_FLASH = 1, VCX_FAM_TATTN = 2, VCX_FAM_GN = 3, VCX_FAM_LN = 4, VCX_FAM_ELT = 5 };
