@@ -443,6 +443,16 @@ def gen_api(out):
     print("api:", sum(len(v) for v in table.values()), "callables in", len(table), "files")
 
 
+def gen_yaml(out):
+    """The reference's two model YAMLs, parsed (configs/inference_pvd_{1024,512}.yaml), as JSON: what `instantiate_from_config`
+    receives when a user points this implementation at an unchanged reference checkout's config."""
+    import json
+    import yaml
+    for name in ("inference_pvd_1024", "inference_pvd_512"):
+        out[name] = np.array(json.dumps(yaml.safe_load(open(os.path.join(REF, "configs", name + ".yaml"))), sort_keys=True))
+        print(name, len(str(out[name])), "characters")
+
+
 def main():
     try:      # condition.py imports these; resolve transformers' lazy modules before the torchvision stub confuses its probes
         from transformers import T5Tokenizer, T5EncoderModel, CLIPTokenizer, CLIPTextModel  # noqa: F401
@@ -452,7 +462,7 @@ def main():
     torch.set_num_threads(8)
     for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
                      ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs),
-                     ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli), ("api_signatures", gen_api)):
+                     ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli), ("api_signatures", gen_api), ("reference_yaml", gen_yaml)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         out = {}

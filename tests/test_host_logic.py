@@ -495,3 +495,38 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert 3.0 < d["value"] < 8.0           # 576x1024x25 on one MI355X: the measured range of this code base
+
+
+@pytest.mark.parametrize("name", ["inference_pvd_1024", "inference_pvd_512"])
+def test_reference_yaml_selects_this_implementation(name):
+    """The reference's own YAML (parsed into tests/golden/reference_yaml.npz by the generator) differs from configs/<name>.yaml
+    only in training-only keys, and - unchanged, with its `lvdm.*` target strings - instantiates THIS implementation through
+    instantiate_from_config: UNet, VAE, Resampler and both OpenCLIP encoders, built here on the meta device."""
+    import json
+    ref = json.loads(str(golden("reference_yaml")[name]))
+    mine = load_yaml(os.path.join(ROOT, "configs", name + ".yaml"))
+    mine = json.loads(json.dumps(mine.to_dict() if hasattr(mine, "to_dict") else mine, default=lambda o: dict(o)))
+    diffs = []
+
+    def walk(x, y, path):
+        if isinstance(x, dict) and isinstance(y, dict):
+            for k in sorted(set(x) | set(y)):
+                if k not in x or k not in y:
+                    diffs.append(path + "/" + k)
+                else:
+                    walk(x[k], y[k], path + "/" + k)
+        elif x != y:
+            diffs.append(path)
+    walk(ref, mine, "")
+    allowed = {"/model/base_learning_rate", "/model/pretrained_checkpoint", "/model/scale_lr", "/model/params/loop_video"}
+    assert set(diffs) <= allowed, sorted(set(diffs) - allowed)
+    mp = Config.wrap(ref["model"])
+    assert mp["target"] == "lvdm.models.ddpm3d.VIPLatentDiffusion"
+    with torch.device("meta"):
+        model = du.instantiate_from_config(mp)
+    assert type(model).__module__.startswith("viewcrafter_amd.")
+    for sub in (model.model.diffusion_model, model.first_stage_model, model.image_proj_model, model.cond_stage_model, model.embedder):
+        assert type(sub).__module__.startswith("viewcrafter_amd."), type(sub)
+    assert model.model.conditioning_key == "hybrid" and model.parameterization == "v" and model.use_dynamic_rescale
+    assert sum(p.numel() for p in model.model.diffusion_model.parameters()) == 1438854980        # SURVEY: 1438.85 M
+    assert sum(p.numel() for p in model.parameters()) == 2609129005
