@@ -214,10 +214,13 @@ def main():
     sampler._cfg_cache = None
     sampler.share_cfg_prefix = not args.no_shared_prefix
     n_sched = len(sampler.ddim_timesteps)
-    assert args.warmup + args.steps <= n_sched, "warmup + steps must fit the 50-step schedule"
+    x_start = x.clone()
 
     def one_step(x, i):
-        index = n_sched - 1 - i
+        # step i of back-to-back 50-step trajectories: a request for more than 50 steps starts the next trajectory from the same x_T
+        if i and i % n_sched == 0:
+            x = x_start.clone()
+        index = n_sched - 1 - (i % n_sched)
         ts = torch.full((1,), int(sampler.ddim_timesteps[index]), device=device, dtype=torch.long)
         x, _ = sampler.p_sample_ddim(x, cond, ts, index=index, unconditional_guidance_scale=7.5,
                                      unconditional_conditioning=uc, fs=fs, guidance_rescale=0.7,
@@ -238,7 +241,7 @@ def main():
             x = one_step(x, i)
         sync()
         if profile_in_region:
-            ops.profile_begin(1 << 16)
+            ops.profile_begin(max(1 << 16, 1500 * args.steps))      # ~900 family runs per step: never exhaust the event pool
         t0 = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
             x = one_step(x, i)
@@ -248,7 +251,7 @@ def main():
             prof = ops.profile_end()
         else:   # per-family HIP-event timing on extra eager steps of the same loop (not part of `value`)
             unet.use_hip_graph = False
-            n_extra = min(2, n_sched - args.warmup - args.steps)
+            n_extra = 2
             ops.profile_begin(1 << 16)
             xe = x
             for i in range(args.warmup + args.steps, args.warmup + args.steps + n_extra):
