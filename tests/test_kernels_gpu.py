@@ -564,3 +564,21 @@ def test_stale_not_ready_status_is_not_a_launch_failure():
     hip.hipEventDestroy(ev)
     if not seen:
         pytest.skip("the GPU always finished before the query: no pending state produced")
+
+
+def test_front_end_rejects_wrong_dtype_or_host_tensors():
+    """The C ABI sees raw pointers only; the tensor front end refuses what the kernels would misread."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd._lib import VcxError
+    x = torch.randn(64, 64, device=DEV).half()
+    w = torch.randn(64, 64, device=DEV).half()
+    with pytest.raises(VcxError, match="fp16"):
+        ops.linear(x.float(), w)
+    with pytest.raises(VcxError, match="fp16"):
+        ops.linear(x, w.cpu())
+    with pytest.raises(VcxError, match="fp32"):
+        ops.linear(x, w, torch.zeros(64, device=DEV).half())
+    with pytest.raises(VcxError, match="fp32"):
+        ops.layer_norm(x, torch.ones(64, device=DEV).half(), torch.zeros(64, device=DEV))
+    with pytest.raises(VcxError, match="fp16"):
+        ops.group_norm(x.float().view(1, 64, 64), torch.ones(64, device=DEV), torch.zeros(64, device=DEV), 1e-5, False)

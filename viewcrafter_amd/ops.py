@@ -23,6 +23,19 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+def _dev16(*tensors):
+    """The C ABI takes raw pointers: a host tensor or a wrong element type would be read as garbage, not rejected."""
+    for t in tensors:
+        if t is not None and (t.dtype is not _f16 or not t.is_cuda):
+            raise VcxError(f"expected a GPU fp16 tensor, got {t.dtype} on {t.device}")
+
+
+def _dev32(*tensors):
+    for t in tensors:
+        if t is not None and (t.dtype is not _f32 or not t.is_cuda):
+            raise VcxError(f"expected a GPU fp32 tensor, got {t.dtype} on {t.device}")
+
+
 def require_gpu():
     """Raise unless a gfx950 device and the built library are available (no fallback path)."""
     if not torch.cuda.is_available():
@@ -39,6 +52,8 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
     """out[M, N] = epilogue(alpha * X W^T); see include/vcx.h.  `conv` = dict(in_h, in_w, out_h, out_w, cin, kh, kw,
     stride, pad_h, pad_w, ups) switches X to the im2col gather of a channels-last image."""
     n_out = N // 2 if geglu else N
+    _dev16(a, w, residual)
+    _dev32(bias, rowadd)
     if out is None:
         out = torch.empty((M, n_out), dtype=_f32 if out_f32 else _f16, device=a.device)
         ldc = n_out
@@ -116,6 +131,8 @@ def temporal_conv3(x, w, bias, **kwargs):
 def group_norm(x, gamma, beta, eps, silu, groups=32, out=None):
     """x [n_outer, pixels, C] fp16 (contiguous).  Statistics over (pixels, C/groups)."""
     n_outer, pixels, C = x.shape
+    _dev16(x, out)
+    _dev32(gamma, beta)
     stats = torch.empty((n_outer, groups, 2), dtype=_f32, device=x.device)
     L = lib()
     s = _stream()
@@ -130,6 +147,8 @@ def group_norm(x, gamma, beta, eps, silu, groups=32, out=None):
 
 def layer_norm(x, gamma, beta, eps=1e-5):
     rows, C = x.shape
+    _dev16(x)
+    _dev32(gamma, beta)
     out = torch.empty_like(x)
     check(lib().vcx_layernorm_f16(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, eps,
                                   _stream()), "layernorm")
@@ -148,6 +167,7 @@ def flash_attn(q, k, vt, out, *, n_groups, heads, nq, nk, kv_rows, kv_div, ldq, 
     """softmax(scale Q K^T) V per (group, head); `log2_logits`: Q K^T already is the base-2 logit (scale * log2 e was folded
     into the projections, e.g. as the GEMM alpha) and `scale` is ignored."""
     flags = (ATTN_ACCUMULATE if accumulate else 0) | (ATTN_LOG2_LOGITS if log2_logits else 0)
+    _dev16(q, k, vt, out)
     check(lib().vcx_attn_flash_d64_f16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), n_groups, heads, nq,
                                        nk, kv_rows, kv_div, ldq, ldk, ldvt, ldo, scale, flags,
                                        _stream()), "attn_flash_d64")
@@ -157,6 +177,7 @@ def flash_attn(q, k, vt, out, *, n_groups, heads, nq, nk, kv_rows, kv_div, ldq, 
 def flash_attn_dual(q, k1, vt1, k2, vt2, out, *, n_groups, heads, nq, nk1, kv_rows1, kv_div1, ldk1, ldvt1, nk2, kv_rows2, kv_div2,
                     ldk2, ldvt2, ldq, ldo, scale, log2_logits=False):
     """softmax(scale Q K1^T) V1 + softmax(scale Q K2^T) V2 in one pass over Q and O (text (+) image cross-attention)."""
+    _dev16(q, k1, vt1, k2, vt2, out)
     check(lib().vcx_attn_flash_dual_d64_f16(q.data_ptr(), k1.data_ptr(), vt1.data_ptr(), k2.data_ptr(), vt2.data_ptr(),
                                             out.data_ptr(), n_groups, heads, nq, nk1, kv_rows1, kv_div1, ldk1, ldvt1, nk2,
                                             kv_rows2, kv_div2, ldk2, ldvt2, ldq, ldo, scale,
@@ -165,6 +186,7 @@ def flash_attn_dual(q, k1, vt1, k2, vt2, out, *, n_groups, heads, nq, nk1, kv_ro
 
 
 def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale):
+    _dev16(qkv, out)
     check(lib().vcx_attn_temporal_d64_f16(qkv.data_ptr(), out.data_ptr(), B, T, P, heads, ld, k_off, v_off, ldo, scale,
                                           _stream()), "attn_temporal_d64")
     return out
