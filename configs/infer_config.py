@@ -1,5 +1,5 @@
-"""Command-line surface of `python inference.py` — the reference's flags (its configs/infer_config.py), same names,
-defaults and quirks, so existing run scripts keep working.  Only the diffusion group drives code in this repo; the
+"""Command-line surface of `python inference.py` — the reference's flags (its configs/infer_config.py:7-59; pinned option by
+option to its parser in tests/golden/cli_flags.npz), same names, defaults and quirks, so existing run scripts keep working.  Only the diffusion group drives code in this repo; the
 DUSt3R / render groups are forwarded to the reference implementation of those stages."""
 import argparse
 

@@ -3,6 +3,10 @@
 Tensors are only used for device memory and streams; every function below launches one (or two)
 hand-written gfx950 kernels through ctypes.  Activations are fp16 channels-last, i.e. a video
 latent is [B, T, H, W, C] and all token matrices are [rows, C] views of it.
+
+Which reference call sites each entry point stands in for (nn.Linear / Conv2d / Conv3d attention.py:53-57,
+openaimodel3d.py:69-186, GroupNorm basics.py:76-81, LayerNorm attention.py:226-228, memory_efficient_attention
+attention.py:175,187, the DDIM update ddim.py:228-279, ...) is tabulated in INTEGRATION.md section 2 and include/vcx.h.
 """
 import ctypes
 import torch
