@@ -367,18 +367,24 @@ def vae_attn_block(sd, p, x):
     return x + F.conv2d(o, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
 
 
-def vae_decode(sd, dd, z):
+def vae_decode(sd, dd, z, taps=None):
     """AutoencoderKL.decode (autoencoder.py:104-107) -> Decoder.forward (ae_modules.py:539-578).
-    sd keys relative to first_stage_model; dd = ddconfig."""
+    sd keys relative to first_stage_model; dd = ddconfig.  `taps`: optional dict that receives max |activation| of the
+    residual stream after every block (the fp16-range stress test reads it)."""
     nres, nrb = len(dd["ch_mult"]), dd["num_res_blocks"]
+
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = float(t.abs().max())
+        return t
     h = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
     h = F.conv2d(h, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
-    h = vae_resnet_block(sd, "decoder.mid.block_1", h)
-    h = vae_attn_block(sd, "decoder.mid.attn_1", h)
-    h = vae_resnet_block(sd, "decoder.mid.block_2", h)
+    h = tap("decoder.mid.block_1", vae_resnet_block(sd, "decoder.mid.block_1", h))
+    h = tap("decoder.mid.attn_1", vae_attn_block(sd, "decoder.mid.attn_1", h))
+    h = tap("decoder.mid.block_2", vae_resnet_block(sd, "decoder.mid.block_2", h))
     for lvl in reversed(range(nres)):
         for blk in range(nrb + 1):
-            h = vae_resnet_block(sd, f"decoder.up.{lvl}.block.{blk}", h)
+            h = tap(f"decoder.up.{lvl}.block.{blk}", vae_resnet_block(sd, f"decoder.up.{lvl}.block.{blk}", h))
         if lvl != 0:   # Upsample, ae_modules.py:123-127
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = F.conv2d(h, sd[f"decoder.up.{lvl}.upsample.conv.weight"], sd[f"decoder.up.{lvl}.upsample.conv.bias"], padding=1)
