@@ -1,6 +1,11 @@
 """Headline benchmark: DDIM steps/s of the ViewCrafter denoising loop on MI355X (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1 under torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Started as a plain `python bench.py --gpus N` the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` (the same line
+the driver uses; under that launcher - WORLD_SIZE set - it just runs as one rank).  Either way the line it prints carries
+`n_gpus` = the world size it really ran with, which must equal --gpus, and the backend must be nccl (= RCCL).
 
 Workload (N=1): configs[3] of BASELINE.json — ViewCrafter_25, 576x1024x25 frames (latent 25x72x128), the 1.44 B-parameter
 lvdm UNet built from configs/inference_pvd_1024.yaml, one trajectory per GPU.  One step = one DDIM step = two UNet
@@ -139,6 +144,72 @@ def gpu_legs(model, hp, dd, T, h, w, device, x, ts, ctx, fs, z_dec):
     return out
 
 
+def self_launch(argv, n):
+    """`python bench.py --gpus N` (N > 1) without a launcher: become `python -m torch.distributed.run ... bench.py <same args>`,
+    one rank per GPU on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] --gpus {n} without a launcher: re-executing as {' '.join(cmd[1:8])} bench.py ...", file=sys.stderr)
+    sys.stderr.flush()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
+def per_rank_rates(elapsed_local, steps, device):
+    """Every rank's own steps/s (all_gather of the local elapsed time) and the max-over-ranks elapsed time `value` is built on."""
+    t = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+    allt = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(allt, t)
+    el = [float(x.item()) for x in allt]
+    return max(el), [steps / e for e in el]
+
+
+def stub_main(args, world, rank):
+    """`--stub`: the launch / barrier / max-over-ranks timing / reporting harness on CPU ranks (gloo) with a stand-in step
+    function - no model, no GPU, numbers meaningless.  tests/test_entry_cpu.py runs `python bench.py --gpus 2 --stub`
+    to cover the self-launch path; the line says "data": "stub" so it can never be mistaken for a measurement."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus, f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks"
+    g = torch.Generator().manual_seed(123 + rank)
+    x = torch.randn(4, 8, 16, 16, generator=g)
+
+    def one_step(x, i):
+        return 0.99 * x + 0.01 * torch.tanh(x.roll(1, -1))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+    for i in range(args.warmup):
+        x = one_step(x, i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        x = one_step(x, i)
+    local = time.perf_counter() - t0
+    sync()
+    elapsed = time.perf_counter() - t0
+    rates = [args.steps / local]
+    if world > 1:
+        elapsed, _ = per_rank_rates(elapsed, args.steps, "cpu")
+        _, rates = per_rank_rates(local, args.steps, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "DDIM steps/sec (STUB: harness self-test, no model)", "value": world * args.steps / elapsed,
+                          "unit": "DDIM steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "stub", "backend": dist.get_backend() if world > 1 else None,
+                          "per_rank_steps_per_s": rates, "config": {"workload": "stub", "parallelism": f"trajectory-sharded x{world}"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,11 +226,20 @@ def main():
     ap.add_argument("--no-video", action="store_true", help="skip the measured 50-step video after the timed region")
     ap.add_argument("--no-shared-prefix", action="store_true", help="evaluate cond and uncond as a plain B=2 forward (A/B of the "
                     "shared CFG prefix: the layers ahead of the first cross-attention see identical inputs and run once by default)")
+    ap.add_argument("--stub", action="store_true", help="CPU self-test of the launch / timing / reporting harness (gloo ranks, a "
+                    "stand-in step function, no model): prints \"data\": \"stub\"; not a measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(sys.argv[1:], args.gpus)               # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the launch line and --gpus must agree "
+                         "(a line with the wrong n_gpus is worse than no line)")
+    if args.stub:
+        return stub_main(args, world, rank)
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs an MI355X GPU (torch.cuda.device_count() == 0)")
@@ -171,14 +251,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if ndev >= world:
             dist.init_process_group("nccl", device_id=device)       # RCCL over xGMI, one rank per GPU
-        else:
-            # fewer GPUs than ranks (only happens when the launch line is smoke-tested on a 1-GPU box): RCCL cannot
-            # put two ranks on one device, so the control-plane collectives fall back to gloo; the numbers are meaningless
+        elif os.environ.get("VCX_BENCH_SHARE_GPU") == "1":
+            # fewer GPUs than ranks (smoke-testing the launch line on a 1-GPU box): RCCL cannot put two ranks on one device, so
+            # the control-plane collectives fall back to gloo; the line is marked and the numbers are meaningless
             print(f"[bench] {world} ranks on {ndev} GPU(s): sharing devices, gloo control plane (smoke test only)", file=sys.stderr)
             dist.init_process_group("gloo")
-    if args.gpus != world:
-        if rank == 0:
-            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; running with {world} rank(s)", file=sys.stderr)
+        else:
+            raise SystemExit(f"bench.py --gpus {world} needs {world} GPUs, this node shows {ndev} (VCX_BENCH_SHARE_GPU=1 smoke-tests "
+                             "the launch line on fewer)")
+        assert dist.get_world_size() == args.gpus, f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks"
+        assert dist.get_backend() == "nccl" or os.environ.get("VCX_BENCH_SHARE_GPU") == "1", dist.get_backend()
 
     from viewcrafter_amd import ops
     from viewcrafter_amd.builder import build_diffusion_model, randomize_parameters
@@ -262,10 +344,9 @@ def main():
                 for k in ("launches", "ms", "flops", "bytes"):
                     v[k] = v[k] * args.steps / max(n_extra, 1)
     assert torch.isfinite(x).all(), "non-finite latent after the timed steps"
+    rank_rates = [args.steps / elapsed]
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, rank_rates = per_rank_rates(elapsed, args.steps, device if dist.get_backend() == "nccl" else "cpu")
 
     gather_s = None
     if world > 1 and not args.no_decode:
@@ -292,7 +373,9 @@ def main():
         else f"DDIM steps/sec ({args.workload})",
         "value": steps_per_s, "unit": "DDIM steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16", "data": "synthetic", "launch_mode": "hipGraph replay" if args.graph else "eager",
+        "dtype": "f16", "data": "synthetic", "backend": (dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else
+                                                                             " (SHARED-GPU SMOKE TEST: not a measurement)")) if world > 1 else None,
+        "per_rank_steps_per_s": rank_rates, "tune": ops.tune_report(), "launch_mode": "hipGraph replay" if args.graph else "eager",
         "roofline_measured_on": "the timed region" if profile_in_region else "extra eager steps after the timed region",
         "config": {"workload": args.workload, "trajectories_per_gpu": 1, "frames": T, "latent": [T, h, w],
                    "guidance": "CFG 7.5 + rescale 0.7, cond/uncond batched as B=2" + ("" if args.no_shared_prefix else

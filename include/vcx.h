@@ -32,7 +32,7 @@ extern "C" {
 #define VCX_ELAUNCH (-2)  /* HIP launch or runtime error                 */
 #define VCX_ENODEV (-3)   /* no gfx950 device                            */
 
-#define VCX_ABI_VERSION 1
+#define VCX_ABI_VERSION 2   /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*; fused-norm entry points */
 
 int vcx_abi_version(void);
 const char* vcx_last_error(void);
@@ -220,6 +220,24 @@ int vcx_ddim_step3_f32(const float* x, const float* v_cond, const float* v_uncon
 #define VCX_PROF_FAMILIES 6
 int vcx_profile_begin(int max_records);
 int vcx_profile_end(double* out_host);
+
+/* ------------------------------------------------------------------------------------
+ * Experiment knobs (debug / A-B tooling only; the defaults ARE the product).  A knob is a
+ * process-wide integer read by the dispatchers at launch time; its initial value comes
+ * from the environment variable VCX_TUNE_<NAME> read ONCE at the first use, never per
+ * launch.  vcx_tune_set returns the previous value.  bench.py prints every knob that is
+ * not at its default next to the numbers it measured.
+ * ---------------------------------------------------------------------------------- */
+#define VCX_TUNE_GEMM_CFG 0        /* -1 auto | 0..3 force tile config 128x128 / 128x160 / 256x256 / 256x320 */
+#define VCX_TUNE_GEMM_DMA 1        /* 1 | 0 = register-staged kernel everywhere                              */
+#define VCX_TUNE_FLASH_QB 2        /* 0 auto | 1 | 2 query blocks of 32 rows per wave (v1 kernel)            */
+#define VCX_TUNE_XATTN_RESIDENT 3  /* 1 | 0 = never use the LDS-resident cross-attention kernel              */
+#define VCX_TUNE_FLASH_IMPL 4      /* 0 auto | 1 phased v1 kernel | 2 software-pipelined v2 kernel           */
+#define VCX_TUNE_EXP0 5            /* free for one-off experiments (0)                                       */
+#define VCX_TUNE_EXP1 6
+#define VCX_TUNE_COUNT 7
+int vcx_tune_set(int knob, int value);
+int vcx_tune_get(int knob);
 
 #ifdef __cplusplus
 }

@@ -25,8 +25,26 @@ def test_header_functions_are_exported_and_bound():
 
 def test_abi_version_and_error_string():
     L = _lib.lib()
-    assert L.vcx_abi_version() == 1
+    src = open(os.path.join(ROOT, "include", "vcx.h")).read()
+    assert L.vcx_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define VCX_ABI_VERSION (\d+)", src).group(1))
     assert isinstance(L.vcx_last_error(), bytes)
+
+
+def test_tune_knobs_default_to_the_product_and_round_trip():
+    """include/vcx.h VCX_TUNE_*: the Python table mirrors the header's indices, every knob starts at its default (no VCX_TUNE_*
+    in the test environment), set returns the previous value, an unknown knob is rejected."""
+    L = _lib.lib()
+    src = open(os.path.join(ROOT, "include", "vcx.h")).read()
+    header = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define VCX_TUNE_([A-Z0-9_]+) (\d+)", src)}
+    count = header.pop("COUNT")
+    assert {k: v[0] for k, v in _lib.TUNE.items()} == header and count == len(header)
+    for name, (idx, dflt) in _lib.TUNE.items():
+        if "VCX_TUNE_" + name in os.environ:
+            continue
+        assert L.vcx_tune_get(idx) == dflt, name
+        assert L.vcx_tune_set(idx, 7) == dflt and L.vcx_tune_get(idx) == 7
+        assert L.vcx_tune_set(idx, dflt) == 7
+    assert L.vcx_tune_set(99, 1) == -1 and b"knob" in L.vcx_last_error()
 
 
 def test_gemm_desc_layout_matches_header():

@@ -175,3 +175,36 @@ def test_viewcrafter_forwards_the_reference_class_surface(tmp_path, monkeypatch)
     bare = viewcrafter.ViewCrafter.__new__(viewcrafter.ViewCrafter)
     with pytest.raises(AttributeError, match="no reference checkout attached"):
         bare.run_dust3r
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it must itself become two ranks: the harness is run in
+    --stub mode (gloo ranks, stand-in step, no model) and rank 0 prints ONE line with n_gpus = the real world size."""
+    r, lines = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--stub"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["backend"] == "gloo" and out["data"] == "stub" and out["scaling"] == "weak"
+    assert len(out["per_rank_steps_per_s"]) == 2 and all(v > 0 for v in out["per_rank_steps_per_s"])
+    assert out["value"] == pytest.approx(2 * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"]), rel=1e-6)
+    assert out["value"] <= sum(out["per_rank_steps_per_s"]) * (1 + 1e-6)       # max-over-ranks time, barrier included
+    assert "torch.distributed.run" in r.stderr
+
+
+def test_bench_refuses_a_launch_line_that_disagrees_with_gpus():
+    r, lines = _run_bench(["--gpus", "2", "--stub"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not lines and "must agree" in r.stderr
+    r, lines = _run_bench(["--gpus", "1", "--steps", "2", "--stub"])
+    assert r.returncode == 0 and lines[0]["n_gpus"] == 1 and lines[0]["backend"] is None

@@ -68,3 +68,33 @@ def test_broadcast_and_gather_two_ranks(n_items):
     assert all(o[0] for o in outs), "weights differ after broadcast"
     gathered = [o[1] for o in outs if o[1] is not None][0]
     assert gathered == [float(i * 10 + i) for i in range(n_items)]
+
+
+def _worker_mismatch(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_distributed("gloo")
+    empty = parallel.gather_results({}, 0)
+    # clip 1 (owned by rank 1) has another length: EVERY rank must raise, none may be left waiting in the all_gather
+    local = {rank: torch.zeros(3 + rank, 2)}
+    try:
+        parallel.gather_results(local, 2)
+        q.put((rank, empty, "no error"))
+    except ValueError as e:
+        q.put((rank, empty, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_results_rejects_mixed_shapes_on_every_rank_and_handles_zero_items():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mismatch, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[0][1] == [] and outs[1][1] is None
+    assert all("one shape and dtype" in o[2] for o in outs), outs

@@ -37,19 +37,19 @@ lin(115200, 640, 640, res=True); lin(28800, 1280, 5120, res=True); lin(28800, 38
 geglu(460800, 320); geglu(115200, 640); geglu(28800, 1280)
 lin(28800, 1280, 1280, res=True); lin(115200, 640, 2560, res=True); lin(460800, 640, 320)
 conv(1280, 9, 16); tconv(640, 2304)
-# A/B of VCX_GEMM_TUNE values given on the command line (read per call by vcx_gemm_f16), interleaved rounds, median and min
-# arguments: VCX_GEMM_TUNE values, or cfgN to force tile configuration N (VCX_GEMM_CFG) with tune 0
-tunes = [a for a in sys.argv[1:]] or ["0"]
+# A/B of dispatcher settings given on the command line, interleaved rounds, median and min.  Arguments: "auto" (the product),
+# cfgN = force tile configuration N (knob GEMM_CFG), expN = knob EXP0 set to N (whatever experiment the library was built with)
+tunes = [a for a in sys.argv[1:]] or ["auto"]
 rounds = 3
 res = {t: [[] for _ in cases] for t in tunes}
 for r in range(rounds):
     for t in tunes:
-        os.environ["VCX_GEMM_TUNE"] = "0" if t.startswith("cfg") else t
-        os.environ["VCX_GEMM_CFG"] = t[3:] if t.startswith("cfg") else ""
+        ops.tune_set("GEMM_CFG", int(t[3:]) if t.startswith("cfg") else -1)
+        ops.tune_set("EXP0", int(t[3:]) if t.startswith("exp") else 0)
         for i, (name, fn, fl) in enumerate(cases):
             res[t][i].append(timeit(fn, iters=6))
 med = lambda v: sorted(v)[len(v) // 2]
-print(f"{'problem':34s} " + " ".join(f"{'tune ' + str(t) + ' ms (min)':>22s} {'TF/s':>6s}" for t in tunes))
+print(f"{'problem':34s} " + " ".join(f"{str(t) + ' ms (min)':>22s} {'TF/s':>6s}" for t in tunes))
 tot = {t: 0.0 for t in tunes}
 for i, (name, fn, fl) in enumerate(cases):
     row = f"{name:34s} "

@@ -49,8 +49,10 @@ class ViewCrafter:
         rank, world = parallel.rank_world()
         # one process per GPU (torchrun): rank 0 reads the checkpoint, the others receive the weights in a few large RCCL
         # broadcasts over xGMI (parallel.broadcast_module_) instead of W reads of the same 10 GB file
-        if rank == 0:
-            assert os.path.exists(self.opts.ckpt_path), "Error: checkpoint Not Found!"
+        found = [os.path.exists(self.opts.ckpt_path) if rank == 0 else True]
+        if world > 1:       # rank 0's verdict reaches everybody BEFORE the weight broadcast: all ranks fail together instead of
+            torch.distributed.broadcast_object_list(found, src=0)     # the others waiting in a collective rank 0 never joins
+        assert found[0], "Error: checkpoint Not Found!"
         model = build_diffusion_model(self.opts.config, device=self.device, ckpt_path=self.opts.ckpt_path if rank == 0 else None,
                                       perframe_ae=self.opts.perframe_ae, conditioners="config", init_on_device=False)
         if world > 1:
@@ -81,7 +83,9 @@ class ViewCrafter:
         ranks: rank r runs clips r, r + W, ... with NO collective inside the DDIM loop; the decoded clips are gathered on
         rank 0 with one all_gather.  Returns the list of results on rank 0, None elsewhere; with one
         process it is a plain loop.  Clip i is seeded with opts.seed + i, so the result does not depend on the world size
-        (clip 0 equals the single-process run; later clips differ from the reference's sequential generator stream)."""
+        (clip 0 equals the reference's single-process run; later clips differ from the reference's one sequential generator
+        stream - `nvs_sparse_view_interp` therefore keeps the reference's own loop when there is one process, and the
+        sharded launch is documented as a different, world-size-independent stream)."""
         _, world = parallel.rank_world()
 
         def one(clip, index):
@@ -108,7 +112,7 @@ class ViewCrafter:
             for i, out in enumerate(outs):
                 torch.save(out.cpu(), os.path.join(self.opts.save_dir, f"diffusion{i}.pt"))
                 # like the reference's nvs_single_view (viewcrafter.py:118-121): write the generated clip as a video as well
-                save_video((out + 1.0) / 2.0, os.path.join(self.opts.save_dir, f"diffusion{i}.mp4"), fps=10, value_range=(0.0, 1.0))
+                save_video((out + 1.0) / 2.0, os.path.join(self.opts.save_dir, f"diffusion{i}.mp4"), fps=8, value_range=(0.0, 1.0))
         return outs[0] if (rank == 0 and len(clips) == 1) else outs
 
     # ------------------------------------------------------------------ geometry stages (reference)
@@ -155,7 +159,10 @@ class ViewCrafter:
         """Reference viewcrafter.py:196-277.  Its (N - 1) clips are independent `run_diffusion` calls (:272-274): under a
         torchrun launch the reference's method runs in recording mode on every rank (DUSt3R and the render are the
         reference's and deterministic; the clips are only collected), then the clips are sharded over the GPUs and rank 0
-        writes diffusion.mp4 - instead of (N - 1) sequential 11 s generations on one GPU."""
+        writes diffusion.mp4 (fps 8, the reference's writer default, pvd_utils.py:38) - instead of (N - 1) sequential 11 s
+        generations on one GPU.  One process: the reference's own loop, i.e. its single sequential noise stream; N processes:
+        clip i draws from seed + i (independent of N), so clips 1.. differ from the one-process run - by construction, a
+        sharded launch cannot replay one sequential generator."""
         rank, world = parallel.rank_world()
         if world == 1:
             return self._ref.nvs_sparse_view_interp()
@@ -170,7 +177,7 @@ class ViewCrafter:
         if rank != 0:
             return None
         result = torch.cat(outs)
-        save_video((result + 1.0) / 2.0, os.path.join(self.opts.save_dir, "diffusion.mp4"), fps=10, value_range=(0.0, 1.0))
+        save_video((result + 1.0) / 2.0, os.path.join(self.opts.save_dir, "diffusion.mp4"), fps=8, value_range=(0.0, 1.0))
         return result
 
     def nvs_single_view_eval(self):

@@ -18,9 +18,13 @@ SYMBOLS = [
     "vcx_attn_flash_d64_f16", "vcx_attn_flash_dual_d64_f16", "vcx_attn_temporal_d64_f16", "vcx_softmax_rows_f16",
     "vcx_silu_f32", "vcx_gelu_f16", "vcx_timestep_embedding_f32", "vcx_cast_f32_to_f16", "vcx_cast_f16_to_f32",
     "vcx_copy2d_f16", "vcx_ncthw_f32_to_nthwc_f16", "vcx_nthwc_to_ncthw_f32", "vcx_ddim_step_f32", "vcx_ddim_step3_f32",
-    "vcx_profile_begin", "vcx_profile_end",
+    "vcx_profile_begin", "vcx_profile_end", "vcx_tune_set", "vcx_tune_get",
 ]
 
+ABI_VERSION = 2          # include/vcx.h VCX_ABI_VERSION
+# experiment knobs (include/vcx.h VCX_TUNE_*): name -> (index, default)
+TUNE = {"GEMM_CFG": (0, -1), "GEMM_DMA": (1, 1), "FLASH_QB": (2, 0), "XATTN_RESIDENT": (3, 1), "FLASH_IMPL": (4, 0), "EXP0": (5, 0),
+        "EXP1": (6, 0)}
 GEMM_BIAS_N, GEMM_BIAS_M, GEMM_ROWADD, GEMM_RESIDUAL, GEMM_GEGLU, GEMM_OUT_F32, GEMM_CONV_SLABK = 1, 2, 4, 8, 16, 32, 64
 PROF_FAMILIES = ("gemm", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "elementwise")
 
@@ -91,14 +95,16 @@ def lib():
                                      c_int64, POINTER(c_float), c_void_p]
     L.vcx_profile_begin.argtypes = [c_int]
     L.vcx_profile_end.argtypes = [POINTER(c_double)]
+    L.vcx_tune_set.argtypes = [c_int, c_int]
+    L.vcx_tune_get.argtypes = [c_int]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name == "vcx_groupnorm_ws_bytes":
             fn.restype = ctypes.c_size_t
         elif name != "vcx_last_error":
             fn.restype = c_int
-    if L.vcx_abi_version() != 1:
-        raise VcxError(f"libvcx ABI version {L.vcx_abi_version()} != 1; rebuild the library")
+    if L.vcx_abi_version() != ABI_VERSION:
+        raise VcxError(f"libvcx ABI version {L.vcx_abi_version()} != {ABI_VERSION}; rebuild the library (make -C viewcrafter_amd/csrc)")
     _lib = L
     return L
 

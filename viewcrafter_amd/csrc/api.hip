@@ -1,6 +1,7 @@
 // libvcx: error reporting, device query, HIP-event profiling of kernel families.
 #include "vcx_common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 #include <mutex>
@@ -45,6 +46,37 @@ extern "C" int vcx_device_arch(char* name_host, int len) {
         name_host[len - 1] = 0;
     }
     return VCX_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Experiment knobs: process-wide atomics, seeded once from VCX_TUNE_<NAME>; the dispatchers read them with a relaxed load
+// (no getenv on the launch path).
+// ---------------------------------------------------------------------------------------
+static std::atomic<int> g_tune[VCX_TUNE_COUNT];
+static std::once_flag g_tune_once;
+static const struct { const char* name; int dflt; } g_tune_def[VCX_TUNE_COUNT] = {
+    {"GEMM_CFG", -1}, {"GEMM_DMA", 1}, {"FLASH_QB", 0}, {"XATTN_RESIDENT", 1}, {"FLASH_IMPL", 0}, {"EXP0", 0}, {"EXP1", 0}};
+
+static void tune_init() {
+    for (int i = 0; i < VCX_TUNE_COUNT; ++i) {
+        char key[64];
+        snprintf(key, sizeof(key), "VCX_TUNE_%s", g_tune_def[i].name);
+        const char* e = getenv(key);
+        g_tune[i].store((e && e[0]) ? atoi(e) : g_tune_def[i].dflt, std::memory_order_relaxed);
+    }
+}
+int vcx_tune(int knob) {
+    std::call_once(g_tune_once, tune_init);
+    return g_tune[knob].load(std::memory_order_relaxed);
+}
+extern "C" int vcx_tune_get(int knob) {
+    if (knob < 0 || knob >= VCX_TUNE_COUNT) { vcx_set_error("vcx_tune_get: no knob %d", knob); return VCX_EINVAL; }
+    return vcx_tune(knob);
+}
+extern "C" int vcx_tune_set(int knob, int value) {
+    if (knob < 0 || knob >= VCX_TUNE_COUNT) { vcx_set_error("vcx_tune_set: no knob %d", knob); return VCX_EINVAL; }
+    std::call_once(g_tune_once, tune_init);
+    return g_tune[knob].exchange(value, std::memory_order_relaxed);
 }
 
 // ---------------------------------------------------------------------------------------

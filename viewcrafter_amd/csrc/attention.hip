@@ -726,7 +726,7 @@ extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* 
     VCX_REQUIRE(((int64_t)(nk - 1) * ldk + 64) * 2 < 0xFFFF0000ll && (63ll * ldvt + nk + 8) * 2 < 0xFFFF0000ll,
                 "vcx_attn_flash_d64_f16: K / V^T extents per (group, head) must stay below 4 GiB");
     // two 32-row query blocks per wave (256 rows per block) unless the row count would waste > 20 % of such blocks
-    static const int force_qb = []() { const char* e = getenv("VCX_FLASH_QB"); return e ? atoi(e) : 0; }();
+    const int force_qb = vcx_tune(VCX_TUNE_FLASH_QB);
     const int blocks2 = (nq + 255) / 256;
     bool qb2 = (double)nq / (blocks2 * 256.0) >= 0.8;
     if (force_qb == 1) qb2 = false;
@@ -776,7 +776,7 @@ extern "C" int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const 
     const double nprob = (double)n_groups * heads;
     VcxProfScope prof(VCX_FAM_FLASH, s, 4.0 * nprob * nq * (double)(nk1 + nk2) * 64, 2.0 * nprob * 64 * (2.0 * nq + 2.0 * (nk1 + nk2)));
     // Both key sets shared by the same frame groups and small enough for LDS: the resident-K/V kernel (no per-tile pipeline)
-    static const bool resident_on = []() { const char* e = getenv("VCX_XATTN_RESIDENT"); return !(e && e[0] == '0'); }();
+    const bool resident_on = vcx_tune(VCX_TUNE_XATTN_RESIDENT) != 0;
     if (resident_on && kv_div1 == kv_div2 && n_groups % kv_div1 == 0 && nk1 <= 128 && nk2 <= 256) {
         XAttnArgs x;
         x.q = (const half_t*)q; x.o = (half_t*)o;
@@ -807,7 +807,7 @@ extern "C" int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const 
     }
     // two query blocks per wave (half the LDS fragment traffic per MFMA) unless that wastes > 20 % of the 256-row blocks; with
     // two blocks the kept first result is packed fp16 and the running-max-in-C variant is not used (register budget)
-    static const int force_qb = []() { const char* e = getenv("VCX_FLASH_QB"); return e ? atoi(e) : 0; }();
+    const int force_qb = vcx_tune(VCX_TUNE_FLASH_QB);
     const int blocks2 = (nq + 255) / 256;
     bool qb2 = (double)nq / (blocks2 * 256.0) >= 0.8;
     if (force_qb == 1) qb2 = false;

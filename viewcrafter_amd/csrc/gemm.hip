@@ -453,17 +453,13 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const int bn = use160 ? 160 : 128;
     a.tiles_m = (d->M + BM - 1) / BM;
     a.tiles_n = (d->N + bn - 1) / bn;
-    // experiment bits, read per call so that one process can A/B variants (tools/gemm_quick.py): 1 = phase-split gemm_pp.hip
-    // main loop for the 256-row tiles instead of the lock-step gemm_dma.hip one (parity-green, 7 % slower on the model's
-    // shapes: profiles/r02_gemm_experiments.md), 2 = s_setprio around its MFMA slots
-    { const char* e = getenv("VCX_GEMM_TUNE"); a.tune = e ? atoi(e) : 0; }
     a.m_begin = 0;
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * (double)d->N * d->K;
     const double bytes = 2.0 * ((double)d->M * d->K / (conv ? d->kh * d->kw : 1) + (double)d->N * d->K + (double)d->M * d->N);
     VcxProfScope prof(VCX_FAM_GEMM, s, flops, bytes);
     // DMA kernel (gemm_dma.hip) whenever its addressing assumptions hold; the register-staged kernel otherwise.
-    static const bool dma_enabled = []() { const char* e = getenv("VCX_GEMM_DMA"); return !(e && e[0] == '0'); }();
+    const bool dma_enabled = vcx_tune(VCX_TUNE_GEMM_DMA) != 0;
     const unsigned long long lim = 0xFFFF0000ull;
     const unsigned long long a_ext = conv ? 2ull * (unsigned long long)(d->M / (d->out_h * d->out_w)) * d->in_h * d->in_w * d->lda
                                           : 2ull * ((unsigned long long)(d->M - 1) * d->lda + d->K);
@@ -482,8 +478,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.r_bytes = (unsigned)r_ext;
     if (dma_ok) {
         // tile choice: the large (256-row, 8-wave) tiles halve the LDS traffic per MFMA but need >= ~1.5 waves of 256 tiles
-        int force = -1;      // read per call: tools/gemm_quick.py A/Bs tile configurations inside one process
-        { const char* e = getenv("VCX_GEMM_CFG"); if (e && e[0]) force = atoi(e); }
+        const int force = vcx_tune(VCX_TUNE_GEMM_CFG);      // -1 in production; tools/gemm_quick.py A/Bs tile configurations
         int cfg = use160 ? 1 : 0;
         const int big_bn = (d->N % 320 == 0 && !geglu) ? 320 : ((d->N % 256 == 0 || d->N >= 1024) ? 256 : 0);
         if (big_bn) {
@@ -494,7 +489,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
         const int tbm = cfg >= 2 ? 256 : 128, tbn = cfg == 0 ? 128 : cfg == 1 ? 160 : cfg == 2 ? 256 : 320;
         a.tiles_m = (d->M + tbm - 1) / tbm;
         a.tiles_n = (d->N + tbn - 1) / tbn;
-        auto big = [&](GemmArgs& g, int c) { return (g.tune & 1) ? launch_pp(g, c, conv, geglu, f32, s) : launch_dma(g, c, conv, geglu, f32, s); };
+        auto big = [&](GemmArgs& g, int c) { return launch_dma(g, c, conv, geglu, f32, s); };
         if (cfg >= 2) {
             // Large tiles run one block per CU: a partial last round of 256-row tiles costs a full tile time.  When the
             // remainder is small, finish the full rounds with large tiles and hand the tail rows to the small-tile config.

@@ -26,7 +26,6 @@ struct GemmArgs {
     unsigned a_bytes, w_bytes;   // operand extents for the DMA kernel's buffer descriptors (whole problem, not the launch's rows)
     unsigned c_bytes, r_bytes;   // output / residual extents (the DMA kernel's epilogue addresses them through descriptors too)
     int m_begin;   // first output row of this launch (tail split of large-tile launches); rows are < M
-    int tune;   // experiment bits from $VCX_GEMM_TUNE (0 in production)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -73,6 +72,5 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
 
 int persistent_grid(int ntiles, int blocks_per_cu = 2);
 int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);
-int launch_pp(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);   // gemm_pp.hip: phase-split main loop, cfg 2 / 3
 
 }  // namespace vcxgemm

@@ -45,6 +45,9 @@ struct VcxLdsAttr {
     }
 };
 
+// ---- experiment knobs (api.hip; include/vcx.h VCX_TUNE_*) ----
+int vcx_tune(int knob);
+
 // ---- profiling (api.hip) ----
 enum { VCX_FAM_GEMM = 0, VCX_FAM_FLASH = 1, VCX_FAM_TATTN = 2, VCX_FAM_GN = 3, VCX_FAM_LN = 4, VCX_FAM_ELT = 5 };
 struct VcxProfScope {

@@ -38,6 +38,10 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 x = layer(x, emb, batch_size=batch_size)
             elif isinstance(layer, SpatialTransformer):
                 x = layer(x, context_kv=context[id(layer)], frames_per_video=x.shape[0] // batch_size, cfg_repeat=cfg_repeat)
+                if cfg_repeat > 1:
+                    # x now holds batch_size * r videos: a ResBlock FOLLOWING the transformer inside this block reads one emb row
+                    # per video through a raw pointer (rowadd), so emb must grow with x here, not after the block returns
+                    emb = ops.repeat_rows(emb, cfg_repeat)
                 batch_size, cfg_repeat = batch_size * cfg_repeat, 1
             elif isinstance(layer, TemporalTransformer):
                 n, H, W, C = x.shape

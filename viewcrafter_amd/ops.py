@@ -12,7 +12,7 @@ import ctypes
 import torch
 
 from ._lib import (GEMM_BIAS_M, GEMM_BIAS_N, GEMM_CONV_SLABK, GEMM_GEGLU, GEMM_OUT_F32, GEMM_RESIDUAL, GEMM_ROWADD, PROF_FAMILIES,
-                   GemmDesc, VcxError, check, lib)
+                   TUNE, GemmDesc, VcxError, check, lib)
 from .packing import conv_slab_major
 
 _f16 = torch.float16
@@ -296,6 +296,23 @@ def ddim_step(x, v_cond, v_uncond, noise, coef, ws=None, v_img=None, cfg_img=0.0
     check(lib().vcx_ddim_step3_f32(x.data_ptr(), v_cond.data_ptr(), _ptr(v_uncond), _ptr(v_img), _ptr(noise),
                                    x_prev.data_ptr(), pred_x0.data_ptr(), ws.data_ptr(), B, n, c, _stream()), "ddim_step")
     return x_prev, pred_x0
+
+
+# ------------------------------------------------------------------------------------------
+# experiment knobs (include/vcx.h VCX_TUNE_*): A/B tooling only, the defaults are the product
+# ------------------------------------------------------------------------------------------
+def tune_set(name, value):
+    """Set knob `name` (a key of _lib.TUNE), return its previous value."""
+    return lib().vcx_tune_set(TUNE[name][0], int(value))
+
+
+def tune_get(name):
+    return lib().vcx_tune_get(TUNE[name][0])
+
+
+def tune_report():
+    """Knobs that are NOT at their default (bench.py prints this next to its numbers): {} in production."""
+    return {k: tune_get(k) for k, (_, d) in TUNE.items() if tune_get(k) != d}
 
 
 # ------------------------------------------------------------------------------------------

@@ -107,11 +107,20 @@ def gather_results(local, n_items, dst=0, _force=False):
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not _force):
         return [local[i] for i in range(n_items)]
     rank, world = dist.get_rank(), dist.get_world_size()
+    if n_items == 0:
+        return [] if rank == dst else None
     per_rank = (n_items + world - 1) // world
     example = next(iter(local.values())) if local else None
+    # every rank reports the (shape, dtype) of ALL its results first: a mismatch must fail on every rank together - if only the
+    # rank holding the odd clip raised, the others would wait in the all_gather below until the launcher kills them
+    mine = sorted({(tuple(t.shape), str(t.dtype).replace("torch.", "")) for t in local.values()})
     meta = [None] * world
-    dist.all_gather_object(meta, None if example is None else (tuple(example.shape), str(example.dtype).replace("torch.", "")))
-    shape, dtype = next(m for m in meta if m is not None)
+    dist.all_gather_object(meta, mine)
+    kinds = sorted({k for m in meta for k in m})
+    if len(kinds) != 1:
+        raise ValueError(f"gather_results needs results of one shape and dtype, the ranks hold {kinds} "
+                         "(clips of different length / size must be generated in separate launches)")
+    shape, dtype = kinds[0]
     dev = example.device if example is not None else (torch.device("cuda", torch.cuda.current_device())
                                                       if dist.get_backend() == "nccl" else torch.device("cpu"))
     stack = torch.zeros((per_rank,) + tuple(shape), dtype=getattr(torch, dtype), device=dev)
