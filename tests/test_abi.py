@@ -62,3 +62,19 @@ def test_argument_validation_without_gpu():
     assert L.vcx_gemm_f16(ctypes.byref(d), None) == -1
     assert b"null" in L.vcx_last_error()
     assert L.vcx_layernorm_f16(None, None, None, None, 4, 64, 1e-5, None) == -1
+
+
+def test_flash_v2_listing_passes_the_static_audit():
+    """tools/isa_audit.py: the hand-scheduled attention kernel compiles to gfx950 with its 96 asm-owned AGPRs, no scratch,
+    no compiler-generated AGPR traffic, and none of the hazards hipcc does not pad inside asm statements."""
+    import importlib.util
+    import shutil
+    import pytest
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not (os.path.exists(mod.HIPCC) or shutil.which(mod.HIPCC)):
+        pytest.skip("hipcc not available")
+    problems, summary = mod.audit(mod.compile_listing())
+    assert not problems, problems
+    assert summary["mfma"] == 16 + 3 * 32 + 2 * 16 and summary["agpr_count"] == 96      # prologue, 3 full steps, 2 tail steps

@@ -364,6 +364,106 @@ def test_flash_log2_logits_staircase(growth):
     check(out, attn_ref(q[None], k[None], v[None], LN2)[0], tol=3e-3, name=f"flash log2 staircase {growth}")
 
 
+# ---- the software-pipelined kernel (csrc/attention_v2.hip), forced through the FLASH_IMPL knob so that short sequences reach it
+@pytest.fixture
+def flash_v2():
+    from viewcrafter_amd import ops
+    prev = ops.tune_set("FLASH_IMPL", 2)
+    yield ops
+    ops.tune_set("FLASH_IMPL", prev)
+
+
+@pytest.mark.parametrize("G,heads,nq,nk,kv_div", [(1, 1, 256, 64, 1),      # one key tile: prologue + tail only
+                                                  (2, 1, 256, 128, 1),     # two tiles: one pipelined step + tail
+                                                  (3, 2, 300, 192, 1),     # odd tile count, ragged query block
+                                                  (2, 3, 1000, 640, 1),    # 10 tiles, 4 query blocks of which the last is partial
+                                                  (4, 2, 512, 320, 2),     # K / V shared by pairs of groups (kv_div)
+                                                  (2, 5, 2304, 2304, 1),   # level-1 shape of the UNet
+                                                  (9, 1, 64, 1088, 1)])    # more problems than XCDs, 17 tiles
+def test_flash_v2_matches_reference(flash_v2, G, heads, nq, nk, kv_div):
+    """Same contract as vcx_attn_flash_d64_f16 with VCX_ATTN_LOG2_LOGITS; every structural case of the pipeline (tile-count
+    parity, tail step, partial query blocks, shared K/V, XCD-grouped grid with padding)."""
+    ops = flash_v2
+    C = heads * 64
+    Gk = G // kv_div
+    q = _log2_q(rnd(G * nq, C, seed=170)).to(DEV)
+    k = rnd(Gk * nk, C, seed=171).to(DEV).half()
+    v = rnd(Gk * nk, C, seed=172).to(DEV).half()
+    out = torch.full((G * nq, C), float("nan"), device=DEV, dtype=torch.float16)
+    ops.flash_attn(q, k, v.t().contiguous(), out, n_groups=G, heads=heads, nq=nq, nk=nk, kv_rows=nk, kv_div=kv_div, ldq=C, ldk=C,
+                   ldvt=Gk * nk, ldo=C, scale=0.0, log2_logits=True)
+
+    def split(t, g, n):
+        return t.view(g, n, heads, 64).permute(0, 2, 1, 3)
+    kk = split(k, Gk, nk).repeat_interleave(kv_div, dim=0).reshape(G * heads, nk, 64)
+    vv = split(v, Gk, nk).repeat_interleave(kv_div, dim=0).reshape(G * heads, nk, 64)
+    ref = attn_ref(split(q, G, nq).reshape(G * heads, nq, 64), kk, vv, LN2).view(G, heads, nq, 64).permute(0, 2, 1, 3).reshape(G * nq, C)
+    assert torch.isfinite(out).all()
+    check(out, ref, tol=3e-3, name=f"flash v2 {G}x{heads}x{nq}x{nk}")
+
+
+@pytest.mark.parametrize("growth", [-9.0, 1.5, 6.0, 12.0])
+def test_flash_v2_staircase(flash_v2, growth):
+    """The deferred max update of the pipelined kernel: the decision for tile j + 1 is taken while the PV MFMAs of tile j are
+    in flight, and O / l / the pending score tile are rescaled behind them.  Never / sometimes / always over the threshold,
+    and falling scores, on top of a -40 offset (the first-tile update)."""
+    ops = flash_v2
+    n = 640
+    q = rnd(n, 64, seed=61) * 0.3
+    k = rnd(n, 64, seed=62) * 0.3
+    v = rnd(n, 64, seed=63)
+    q[:, 0] = 1.0
+    k[:, 0] = ((torch.arange(n) // 64).float() * growth - 40.0) * (8.0 / 1.4426950408889634)
+    k[:, 0] += rnd(n, seed=64) * 0.5
+    q, k, v = _log2_q(q).to(DEV), k.to(DEV).half(), v.to(DEV).half()
+    out = torch.empty(n, 64, device=DEV, dtype=torch.float16)
+    ops.flash_attn(q, k, v.t().contiguous(), out, n_groups=1, heads=1, nq=n, nk=n, kv_rows=n, kv_div=1, ldq=64, ldk=64,
+                   ldvt=n, ldo=64, scale=0.0, log2_logits=True)
+    check(out, attn_ref(q[None], k[None], v[None], LN2)[0], tol=3e-3, name=f"flash v2 staircase {growth}")
+
+
+def test_flash_v2_spiked_keys_force_the_rescale_branch(flash_v2):
+    """Single rows whose maximum jumps by far more than 2^8 in a late tile (odd and even tile parity), for queries in both
+    32-row blocks of a wave and in both lane halves; all other rows of those waves take the rescale with alpha = 1."""
+    ops = flash_v2
+    n = 704                                     # 11 key tiles
+    q = rnd(n, 64, seed=52)
+    k = rnd(n, 64, seed=53)
+    v = rnd(n, 64, seed=54)
+    for qi, ki, amp in [(7, 300, 6.0), (100, 10, 4.0), (45, 650, 5.0), (300, 385, 7.0), (301, 449, 7.0), (600, 703, 3.0)]:
+        k[ki] = q[qi] * amp
+    ql, k, v = _log2_q(q).to(DEV), k.to(DEV).half(), v.to(DEV).half()
+    out = torch.empty(n, 64, device=DEV, dtype=torch.float16)
+    ops.flash_attn(ql, k, v.t().contiguous(), out, n_groups=1, heads=1, nq=n, nk=n, kv_rows=n, kv_div=1, ldq=64, ldk=64,
+                   ldvt=n, ldo=64, scale=0.0, log2_logits=True)
+    check(out, attn_ref(ql[None], k[None], v[None], LN2)[0], tol=3e-3, name="flash v2 spiked keys")
+
+
+def test_flash_v2_is_bit_reproducible_and_dispatched_for_long_sequences():
+    """Default dispatch (knob at 0) takes the pipelined kernel from 1024 keys on; two runs agree bit for bit and with the phased
+    kernel (knob 1) to fp16 rounding."""
+    from viewcrafter_amd import ops
+    G, heads, n = 2, 2, 1024
+    C = heads * 64
+    qk = rnd(G * n, 2 * C, seed=180).to(DEV).half()
+    qk[:, :C] = _log2_q(qk[:, :C].float().cpu()).to(DEV)
+    v = rnd(G * n, C, seed=181).to(DEV).half()
+    vt = v.t().contiguous()
+    outs = []
+    for impl in (0, 0, 1):
+        prev = ops.tune_set("FLASH_IMPL", impl)
+        try:
+            o = torch.empty(G * n, C, device=DEV, dtype=torch.float16)
+            ops.flash_attn(qk, qk[:, C:], vt, o, n_groups=G, heads=heads, nq=n, nk=n, kv_rows=n, kv_div=1, ldq=2 * C, ldk=2 * C,
+                           ldvt=G * n, ldo=C, scale=0.0, log2_logits=True)
+            outs.append(o)
+        finally:
+            ops.tune_set("FLASH_IMPL", prev)
+    assert torch.equal(outs[0], outs[1])
+    check(outs[0], outs[2].float(), tol=2e-3, name="flash v2 vs v1")
+    assert not torch.equal(outs[0], outs[2])          # different kernels (summation order): equality would mean the knob is dead
+
+
 @pytest.mark.parametrize("n", [288, 512])      # one / two 32-row query blocks per wave
 def test_flash_log2_logits_accumulate(n):
     from viewcrafter_amd import ops

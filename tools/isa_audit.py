@@ -1,0 +1,167 @@
+"""Static audit of the hand-scheduled flash-attention kernel (viewcrafter_amd/csrc/attention_v2.hip).
+
+The kernel owns the accumulator half of the register file by NAME inside asm statements and issues every MFMA and every
+softmax VALU operation as asm, so hipcc neither allocates those registers nor pads the hazards of those instructions.  This
+script compiles the file to gfx950 assembly (device side only, a few seconds, no GPU) and checks what the compiler cannot:
+
+  1. resources: no scratch, no VGPR spills, exactly the 96 asm-owned AGPRs (a[0:63] O^T, a[64:95] Q), arch VGPRs <= 256;
+  2. the compiler itself never touches an AGPR: no v_accvgpr_* and no a-register operand outside ;;#ASMSTART / ;;#ASMEND;
+  3. every v_mfma sits inside an asm statement (no builtin MFMA whose register form the allocator would choose);
+  4. MFMA result -> VALU: no non-MFMA instruction reads or writes a VGPR of an MFMA destination tuple within MIN_MFMA_GAP
+     wait states behind that MFMA (8-pass XDL write -> VALU read needs 11-12; an instruction is 1, s_nop N is N + 1);
+  5. VALU write -> v_permlane32_swap of the same register: at least 2 instructions in between;
+  6. transcendental forwarding: the instruction right behind a v_exp_f32 does not read its result;
+  7. VALU write -> MFMA source (A / B / C in VGPRs): at least 2 wait states (instructions or s_nop states) in between.
+Checks 4-7 walk the listing linearly (basic blocks in layout order), which is how the hot loop executes.
+
+    python tools/isa_audit.py            # exit code 0 = clean; prints a per-check summary
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "viewcrafter_amd", "csrc", "attention_v2.hip")
+KERNEL = "flash2_d64_kernel"
+MIN_MFMA_GAP = 16
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only", "-fno-slp-vectorize",
+         "-S", "--cuda-device-only"]
+
+
+def compile_listing(path=None):
+    out = path or os.path.join(tempfile.mkdtemp(prefix="vcx_isa_"), "attention_v2.s")
+    r = subprocess.run([HIPCC] + FLAGS + ["-o", out, SRC], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stderr[-3000:])
+    return open(out).read()
+
+
+def vregs(tok, prefix="v"):
+    """'v[12:15]' -> {12..15}, 'v7' -> {7}; anything else -> {}."""
+    m = re.fullmatch(prefix + r"\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(prefix + r"(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def parse(listing):
+    body = listing[listing.index(next(l for l in listing.split("\n") if l.startswith("_Z") and KERNEL in l.split(":")[0] and ":" in l)):]
+    body = body[:body.index(".Lfunc_end")]
+    ins, in_asm = [], False
+    for raw in body.split("\n")[1:]:
+        t = raw.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+            continue
+        t = t.split(";")[0].strip()
+        op, _, rest = t.partition(" ")
+        ops = [o.strip() for o in rest.split(",")] if rest else []
+        ins.append(dict(op=op, ops=ops, asm=in_asm, text=t))
+    meta = {k: int(v) for k, v in re.findall(r"\.(agpr_count|vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)",
+                                              listing[listing.index("amdhsa.kernels"):])}
+    return ins, meta
+
+
+def writes_reads(i):
+    """(written VGPR set, read VGPR set) of one instruction, by mnemonic class; conservative for what matters here."""
+    op, ops = i["op"], i["ops"]
+    if not ops or op.startswith("s_") or op.startswith("buffer_") or op.startswith("global_store"):
+        return set(), set().union(*[vregs(o) for o in ops]) if ops else set()
+    if op.startswith("v_permlane"):
+        both = vregs(ops[0]) | vregs(ops[1])
+        return both, both
+    if op.startswith("v_cmp"):
+        return set(), set().union(*[vregs(o.split(" ")[0]) for o in ops])
+    w = vregs(ops[0])
+    r = set().union(*[vregs(o.split(" ")[0].lstrip("-|").rstrip("|")) for o in ops[1:]]) if len(ops) > 1 else set()
+    return w, r
+
+
+def wait_states(i):
+    return int(i["ops"][0]) + 1 if i["op"] == "s_nop" and i["ops"] else 1
+
+
+def audit(listing):
+    ins, meta = parse(listing)
+    problems = []
+    arch = meta.get("vgpr_count", 0) - meta.get("agpr_count", 0)
+    if meta.get("private_segment_fixed_size", 1) != 0 or meta.get("vgpr_spill_count", 1) != 0 or meta.get("sgpr_spill_count", 1) != 0:
+        problems.append(f"1: scratch / spills: {meta}")
+    if meta.get("agpr_count") != 96 or arch > 256:
+        problems.append(f"1: expected exactly 96 asm-owned AGPRs and <= 256 arch VGPRs, got {meta}")
+    n_mfma = 0
+    for k, i in enumerate(ins):
+        touches_a = i["op"].startswith("v_accvgpr") or any(vregs(o, "a") for o in i["ops"])
+        if touches_a and not i["asm"]:
+            problems.append(f"2: compiler-generated AGPR access: {i['text']}")
+        if i["op"].startswith("v_mfma"):
+            n_mfma += 1
+            if not i["asm"]:
+                problems.append(f"3: MFMA outside an asm statement: {i['text']}")
+            dst = vregs(i["ops"][0])
+            if dst:          # VGPR destination: nobody but the accumulate chain touches it for MIN_MFMA_GAP wait states
+                states = 0
+                for j in ins[k + 1:k + 1 + MIN_MFMA_GAP]:
+                    if states >= MIN_MFMA_GAP:
+                        break
+                    if not (j["op"].startswith("v_mfma") or j["op"].startswith("ds_read") and not (vregs(j["ops"][0]) & dst)):
+                        w, r = writes_reads(j)
+                        if (w | r) & dst:
+                            problems.append(f"4: '{j['text']}' touches the destination of '{i['text']}' only {states} wait states behind it")
+                            break
+                    states += wait_states(j)
+            srcs = set().union(*[vregs(o) for o in i["ops"][1:]])
+            states = 0
+            for j in reversed(ins[max(0, k - 4):k]):
+                if j["op"] == "s_nop":
+                    states += wait_states(j)
+                    continue
+                w, _ = writes_reads(j)
+                if j["op"].startswith("v_") and not j["op"].startswith("v_mfma") and w & srcs and states < 2:
+                    problems.append(f"7: '{j['text']}' writes a source of '{i['text']}' only {states} wait state(s) ahead")
+                states += 1
+                if states >= 2:
+                    break
+        if i["op"].startswith("v_permlane"):
+            regs = vregs(i["ops"][0]) | vregs(i["ops"][1])
+            states = 0
+            for j in reversed(ins[max(0, k - 3):k]):
+                if j["op"] == "s_nop":
+                    states += wait_states(j)
+                    continue
+                if states >= 2:
+                    break
+                w, _ = writes_reads(j)
+                if j["op"].startswith("v_") and w & regs:
+                    problems.append(f"5: '{j['text']}' writes an operand of '{i['text']}' only {states} wait state(s) ahead")
+                states += 1
+        if i["op"].startswith("v_exp_f32") and k + 1 < len(ins):
+            w, _ = writes_reads(i)
+            _, r = writes_reads(ins[k + 1])
+            if w & r:
+                problems.append(f"6: '{ins[k + 1]['text']}' reads the transcendental result of '{i['text']}' right behind it")
+    summary = dict(meta, arch_vgprs=arch, instructions=len(ins), mfma=n_mfma, asm_statements=sum(1 for i in ins if i["asm"]),
+                   s_nop=sum(1 for i in ins if i["op"] == "s_nop"))
+    return problems, summary
+
+
+def main():
+    problems, summary = audit(compile_listing(sys.argv[1] if len(sys.argv) > 1 else None))
+    print("flash2_d64_kernel:", summary)
+    for p in problems:
+        print("PROBLEM", p)
+    print("clean" if not problems else f"{len(problems)} problem(s)")
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

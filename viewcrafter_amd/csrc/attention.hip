@@ -1,6 +1,7 @@
 // Attention kernels for gfx950: flash attention (head dim 64) on MFMA 32x32x16 f16, temporal
 // attention over T <= 32 frames on the VALU, and an in-place row softmax.
 #include "vcx_common.h"
+#include "flash2.h"
 #include <stdlib.h>
 
 namespace {
@@ -725,6 +726,19 @@ extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* 
     VcxProfScope prof(VCX_FAM_FLASH, s, 4.0 * nprob * nq * (double)nk * 64, 2.0 * nprob * 64 * (2.0 * nq + 2.0 * nk));
     VCX_REQUIRE(((int64_t)(nk - 1) * ldk + 64) * 2 < 0xFFFF0000ll && (63ll * ldvt + nk + 8) * 2 < 0xFFFF0000ll,
                 "vcx_attn_flash_d64_f16: K / V^T extents per (group, head) must stay below 4 GiB");
+    // Long key sequences with base-2 logits and whole 64-key tiles: the software-pipelined kernel (attention_v2.hip: MFMA and
+    // softmax overlapped inside one wave per SIMD).  One block per CU and a prologue that is not hidden behind another block:
+    // from 16 key tiles up (knob FLASH_IMPL: 1 = never, 2 = whenever the shapes allow)
+    const int impl = vcx_tune(VCX_TUNE_FLASH_IMPL);
+    if (impl != 1 && pre && !(flags & VCX_ATTN_ACCUMULATE) && nk % 64 == 0 && (impl == 2 || nk >= 1024)) {
+        Flash2Args f;
+        f.q = (const half_t*)q; f.k = (const half_t*)k; f.vt = (const half_t*)vt; f.o = (half_t*)o;
+        f.heads = heads; f.nq = nq; f.nk = nk; f.kv_rows = kv_rows; f.kv_div = kv_div;
+        f.ldq = ldq; f.ldk = ldk; f.ldvt = ldvt; f.ldo = ldo;
+        f.nqb = (nq + 255) / 256;
+        f.nprob = n_groups * heads;
+        return vcx_flash2_launch(f, s);
+    }
     // two 32-row query blocks per wave (256 rows per block) unless the row count would waste > 20 % of such blocks
     const int force_qb = vcx_tune(VCX_TUNE_FLASH_QB);
     const int blocks2 = (nq + 255) / 256;
