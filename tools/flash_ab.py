@@ -1,0 +1,40 @@
+"""A/B of the two flash-attention kernels (knob FLASH_IMPL: 1 = phased v1, 2 = software-pipelined v2) on the UNet's self-attention
+shapes, interleaved rounds in one process, median / min ms and TF/s, plus the largest difference between the two outputs.
+    python tools/flash_ab.py [rounds]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from viewcrafter_amd import ops
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+shapes = [(9216, 50, 5), (2304, 50, 10), (1152, 50, 10), (576, 50, 20)]      # (tokens, frames, heads)
+torch.manual_seed(0)
+for N, G, heads in shapes:
+    C = heads * 64
+    qk = torch.randn(G * N, 2 * C, device="cuda")
+    qk[:, :C] *= (0.125 * ops.LOG2E)
+    qk = qk.half()
+    vt = torch.randn(C, G * N, device="cuda").half()
+    outs, times = {}, {1: [], 2: []}
+    for impl in (1, 2):
+        outs[impl] = torch.empty(G * N, C, device="cuda", dtype=torch.float16)
+
+    def run(impl):
+        ops.flash_attn(qk, qk[:, C:], vt, outs[impl], n_groups=G, heads=heads, nq=N, nk=N, kv_rows=N, kv_div=1, ldq=2 * C, ldk=2 * C,
+                       ldvt=G * N, ldo=C, scale=0.125, log2_logits=True)
+    for r in range(rounds):
+        for impl in (1, 2):
+            ops.tune_set("FLASH_IMPL", impl)
+            run(impl); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5): run(impl)
+            b.record(); torch.cuda.synchronize()
+            times[impl].append(a.elapsed_time(b) / 5)
+    ops.tune_set("FLASH_IMPL", 0)
+    fl = 4.0 * G * heads * N * N * 64
+    d = (outs[1].float() - outs[2].float()).abs().max().item()
+    row = f"N={N:5d} G={G} heads={heads:2d}: "
+    for impl in (1, 2):
+        t = sorted(times[impl]); med = t[len(t) // 2]
+        row += f"v{impl} {med:7.3f} ms (min {t[0]:7.3f}) {fl / med / 1e9:5.0f} TF/s   "
+    print(row + f"max |v1 - v2| = {d:.2e}  finite={bool(torch.isfinite(outs[2]).all())}", flush=True)

@@ -4,7 +4,7 @@ The kernel owns the accumulator half of the register file by NAME inside asm sta
 softmax VALU operation as asm, so hipcc neither allocates those registers nor pads the hazards of those instructions.  This
 script compiles the file to gfx950 assembly (device side only, a few seconds, no GPU) and checks what the compiler cannot:
 
-  1. resources: no scratch, no VGPR spills, exactly the 96 asm-owned AGPRs (a[0:63] O^T, a[64:95] Q), arch VGPRs <= 256;
+  1. resources: no scratch, no VGPR spills, exactly the 132 asm-owned AGPRs (a[0:63] O^T, a[64:95] Q, a[96:127] row sums, a[128:131] ones), arch VGPRs <= 256;
   2. the compiler itself never touches an AGPR: no v_accvgpr_* and no a-register operand outside ;;#ASMSTART / ;;#ASMEND;
   3. every v_mfma sits inside an asm statement (no builtin MFMA whose register form the allocator would choose);
   4. MFMA result -> VALU: no non-MFMA instruction reads or writes a VGPR of an MFMA destination tuple within MIN_MFMA_GAP
@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "viewcrafter_amd", "csrc", "attention_v2.hip")
 KERNEL = "flash2_d64_kernel"
 MIN_MFMA_GAP = 16
+N_AGPR = 132
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only", "-fno-slp-vectorize",
          "-S", "--cuda-device-only"]
@@ -96,8 +97,8 @@ def audit(listing):
     arch = meta.get("vgpr_count", 0) - meta.get("agpr_count", 0)
     if meta.get("private_segment_fixed_size", 1) != 0 or meta.get("vgpr_spill_count", 1) != 0 or meta.get("sgpr_spill_count", 1) != 0:
         problems.append(f"1: scratch / spills: {meta}")
-    if meta.get("agpr_count") != 96 or arch > 256:
-        problems.append(f"1: expected exactly 96 asm-owned AGPRs and <= 256 arch VGPRs, got {meta}")
+    if meta.get("agpr_count") != N_AGPR or arch > 256:
+        problems.append(f"1: expected exactly {N_AGPR} asm-owned AGPRs and <= 256 arch VGPRs, got {meta}")
     n_mfma = 0
     for k, i in enumerate(ins):
         touches_a = i["op"].startswith("v_accvgpr") or any(vregs(o, "a") for o in i["ops"])

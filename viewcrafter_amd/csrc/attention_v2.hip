@@ -54,16 +54,17 @@ FI void sfor(F&& f) {
 }
 
 // ---- the asm-owned accumulator file
-#define CLOB_O16(b) "a" #b "0"
 #define CLOB_O "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19",  \
                "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37",    \
                "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55",    \
                "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"
+#define CLOB_L "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112",   \
+               "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128",  \
+               "a129", "a130", "a131"
 #define CLOB_Q "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81",   \
                "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"
 
 // score MFMAs: D(v) = K(v) x Q(a[...]) + C.  I = 4 b + s selects the Q fragment.
-#define QREG(I) (I == 0 ? 0 : 0)
 template <int I>
 FI void mfma_qk_zero(f16v& d, const h8& kf) {
 #define VCX_QK0(n, lo, hi) if constexpr (I == n) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[" #lo ":" #hi "], 0" : "=&v"(d) : "v"(kf))
@@ -73,7 +74,7 @@ FI void mfma_qk_zero(f16v& d, const h8& kf) {
 }
 template <int I>
 FI void mfma_qk_first(f16v& d, const h8& kf, const f16v& c) {       // C = -running max in all slots
-#define VCX_QK1(n, lo, hi) if constexpr (I == n) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, a[" #lo ":" #hi "], %2" : "=&v"(d) : "v"(kf), "v"(c))
+#define VCX_QK1(n, lo, hi) if constexpr (I == n) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[" #lo ":" #hi "], %2" : "=&v"(d) : "v"(kf), "v"(c))
     VCX_QK1(0, 64, 67); VCX_QK1(1, 68, 71); VCX_QK1(2, 72, 75); VCX_QK1(3, 76, 79);
     VCX_QK1(4, 80, 83); VCX_QK1(5, 84, 87); VCX_QK1(6, 88, 91); VCX_QK1(7, 92, 95);
 #undef VCX_QK1
@@ -85,18 +86,32 @@ FI void mfma_qk_acc(f16v& d, const h8& kf) {
     VCX_QK2(4, 80, 83); VCX_QK2(5, 84, 87); VCX_QK2(6, 88, 91); VCX_QK2(7, 92, 95);
 #undef VCX_QK2
 }
-// PV MFMAs: O^T(a) += V^T(v) x P(v).  I = 2 b + db selects the accumulator.
+// PV MFMAs: O^T(a) += V^T(v) x P(v).  I = 2 b + db selects the accumulator.  No clobber list and no s_nop on the hot statements:
+// hipcc pads an s_nop in front of an asm statement that clobbers registers, and P is written >= 2 instructions ahead by
+// schedule (tools/isa_audit.py check 7); the statements that initialise / rescale / read the accumulators carry the clobbers.
 template <int I>
 FI void mfma_pv(const h8& vf, const u4v& pf) {
-#define VCX_PV(n, lo, hi) if constexpr (I == n) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[" #lo ":" #hi "], %0, %1, a[" #lo ":" #hi "]" : : "v"(vf), "v"(pf) : CLOB_O)
+#define VCX_PV(n, lo, hi) if constexpr (I == n) asm volatile("v_mfma_f32_32x32x16_f16 a[" #lo ":" #hi "], %0, %1, a[" #lo ":" #hi "]" : : "v"(vf), "v"(pf))
     VCX_PV(0, 0, 15); VCX_PV(1, 16, 31); VCX_PV(2, 32, 47); VCX_PV(3, 48, 63);
 #undef VCX_PV
 }
-FI void acc_zero_o() {
+// Row sums on the matrix pipe: L_b(a) += ONES(a) x P(v) - every row of the 32 x 32 result is sum_k P[k][q], over all 16 keys of
+// the k-step (both lane halves).  8 MFMAs per tile instead of 64 v_add_f32: the key loop is bound by instruction issue (one wave
+// per SIMD issues ~1 instruction per 5 cycles), not by the pipe, and the sum is taken over the fp16 P that the PV product uses.
+template <int B>
+FI void mfma_rowsum(const u4v& pf) {
+    if constexpr (B == 0) asm volatile("v_mfma_f32_32x32x16_f16 a[96:111], a[128:131], %0, a[96:111]" : : "v"(pf));
+    else asm volatile("v_mfma_f32_32x32x16_f16 a[112:127], a[128:131], %0, a[112:127]" : : "v"(pf));
+}
+FI void acc_zero_o(const u32& ones) {       // ones = 0x3c003c00: two fp16 1.0
 #define Z4(a, b, c, d) "v_accvgpr_write_b32 a" #a ", 0\n\tv_accvgpr_write_b32 a" #b ", 0\n\tv_accvgpr_write_b32 a" #c ", 0\n\tv_accvgpr_write_b32 a" #d ", 0\n\t"
     asm volatile(Z4(0, 1, 2, 3) Z4(4, 5, 6, 7) Z4(8, 9, 10, 11) Z4(12, 13, 14, 15) Z4(16, 17, 18, 19) Z4(20, 21, 22, 23) Z4(24, 25, 26, 27)
                  Z4(28, 29, 30, 31) Z4(32, 33, 34, 35) Z4(36, 37, 38, 39) Z4(40, 41, 42, 43) Z4(44, 45, 46, 47) Z4(48, 49, 50, 51)
                  Z4(52, 53, 54, 55) Z4(56, 57, 58, 59) Z4(60, 61, 62, 63) "s_nop 1" : : : CLOB_O);
+    asm volatile(Z4(96, 97, 98, 99) Z4(100, 101, 102, 103) Z4(104, 105, 106, 107) Z4(108, 109, 110, 111) Z4(112, 113, 114, 115) Z4(116, 117, 118, 119)
+                 Z4(120, 121, 122, 123) Z4(124, 125, 126, 127)
+                 "v_accvgpr_write_b32 a128, %0\n\tv_accvgpr_write_b32 a129, %0\n\tv_accvgpr_write_b32 a130, %0\n\tv_accvgpr_write_b32 a131, %0\n\ts_nop 1"
+                 : : "v"(ones) : CLOB_L);
 #undef Z4
 }
 // Q fragment I = 4 b + s (four dwords) into a[64 + 4 I ...]
@@ -107,19 +122,22 @@ FI void acc_load_q(const u4v& w) {
     VCX_LQ(4, 80, 81, 82, 83); VCX_LQ(5, 84, 85, 86, 87); VCX_LQ(6, 88, 89, 90, 91); VCX_LQ(7, 92, 93, 94, 95);
 #undef VCX_LQ
 }
-// O^T of query block B (a[32 B .. 32 B + 31]) times alpha (per lane), in place; the PV MFMAs in flight complete first
+// O^T of query block B (a[32 B .. 32 B + 31]) and its row sums L_B (a[96 + 16 B ...]) times alpha (per lane), in place; the
+// MFMAs in flight complete first
 #define S1(n) "v_accvgpr_read_b32 %0, a" #n "\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a" #n ", %0\n\t"
 template <int B>
 FI void acc_scale_o(const float& alpha) {
     float t;
     if constexpr (B == 0)
         asm volatile("s_nop 15\n\ts_nop 15\n\t" S1(0) S1(1) S1(2) S1(3) S1(4) S1(5) S1(6) S1(7) S1(8) S1(9) S1(10) S1(11) S1(12) S1(13) S1(14) S1(15)
-                     S1(16) S1(17) S1(18) S1(19) S1(20) S1(21) S1(22) S1(23) S1(24) S1(25) S1(26) S1(27) S1(28) S1(29) S1(30) S1(31) "s_nop 1"
-                     : "=&v"(t) : "v"(alpha) : CLOB_O);
+                     S1(16) S1(17) S1(18) S1(19) S1(20) S1(21) S1(22) S1(23) S1(24) S1(25) S1(26) S1(27) S1(28) S1(29) S1(30) S1(31)
+                     S1(96) S1(97) S1(98) S1(99) S1(100) S1(101) S1(102) S1(103) S1(104) S1(105) S1(106) S1(107) S1(108) S1(109) S1(110) S1(111) "s_nop 1"
+                     : "=&v"(t) : "v"(alpha) : CLOB_O, CLOB_L);
     else
         asm volatile("s_nop 15\n\ts_nop 15\n\t" S1(32) S1(33) S1(34) S1(35) S1(36) S1(37) S1(38) S1(39) S1(40) S1(41) S1(42) S1(43) S1(44) S1(45) S1(46) S1(47)
-                     S1(48) S1(49) S1(50) S1(51) S1(52) S1(53) S1(54) S1(55) S1(56) S1(57) S1(58) S1(59) S1(60) S1(61) S1(62) S1(63) "s_nop 1"
-                     : "=&v"(t) : "v"(alpha) : CLOB_O);
+                     S1(48) S1(49) S1(50) S1(51) S1(52) S1(53) S1(54) S1(55) S1(56) S1(57) S1(58) S1(59) S1(60) S1(61) S1(62) S1(63)
+                     S1(112) S1(113) S1(114) S1(115) S1(116) S1(117) S1(118) S1(119) S1(120) S1(121) S1(122) S1(123) S1(124) S1(125) S1(126) S1(127) "s_nop 1"
+                     : "=&v"(t) : "v"(alpha) : CLOB_O, CLOB_L);
 }
 #undef S1
 // accumulator I = 2 b + db -> 16 VGPR floats (epilogue)
@@ -143,6 +161,14 @@ FI void acc_read_o(f16v& o) {
 #undef R4
 }
 
+template <int B>
+FI float acc_read_l() {     // every element of L_B is the row sum of this lane's query
+    float l;
+    if constexpr (B == 0) asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a96\n\ts_nop 1" : "=v"(l));
+    else asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a112\n\ts_nop 1" : "=v"(l));
+    return l;
+}
+
 // ---- softmax VALU as asm statements: `asm volatile` keeps them exactly where the schedule below puts them (pure HIP arithmetic
 // is placed by instruction selection next to its consumer, whatever sched_barrier says) and exactly these opcodes (no
 // v_pk_add_f32 from the SLP vectoriser, no canonicalising v_max in front of fmaxf: both measured anti-levers beside MFMAs).
@@ -152,7 +178,6 @@ FI void acc_read_o(f16v& o) {
 //     statement that touches any element of it;
 //   * no statement reads the result of the one right before it (transcendental forwarding, v_permlane after VALU).
 #define V_EXP2(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
-#define V_ACC(acc, x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x))
 #define V_PACK(w, lo, hi) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi))
 #define V_SWAP32(a, b) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b))
 #define V_MAX3I(r, a, b, c) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c))
@@ -160,45 +185,48 @@ FI void acc_read_o(f16v& o) {
 #define V_MAX2A(r, b) asm volatile("v_max_f32 %0, %0, %1" : "+v"(r) : "v"(b))
 #define V_MAX2I(r, a, b) asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b))
 
-constexpr int NF_PAIR = 44;               // one (key half, k-step) chunk of BOTH query blocks: 16 exp2, 16 adds, 8 packs, 4 half swaps
-constexpr int NF_EXP = 4 * NF_PAIR;       // 176
+constexpr int NF_PAIR = 28;               // one (key half, k-step) chunk of BOTH query blocks: 16 exp2, 8 packs, 4 half swaps
+constexpr int NF_EXP = 4 * NF_PAIR;       // 112
 constexpr int NF_ALL = NF_EXP + 32 + 4;   // + row maxima of the next tile (4 accumulators x 8, round-robin), 2 combines, 2 cross-half exchanges
-[[maybe_unused]] constexpr int NF_MID = 24;                // micro-operations issued as one burst behind the per-tile barrier (they cover the V^T fragment latency)
+[[maybe_unused]] constexpr int NF_MID = 20;   // micro-operations issued as one burst behind the per-tile barrier (they cover the V^T fragment latency)
+constexpr int NGAP = 40;                  // MFMAs per tile: 16 score, 16 PV, 8 row-sum
 
 // One VALU micro-operation of the softmax stream.
-// F < 176, tile `cur`: chunk t = 2 kb + s holds this lane's scores of keys 16 t + 4 hi + {0..3} and 16 t + 8 + 4 hi + {0..3} (the
-// accumulator layout); exp2 in place, row sums, packing to fp16 words w0..w3, then v_permlane32_swap(w0, w2), (w1, w3) with the
-// lane that holds the other half of the query row: afterwards the lane owns P of keys 16 t + 8 hi + {0..7} - eight consecutive
-// keys, the plain B-operand layout, so that the matching V^T fragment is ONE 16-byte chunk (ds_read_b128, no two-piece gather).
-// Chunks come in the order the PV MFMAs consume them.  F >= 176: row maxima over tile `nxt`.
+// F < 112, tile `cur`: chunk t = 2 kb + s holds this lane's scores of keys 16 t + 4 hi + {0..3} and 16 t + 8 + 4 hi + {0..3} (the
+// accumulator layout); exp2 in place, packing to fp16 words w0..w3, then v_permlane32_swap(w0, w2), (w1, w3) with the lane that
+// holds the other half of the query row: afterwards the lane owns P of keys 16 t + 8 hi + {0..7} - eight consecutive keys, the
+// plain B-operand layout, so that the matching V^T fragment is ONE 16-byte chunk (ds_read_b128, no two-piece gather).
+// Chunks come in the order the PV MFMAs consume them.  F >= 112: row maxima over tile `nxt`.
 template <int F>
-FI void filler(f16v (&cur)[2][2], f16v (&nxt)[2][2], u4v (&pf)[2][2][2], float (&ls)[2][2], float (&mxp)[2][2], float (&mx)[2]) {
+FI void filler(f16v (&cur)[2][2], f16v (&nxt)[2][2], u4v (&pf)[2][2][2], float& m00, float& m01, float& m10, float& m11, float& mx0, float& mx1) {
+    // (six separate scalars, not arrays: an array becomes one register tuple, and a write to one element of a tuple makes hipcc
+    // pad an s_nop in front of the next statement that touches any other element)
     if constexpr (F < NF_EXP) {
         constexpr int t = F / NF_PAIR, q = F % NF_PAIR, kb = t / 2, s = t % 2;
         if constexpr (q < 16) {
             constexpr int b = q % 2, e = q / 2;
             V_EXP2(cur[b][kb][8 * s + e]);
-        } else if constexpr (q < 40) {
-            constexpr int idx = q - 16, b = idx % 2, k = idx / 2, grp = k / 3, w = k % 3;
-            if constexpr (w < 2) V_ACC(ls[b][w], cur[b][kb][8 * s + 2 * grp + w]);
-            else V_PACK(pf[b][kb][s][grp], cur[b][kb][8 * s + 2 * grp], cur[b][kb][8 * s + 2 * grp + 1]);
+        } else if constexpr (q < 24) {
+            constexpr int idx = q - 16, b = idx % 2, grp = idx / 2;
+            V_PACK(pf[b][kb][s][grp], cur[b][kb][8 * s + 2 * grp], cur[b][kb][8 * s + 2 * grp + 1]);
         } else {
-            constexpr int idx = q - 40, b = idx % 2, which = idx / 2;
+            constexpr int idx = q - 24, b = idx % 2, which = idx / 2;
             V_SWAP32(pf[b][kb][s][which], pf[b][kb][s][which + 2]);
         }
     } else if constexpr (F < NF_EXP + 32) {
         constexpr int m = F - NF_EXP, o = m / 4, acc = m % 4, kb = acc / 2, b = acc % 2;       // the four chains interleaved
-        if constexpr (o == 0) V_MAX3I(mxp[b][kb], nxt[b][kb][0], nxt[b][kb][1], nxt[b][kb][2]);
-        else if constexpr (o < 7) V_MAX3A(mxp[b][kb], nxt[b][kb][2 * o + 1], nxt[b][kb][2 * o + 2]);
-        else V_MAX2A(mxp[b][kb], nxt[b][kb][15]);
+        float& mm = b == 0 ? (kb == 0 ? m00 : m01) : (kb == 0 ? m10 : m11);
+        if constexpr (o == 0) V_MAX3I(mm, nxt[b][kb][0], nxt[b][kb][1], nxt[b][kb][2]);
+        else if constexpr (o < 7) V_MAX3A(mm, nxt[b][kb][2 * o + 1], nxt[b][kb][2 * o + 2]);
+        else V_MAX2A(mm, nxt[b][kb][15]);
     } else if constexpr (F < NF_EXP + 34) {
-        constexpr int b = F - NF_EXP - 32;
-        V_MAX2I(mx[b], mxp[b][0], mxp[b][1]);
+        if constexpr (F == NF_EXP + 32) V_MAX2I(mx0, m00, m01);
+        else V_MAX2I(mx1, m10, m11);
     } else {
-        constexpr int b = F - NF_EXP - 34;      // the other 32 keys of the row live in lane ^ 32: after the half swap t0 / t1 hold, in
-        float t0 = mx[b], t1 = mx[b];           // every lane, this lane's value and its partner's (in either order)
+        float& mxb = F == NF_EXP + 34 ? mx0 : mx1;      // the other 32 keys of the row live in lane ^ 32: after the half swap t0 / t1
+        float t0 = mxb, t1 = mxb;                       // hold, in every lane, this lane's value and its partner's (in either order)
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t0), "+v"(t1));
-        V_MAX2I(mx[b], t0, t1);
+        V_MAX2I(mxb, t0, t1);
     }
 }
 
@@ -276,23 +304,22 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) fa[s] = tile_off2(lq, 2 * s + hi);
     h8 kf[4];                   // ring of K fragment units (slot u % 4), requested two units ahead
-    h8 vf[2][2];                // ring of V^T fragment units (slot t % 2) x d half, requested one unit (4 MFMAs) ahead
+    h8 vf[3][2];                // ring of V^T fragment units (slot t % 3) x d half
     auto read_k = [&](const half_t* cK, auto u_c) {
         constexpr int u = decltype(u_c)::value;
         kf[u % 4] = *reinterpret_cast<const h8*>(cK + (u / 4) * 32 * 64 + fa[u % 4]);
     };
     auto read_v = [&](const half_t* cV, auto t_c) {
         constexpr int t = decltype(t_c)::value;
-        vf[t % 2][0] = *reinterpret_cast<const h8*>(cV + fa[t]);
-        vf[t % 2][1] = *reinterpret_cast<const h8*>(cV + 32 * 64 + fa[t]);
+        vf[t % 3][0] = *reinterpret_cast<const h8*>(cV + fa[t]);
+        vf[t % 3][1] = *reinterpret_cast<const h8*>(cV + 32 * 64 + fa[t]);
     };
 
     // ---- state (VGPRs)
     f16v S[2][2][2];            // [tile parity][query block][key half]: scores minus the running max (base-2 logits)
     f16v cinit[2];              // -running max of query block b in all 16 slots: C operand of a tile's first score MFMA
     u4v pf[2][2][2];            // packed fp16 probabilities [query block][key half][k-step] (8 halves = the B operand of a PV MFMA)
-    float ls[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     // row sums, two partial accumulators per query block
-    float mxp[2][2], mx[2];
+    float m00, m01, m10, m11, mx0, mx1;     // row maxima: partial (per score accumulator) and per query block
     float negm[2] = {0.f, 0.f};
 
     const int ntiles = p.nk >> 6;
@@ -302,7 +329,7 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
     dma_v(C0{}, 0);
     if (ntiles > 1) dma_k(C1{}, 1);
     sfor<0, 8>([&](auto i_c) { acc_load_q<decltype(i_c)::value>(qw[decltype(i_c)::value]); });
-    acc_zero_o();
+    acc_zero_o(0x3c003c00u);
     __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0)
     __builtin_amdgcn_s_barrier();
     sfor<0, 8>([&](auto u_c) {
@@ -320,21 +347,26 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
     if (ntiles > 2) dma_k(C0{}, 2);
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(S[0][0][0]), "+v"(S[0][0][1]), "+v"(S[0][1][0]), "+v"(S[0][1][1]));   // MFMA results -> VALU
     // first tile: the max moves to the row maximum itself (nothing is accumulated yet)
-    sfor<NF_EXP, NF_ALL>([&](auto f_c) { filler<decltype(f_c)::value>(S[1], S[0], pf, ls, mxp, mx); });
+    sfor<NF_EXP, NF_ALL>([&](auto f_c) { filler<decltype(f_c)::value>(S[1], S[0], pf, m00, m01, m10, m11, mx0, mx1); });
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        negm[b] = -mx[b];
+        const float m = b ? mx1 : mx0;
+        negm[b] = -m;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            S[0][b][0][i] -= mx[b];
-            S[0][b][1][i] -= mx[b];
+            S[0][b][0][i] -= m;
+            S[0][b][1][i] -= m;
             cinit[b][i] = negm[b];
         }
     }
     read_k(sK1, C0{});                            // K fragment units 0, 1 of tile 1 (garbage if there is none: never used)
     read_k(sK1, C1{});
 
-    // ---- one tile: PAR = parity of tile kt (compile time), HAS_NEXT = tile kt + 1 exists
+    // ---- one tile: PAR = parity of tile kt (compile time), HAS_NEXT = tile kt + 1 exists.  40 MFMA gaps:
+    //   0-15   score MFMAs of tile kt + 1: gap 2 u + b, K fragment unit u = 4 kb + s, query block b
+    //   16-39  per k-step unit t = 2 kb + s of tile kt six gaps: PV (db, b) x 4, then the two row-sum MFMAs
+    // LDS fragments are requested in pairs of units four or more MFMAs ahead and waited for with ONE explicit lgkmcnt(0) in front
+    // of the first use (the compiler's own counted waits - one per fragment - then vanish: an s_waitcnt is an issue slot too).
     auto step = [&](auto par_c, auto next_c, int kt) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool HAS_NEXT = decltype(next_c)::value != 0;
@@ -342,8 +374,23 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
         const half_t* cK = (PAR ^ 1) ? sK1 : sK0;          // K(kt + 1)
         const half_t* cV = PAR ? sV1 : sV0;                // V^T(kt)
         const half_t* nK = PAR ? sK1 : sK0;                // K(kt + 2)
-        sfor<0, 32>([&](auto g_c) {
+        sfor<0, NGAP>([&](auto g_c) {
             constexpr int gp = decltype(g_c)::value;
+            // (0) fragments due in this group of gaps have arrived; request the next pair
+            if constexpr (HAS_NEXT && gp < 16 && gp % 4 == 0) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
+                if constexpr (gp < 12) {
+                    read_k(cK, std::integral_constant<int, gp / 2 + 2>{});
+                    read_k(cK, std::integral_constant<int, gp / 2 + 3>{});
+                }
+            }
+            if constexpr (gp == 34) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);        // V^T unit 3 (requested at gap 22)
+                if constexpr (HAS_NEXT) {                  // K fragment units 0, 1 of tile kt + 2: five MFMAs ahead of the next step's gap 0
+                    read_k(nK, C0{});
+                    read_k(nK, C1{});
+                }
+            }
             // (1) the MFMA of this gap
             if constexpr (gp < 16) {
                 if constexpr (HAS_NEXT) {
@@ -352,51 +399,48 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
                     else mfma_qk_acc<4 * b + s>(S[PAR ^ 1][b][kb], kf[u % 4]);
                 }
             } else {
-                constexpr int t = (gp - 16) / 4, r = (gp - 16) % 4, db = r / 2, b = r % 2, kb = t / 2, s = t % 2;
-                mfma_pv<2 * b + db>(vf[t % 2][db], pf[b][kb][s]);
+                constexpr int t = (gp - 16) / 6, r = (gp - 16) % 6, kb = t / 2, s = t % 2;
+                if constexpr (r < 4) mfma_pv<2 * (r % 2) + r / 2>(vf[t % 3][r / 2], pf[r % 2][kb][s]);
+                else mfma_rowsum<r - 4>(pf[r - 4][kb][s]);
             }
             // (2) its share of the softmax stream (NF_MID of it runs as a burst behind the barrier, see (4))
             constexpr int NFG = NF - NF_MID;
-            constexpr int f0 = HAS_NEXT ? gp * NFG / 32 + (gp >= 16 ? NF_MID : 0) : (gp < 16 ? gp * 11 : NF);
-            constexpr int f1 = HAS_NEXT ? (gp + 1) * NFG / 32 + (gp >= 15 ? NF_MID : 0) : (gp < 16 ? (gp + 1) * 11 : NF);
+            constexpr int f0 = HAS_NEXT ? gp * NFG / NGAP + (gp >= 16 ? NF_MID : 0) : (gp < 16 ? gp * 7 : NF);
+            constexpr int f1 = HAS_NEXT ? (gp + 1) * NFG / NGAP + (gp >= 15 ? NF_MID : 0) : (gp < 16 ? (gp + 1) * 7 : NF);
             constexpr int fmid = HAS_NEXT ? f1 - NF_MID : f1;       // gap 15: [f0, fmid) before the barrier, [fmid, f1) behind it
-            sfor<f0, (gp == 15 ? fmid : f1)>([&](auto f_c) { filler<decltype(f_c)::value>(S[PAR], S[PAR ^ 1], pf, ls, mxp, mx); });
-            // (3) fragment requests for later gaps
-            if constexpr (HAS_NEXT && gp < 12 && gp % 2 == 1) read_k(cK, std::integral_constant<int, gp / 2 + 2>{});
-            if constexpr (gp == 19) read_v(cV, std::integral_constant<int, 2>{});
-            if constexpr (gp == 23) read_v(cV, std::integral_constant<int, 3>{});
-            if constexpr (HAS_NEXT && gp == 27) read_k(nK, C0{});
-            if constexpr (HAS_NEXT && gp == 29) read_k(nK, C1{});
+            sfor<f0, (gp == 15 ? fmid : f1)>([&](auto f_c) { filler<decltype(f_c)::value>(S[PAR], S[PAR ^ 1], pf, m00, m01, m10, m11, mx0, mx1); });
+            // (3) later requests
+            if constexpr (gp == 22) read_v(cV, std::integral_constant<int, 3>{});      // slot 0: unit 0's PV MFMAs are gaps 16-19
             if constexpr (HAS_NEXT && gp == 18) dma_v(std::integral_constant<int, PAR ^ 1>{}, kt + 1);
             // (4) between the two MFMA phases: everything this wave has in flight by DMA has landed, then all waves meet.  Only now
-            // is V^T(kt) (issued one tile ago) complete for EVERY wave, so its first fragments are requested here and a burst of
-            // the softmax stream covers their LDS latency; K(kt + 1) is no longer read by anybody and V^T(kt - 1) neither:
-            // their slots take K(kt + 3) (here) and V^T(kt + 1) (two gaps on, beside the MFMAs)
+            // is V^T(kt) (issued one tile ago) complete for EVERY wave, so its fragments are requested here and a burst of the
+            // softmax stream covers their LDS latency; K(kt + 1) is no longer read by anybody and V^T(kt - 1) neither: their
+            // slots take K(kt + 3) (here) and V^T(kt + 1) (three gaps on, beside the MFMAs)
             if constexpr (gp == 15) {
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 __builtin_amdgcn_s_barrier();
                 read_v(cV, C0{});
                 read_v(cV, C1{});
+                read_v(cV, std::integral_constant<int, 2>{});
                 if constexpr (HAS_NEXT) {
                     if (kt + 3 < ntiles) dma_k(std::integral_constant<int, PAR ^ 1>{}, kt + 3);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                sfor<fmid, f1>([&](auto f_c) { filler<decltype(f_c)::value>(S[PAR], S[PAR ^ 1], pf, ls, mxp, mx); });
+                sfor<fmid, f1>([&](auto f_c) { filler<decltype(f_c)::value>(S[PAR], S[PAR ^ 1], pf, m00, m01, m10, m11, mx0, mx1); });
+                __builtin_amdgcn_s_waitcnt(0xc07f);        // V^T units 0-2
             }
             __builtin_amdgcn_sched_barrier(0);
         });
         // (5) does the running max have to move for tile kt + 1?  (deferred: only when a row would exceed it by more than 2^8)
         if constexpr (HAS_NEXT) {
-            if (__builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) > F2_DEFER) != 0) {       // wave-uniform, rare
+            if (__builtin_amdgcn_ballot_w64(fmaxf(mx0, mx1) > F2_DEFER) != 0) {       // wave-uniform, rare
                 float delta[2], alpha[2];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    delta[b] = fmaxf(mx[b], 0.f);
+                    delta[b] = fmaxf(b ? mx1 : mx0, 0.f);
                     alpha[b] = __builtin_amdgcn_exp2f(-delta[b]);
                     negm[b] -= delta[b];
-                    ls[b][0] *= alpha[b];
-                    ls[b][1] *= alpha[b];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         S[PAR ^ 1][b][0][i] -= delta[b];
@@ -405,7 +449,7 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
                     }
                 }
                 acc_scale_o<0>(alpha[0]);
-                acc_scale_o<1>(alpha[1]);
+                acc_scale_o<1>(alpha[1]);       // (ends in s_nop 1: the C tuples above are VALU-written MFMA sources)
             }
         }
     };
@@ -425,9 +469,7 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
     // ---- epilogue: O[q][d] = O^T[d][q] / l
     sfor<0, 2>([&](auto b_c) {
         constexpr int b = decltype(b_c)::value;
-        const float lsum = ls[b][0] + ls[b][1];
-        const float l_tot = lsum + __shfl_xor(lsum, 32);
-        const float inv = 1.0f / l_tot;
+        const float inv = 1.0f / acc_read_l<b>();         // both key halves of the row are in the MFMA row sum already
         f16v o[2];
         acc_read_o<2 * b>(o[0]);
         acc_read_o<2 * b + 1>(o[1]);
