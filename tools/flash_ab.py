@@ -14,27 +14,28 @@ for N, G, heads in shapes:
     qk[:, :C] *= (0.125 * ops.LOG2E)
     qk = qk.half()
     vt = torch.randn(C, G * N, device="cuda").half()
-    outs, times = {}, {1: [], 2: []}
-    for impl in (1, 2):
-        outs[impl] = torch.empty(G * N, C, device="cuda", dtype=torch.float16)
+    variants = {"v1": (1, 0), "v2": (2, 0)}       # name: (FLASH_IMPL, EXP1); with tools/_abl/libvcx_abl.so also "v2-mfma-sum": (2, 2)
+    outs, times = {}, {k: [] for k in variants}
+    for k in variants:
+        outs[k] = torch.empty(G * N, C, device="cuda", dtype=torch.float16)
 
-    def run(impl):
-        ops.flash_attn(qk, qk[:, C:], vt, outs[impl], n_groups=G, heads=heads, nq=N, nk=N, kv_rows=N, kv_div=1, ldq=2 * C, ldk=2 * C,
+    def run(k):
+        ops.flash_attn(qk, qk[:, C:], vt, outs[k], n_groups=G, heads=heads, nq=N, nk=N, kv_rows=N, kv_div=1, ldq=2 * C, ldk=2 * C,
                        ldvt=G * N, ldo=C, scale=0.125, log2_logits=True)
     for r in range(rounds):
-        for impl in (1, 2):
-            ops.tune_set("FLASH_IMPL", impl)
-            run(impl); torch.cuda.synchronize()
+        for k, (impl, e1) in variants.items():
+            ops.tune_set("FLASH_IMPL", impl); ops.tune_set("EXP1", e1)
+            run(k); torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            for _ in range(5): run(impl)
+            for _ in range(5): run(k)
             b.record(); torch.cuda.synchronize()
-            times[impl].append(a.elapsed_time(b) / 5)
-    ops.tune_set("FLASH_IMPL", 0)
+            times[k].append(a.elapsed_time(b) / 5)
+    ops.tune_set("FLASH_IMPL", 0); ops.tune_set("EXP1", 0)
     fl = 4.0 * G * heads * N * N * 64
-    d = (outs[1].float() - outs[2].float()).abs().max().item()
     row = f"N={N:5d} G={G} heads={heads:2d}: "
-    for impl in (1, 2):
-        t = sorted(times[impl]); med = t[len(t) // 2]
-        row += f"v{impl} {med:7.3f} ms (min {t[0]:7.3f}) {fl / med / 1e9:5.0f} TF/s   "
-    print(row + f"max |v1 - v2| = {d:.2e}  finite={bool(torch.isfinite(outs[2]).all())}", flush=True)
+    for k in variants:
+        t = sorted(times[k]); med = t[len(t) // 2]
+        d = (outs["v1"].float() - outs[k].float()).abs().max().item()
+        row += f"{k} {med:6.3f} ms (min {t[0]:6.3f}) {fl / med / 1e9:5.0f} TF/s d={d:.1e} | "
+    print(row, flush=True)

@@ -24,7 +24,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "viewcrafter_amd", "csrc", "attention_v2.hip")
-KERNEL = "flash2_d64_kernel"
+KERNELS = ("flash2_d64_kernelILi0ELi0E", "flash2_d64_kernelILi0ELi1E")      # <no ablation, row sums by MFMA | by VALU>
 MIN_MFMA_GAP = 16
 N_AGPR = 132
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -49,8 +49,8 @@ def vregs(tok, prefix="v"):
     return {int(m.group(1))} if m else set()
 
 
-def parse(listing):
-    body = listing[listing.index(next(l for l in listing.split("\n") if l.startswith("_Z") and KERNEL in l.split(":")[0] and ":" in l)):]
+def parse(listing, kernel):
+    body = listing[listing.index(next(l for l in listing.split("\n") if l.startswith("_Z") and kernel in l.split(":")[0] and ":" in l)):]
     body = body[:body.index(".Lfunc_end")]
     ins, in_asm = [], False
     for raw in body.split("\n")[1:]:
@@ -67,8 +67,12 @@ def parse(listing):
         op, _, rest = t.partition(" ")
         ops = [o.strip() for o in rest.split(",")] if rest else []
         ins.append(dict(op=op, ops=ops, asm=in_asm, text=t))
-    meta = {k: int(v) for k, v in re.findall(r"\.(agpr_count|vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)",
-                                              listing[listing.index("amdhsa.kernels"):])}
+    md = listing[listing.index("amdhsa.kernels"):]
+    at = md.index(kernel)                 # one YAML entry per kernel, keys in alphabetical order: .agpr_count ... .name ... .vgpr_count
+    start = md.rindex("- .agpr_count", 0, at)
+    end = md.find("- .agpr_count", at)
+    md = md[start:end if end > 0 else len(md)]
+    meta = {k: int(v) for k, v in re.findall(r"\.(agpr_count|vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", md)}
     return ins, meta
 
 
@@ -91,8 +95,8 @@ def wait_states(i):
     return int(i["ops"][0]) + 1 if i["op"] == "s_nop" and i["ops"] else 1
 
 
-def audit(listing):
-    ins, meta = parse(listing)
+def audit(listing, kernel=None):
+    ins, meta = parse(listing, kernel or KERNELS[0])
     problems = []
     arch = meta.get("vgpr_count", 0) - meta.get("agpr_count", 0)
     if meta.get("private_segment_fixed_size", 1) != 0 or meta.get("vgpr_spill_count", 1) != 0 or meta.get("sgpr_spill_count", 1) != 0:
@@ -155,13 +159,24 @@ def audit(listing):
     return problems, summary
 
 
+def audit_all(listing):
+    out = []
+    for k in KERNELS:
+        if k in listing:
+            problems, summary = audit(listing, k)
+            out.append((k, problems, summary))
+    return out
+
+
 def main():
-    problems, summary = audit(compile_listing(sys.argv[1] if len(sys.argv) > 1 else None))
-    print("flash2_d64_kernel:", summary)
-    for p in problems:
-        print("PROBLEM", p)
-    print("clean" if not problems else f"{len(problems)} problem(s)")
-    return 1 if problems else 0
+    bad = 0
+    for k, problems, summary in audit_all(compile_listing(sys.argv[1] if len(sys.argv) > 1 else None)):
+        print(k + ":", summary)
+        for p in problems:
+            print("PROBLEM", p)
+        bad += len(problems)
+    print("clean" if not bad else f"{bad} problem(s)")
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":

@@ -32,6 +32,12 @@
 //                 gaps 16-31  O += V^T(j) P(j)         | rest of tile j, DMA V^T(j+1), row maxima of tile j+1, max decision
 // (one barrier per tile: V^T(j), issued at mid(j-1), is complete for every wave behind mid(j) - not earlier - and K(j+2) too)
 // The loop is unrolled by two so that slot addresses and the two score-tile register sets are compile-time constants.
+//
+// Measured (MI355X, 50 frames x 5 heads x 9216^2, profiles/r03_flash_v2.md): 977 TF/s against 935 for the phased kernel on the same
+// box; timing-only ablations of the key loop (tools/flash_ablate.py) put the bare MFMA stream of a tile at 0.72 us = 1.49 PFLOP/s
+// - the matrix pipe issues back to back and the board's power cap sets the clock (~1.4 GHz) - and what is NOT hidden under it at
+// DMA issue 0.10 us, LDS fragment reads 0.07, softmax stream 0.2, barrier 0.03 per tile.  Row sums as 8 extra MFMAs per tile
+// (SUMV = 0: 64 fewer VALU instructions) lose 4 % to the plain adds: the pipe, not instruction issue, is the scarce resource.
 #include "flash2.h"
 #include <type_traits>
 
@@ -40,7 +46,8 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef unsigned u32;
 typedef u32 u4v __attribute__((ext_vector_type(4)));
-[[maybe_unused]] constexpr float F2_DEFER = 8.0f;          // log2 units, as FLASH_DEFER in attention.hip
+[[maybe_unused]] constexpr float F2_DEFER = 8.0f;
+#define F2_SUMV_DEFAULT 1                 // row sums: 0 = on the matrix pipe, 1 = v_add_f32 in the softmax stream          // log2 units, as FLASH_DEFER in attention.hip
 #define FI __device__ __forceinline__
 
 FI int tile_off2(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
@@ -185,51 +192,77 @@ FI float acc_read_l() {     // every element of L_B is the row sum of this lane'
 #define V_MAX2A(r, b) asm volatile("v_max_f32 %0, %0, %1" : "+v"(r) : "v"(b))
 #define V_MAX2I(r, a, b) asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b))
 
-constexpr int NF_PAIR = 28;               // one (key half, k-step) chunk of BOTH query blocks: 16 exp2, 8 packs, 4 half swaps
-constexpr int NF_EXP = 4 * NF_PAIR;       // 112
-constexpr int NF_ALL = NF_EXP + 32 + 4;   // + row maxima of the next tile (4 accumulators x 8, round-robin), 2 combines, 2 cross-half exchanges
-[[maybe_unused]] constexpr int NF_MID = 20;   // micro-operations issued as one burst behind the per-tile barrier (they cover the V^T fragment latency)
-constexpr int NGAP = 40;                  // MFMAs per tile: 16 score, 16 PV, 8 row-sum
+// ---- the softmax stream of one tile as a list of micro-operations (each one asm statement), in issue order
+template <int SUMV> struct Stream {
+    static constexpr int PAIR = SUMV ? 44 : 28;    // one (key half, k-step) chunk of BOTH query blocks: 16 exp2, [16 adds,] 8 packs, 4 half swaps
+    static constexpr int EXP = 4 * PAIR;
+    static constexpr int ALL = EXP + 32 + 2;       // + row maxima of the next tile (4 accumulators x 8, round-robin), 2 combines (this lane's half of the row)
+    static constexpr int MID = 20;                 // issued as one burst behind the per-tile barrier (covers the V^T fragment latency)
+    static constexpr int NGAP = SUMV ? 32 : 40;    // MFMAs per tile: 16 score, 16 PV [, 8 row-sum]
+    static constexpr int PVG = SUMV ? 4 : 6;       // gaps per k-step unit in the PV phase
+};
+#define V_ACC(acc, x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x))
 
 // One VALU micro-operation of the softmax stream.
-// F < 112, tile `cur`: chunk t = 2 kb + s holds this lane's scores of keys 16 t + 4 hi + {0..3} and 16 t + 8 + 4 hi + {0..3} (the
-// accumulator layout); exp2 in place, packing to fp16 words w0..w3, then v_permlane32_swap(w0, w2), (w1, w3) with the lane that
-// holds the other half of the query row: afterwards the lane owns P of keys 16 t + 8 hi + {0..7} - eight consecutive keys, the
-// plain B-operand layout, so that the matching V^T fragment is ONE 16-byte chunk (ds_read_b128, no two-piece gather).
-// Chunks come in the order the PV MFMAs consume them.  F >= 112: row maxima over tile `nxt`.
-template <int F>
-FI void filler(f16v (&cur)[2][2], f16v (&nxt)[2][2], u4v (&pf)[2][2][2], float& m00, float& m01, float& m10, float& m11, float& mx0, float& mx1) {
-    // (six separate scalars, not arrays: an array becomes one register tuple, and a write to one element of a tuple makes hipcc
-    // pad an s_nop in front of the next statement that touches any other element)
-    if constexpr (F < NF_EXP) {
-        constexpr int t = F / NF_PAIR, q = F % NF_PAIR, kb = t / 2, s = t % 2;
+// F < EXP, tile `cur`: chunk t = 2 kb + s holds this lane's scores of keys 16 t + 4 hi + {0..3} and 16 t + 8 + 4 hi + {0..3} (the
+// accumulator layout); exp2 in place, (row sums,) packing to fp16 words w0..w3, then v_permlane32_swap(w0, w2), (w1, w3) with the
+// lane that holds the other half of the query row: afterwards the lane owns P of keys 16 t + 8 hi + {0..7} - eight consecutive
+// keys, the plain B-operand layout, so that the matching V^T fragment is ONE 16-byte chunk (ds_read_b128, no two-piece gather).
+// Chunks come in the order the PV MFMAs consume them.  F >= EXP: row maxima over tile `nxt`.
+// (separate scalars, not arrays, for the maxima and sums: an array becomes one register tuple, and a write to one element of a
+// tuple makes hipcc pad an s_nop in front of the next statement that touches any other element)
+template <int F, int SUMV>
+FI void filler(f16v (&cur)[2][2], f16v (&nxt)[2][2], u4v (&pf)[2][2][2], float& m00, float& m01, float& m10, float& m11, float& mx0, float& mx1,
+               float& l00, float& l01, float& l10, float& l11) {
+    using ST = Stream<SUMV>;
+    if constexpr (F < ST::EXP) {
+        constexpr int t = F / ST::PAIR, q = F % ST::PAIR, kb = t / 2, s = t % 2;
         if constexpr (q < 16) {
             constexpr int b = q % 2, e = q / 2;
             V_EXP2(cur[b][kb][8 * s + e]);
-        } else if constexpr (q < 24) {
-            constexpr int idx = q - 16, b = idx % 2, grp = idx / 2;
-            V_PACK(pf[b][kb][s][grp], cur[b][kb][8 * s + 2 * grp], cur[b][kb][8 * s + 2 * grp + 1]);
+        } else if constexpr (q < ST::PAIR - 4) {
+            if constexpr (SUMV) {
+                constexpr int idx = q - 16, grp = idx / 6, w = idx % 6, b = w % 2;
+                if constexpr (w < 4) {
+                    constexpr int e = 2 * grp + w / 2;
+                    float& ll = b == 0 ? (w / 2 == 0 ? l00 : l01) : (w / 2 == 0 ? l10 : l11);
+                    V_ACC(ll, cur[b][kb][8 * s + e]);
+                } else {
+                    V_PACK(pf[b][kb][s][grp], cur[b][kb][8 * s + 2 * grp], cur[b][kb][8 * s + 2 * grp + 1]);
+                }
+            } else {
+                constexpr int idx = q - 16, b = idx % 2, grp = idx / 2;
+                V_PACK(pf[b][kb][s][grp], cur[b][kb][8 * s + 2 * grp], cur[b][kb][8 * s + 2 * grp + 1]);
+            }
         } else {
-            constexpr int idx = q - 24, b = idx % 2, which = idx / 2;
+            constexpr int idx = q - (ST::PAIR - 4), b = idx % 2, which = idx / 2;
             V_SWAP32(pf[b][kb][s][which], pf[b][kb][s][which + 2]);
         }
-    } else if constexpr (F < NF_EXP + 32) {
-        constexpr int m = F - NF_EXP, o = m / 4, acc = m % 4, kb = acc / 2, b = acc % 2;       // the four chains interleaved
+    } else if constexpr (F < ST::EXP + 32) {
+        constexpr int m = F - ST::EXP, o = m / 4, acc = m % 4, kb = acc / 2, b = acc % 2;       // the four chains interleaved
         float& mm = b == 0 ? (kb == 0 ? m00 : m01) : (kb == 0 ? m10 : m11);
         if constexpr (o == 0) V_MAX3I(mm, nxt[b][kb][0], nxt[b][kb][1], nxt[b][kb][2]);
         else if constexpr (o < 7) V_MAX3A(mm, nxt[b][kb][2 * o + 1], nxt[b][kb][2 * o + 2]);
         else V_MAX2A(mm, nxt[b][kb][15]);
-    } else if constexpr (F < NF_EXP + 34) {
-        if constexpr (F == NF_EXP + 32) V_MAX2I(mx0, m00, m01);
-        else V_MAX2I(mx1, m10, m11);
     } else {
-        float& mxb = F == NF_EXP + 34 ? mx0 : mx1;      // the other 32 keys of the row live in lane ^ 32: after the half swap t0 / t1
-        float t0 = mxb, t1 = mxb;                       // hold, in every lane, this lane's value and its partner's (in either order)
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t0), "+v"(t1));
-        V_MAX2I(mxb, t0, t1);
+        if constexpr (F == ST::EXP + 32) V_MAX2I(mx0, m00, m01);
+        else V_MAX2I(mx1, m10, m11);
     }
 }
+// The other 32 keys of a query row live in lane ^ 32: after the half swap t0 / t1 hold, in every lane, this lane's value and its
+// partner's (in either order).  Not part of the hot stream: whether ANY row of the wave exceeds the deferred-max threshold is
+// a ballot over the per-lane partial maxima; the exact row maximum is only needed once the (rare) rescale is taken.
+FI float row_max_across_halves(float m) {
+    float t0 = m, t1 = m, r;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(t0), "+v"(t1));
+    V_MAX2I(r, t0, t1);
+    return r;
+}
 
+// ABL: timing-only ablation bits (knob EXP0; 0 in production, anything else computes garbage): 1 no vmcnt wait at the barrier,
+// 2 no barrier, 4 no exp2, 8 no softmax stream at all, 16 no fragment reads in the loop, 32 no DMA in the loop, 64 no MFMAs
+// SUMV: row sums by v_add_f32 in the softmax stream (1) or by 8 extra MFMAs per tile (0)
+template <int ABL, int SUMV>
 __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // four distinct objects: slot s of K / V^T (see the header: compile-time slots keep the DMA waits exact)
@@ -320,6 +353,9 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
     f16v cinit[2];              // -running max of query block b in all 16 slots: C operand of a tile's first score MFMA
     u4v pf[2][2][2];            // packed fp16 probabilities [query block][key half][k-step] (8 halves = the B operand of a PV MFMA)
     float m00, m01, m10, m11, mx0, mx1;     // row maxima: partial (per score accumulator) and per query block
+    float l00 = 0.f, l01 = 0.f, l10 = 0.f, l11 = 0.f;      // SUMV: row sums, two partial accumulators per query block
+    using ST = Stream<SUMV>;
+    constexpr int NF_EXP = ST::EXP, NF_ALL = ST::ALL, NF_MID = ST::MID, NF_PAIR = ST::PAIR, NGAP = ST::NGAP, PVG = ST::PVG;
     float negm[2] = {0.f, 0.f};
 
     const int ntiles = p.nk >> 6;
@@ -347,10 +383,10 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
     if (ntiles > 2) dma_k(C0{}, 2);
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(S[0][0][0]), "+v"(S[0][0][1]), "+v"(S[0][1][0]), "+v"(S[0][1][1]));   // MFMA results -> VALU
     // first tile: the max moves to the row maximum itself (nothing is accumulated yet)
-    sfor<NF_EXP, NF_ALL>([&](auto f_c) { filler<decltype(f_c)::value>(S[1], S[0], pf, m00, m01, m10, m11, mx0, mx1); });
+    sfor<NF_EXP, NF_ALL>([&](auto f_c) { filler<decltype(f_c)::value, SUMV>(S[1], S[0], pf, m00, m01, m10, m11, mx0, mx1, l00, l01, l10, l11); });
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const float m = b ? mx1 : mx0;
+        const float m = row_max_across_halves(b ? mx1 : mx0);
         negm[b] = -m;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -379,55 +415,64 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
             // (0) fragments due in this group of gaps have arrived; request the next pair
             if constexpr (HAS_NEXT && gp < 16 && gp % 4 == 0) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
-                if constexpr (gp < 12) {
+                if constexpr (gp < 12 && !(ABL & 16)) {
                     read_k(cK, std::integral_constant<int, gp / 2 + 2>{});
                     read_k(cK, std::integral_constant<int, gp / 2 + 3>{});
                 }
             }
-            if constexpr (gp == 34) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);        // V^T unit 3 (requested at gap 22)
-                if constexpr (HAS_NEXT) {                  // K fragment units 0, 1 of tile kt + 2: five MFMAs ahead of the next step's gap 0
+            if constexpr (gp == 16 + 3 * PVG) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);        // V^T unit 3 (requested one unit after unit 0's last PV MFMA)
+                if constexpr (HAS_NEXT && !(ABL & 16)) {   // K fragment units 0, 1 of tile kt + 2: five MFMAs ahead of the next step's gap 0
                     read_k(nK, C0{});
                     read_k(nK, C1{});
                 }
             }
             // (1) the MFMA of this gap
-            if constexpr (gp < 16) {
+            if constexpr (ABL & 64) {
+            } else if constexpr (gp < 16) {
                 if constexpr (HAS_NEXT) {
                     constexpr int u = gp / 2, b = gp % 2, kb = u / 4, s = u % 4;
                     if constexpr (s == 0) mfma_qk_first<4 * b>(S[PAR ^ 1][b][kb], kf[u % 4], cinit[b]);
                     else mfma_qk_acc<4 * b + s>(S[PAR ^ 1][b][kb], kf[u % 4]);
                 }
             } else {
-                constexpr int t = (gp - 16) / 6, r = (gp - 16) % 6, kb = t / 2, s = t % 2;
+                constexpr int t = (gp - 16) / PVG, r = (gp - 16) % PVG, kb = t / 2, s = t % 2;
                 if constexpr (r < 4) mfma_pv<2 * (r % 2) + r / 2>(vf[t % 3][r / 2], pf[r % 2][kb][s]);
-                else mfma_rowsum<r - 4>(pf[r - 4][kb][s]);
+                else mfma_rowsum<r - 4>(pf[r - 4][kb][s]);          // (PVG = 6 only)
             }
             // (2) its share of the softmax stream (NF_MID of it runs as a burst behind the barrier, see (4))
             constexpr int NFG = NF - NF_MID;
-            constexpr int f0 = HAS_NEXT ? gp * NFG / NGAP + (gp >= 16 ? NF_MID : 0) : (gp < 16 ? gp * 7 : NF);
-            constexpr int f1 = HAS_NEXT ? (gp + 1) * NFG / NGAP + (gp >= 15 ? NF_MID : 0) : (gp < 16 ? (gp + 1) * 7 : NF);
+            constexpr int f0 = HAS_NEXT ? gp * NFG / NGAP + (gp >= 16 ? NF_MID : 0) : (gp < 16 ? gp * (NF_EXP / 16) : NF);
+            constexpr int f1 = HAS_NEXT ? (gp + 1) * NFG / NGAP + (gp >= 15 ? NF_MID : 0) : (gp < 16 ? (gp + 1) * (NF_EXP / 16) : NF);
             constexpr int fmid = HAS_NEXT ? f1 - NF_MID : f1;       // gap 15: [f0, fmid) before the barrier, [fmid, f1) behind it
-            sfor<f0, (gp == 15 ? fmid : f1)>([&](auto f_c) { filler<decltype(f_c)::value>(S[PAR], S[PAR ^ 1], pf, m00, m01, m10, m11, mx0, mx1); });
+            sfor<f0, (gp == 15 ? fmid : f1)>([&](auto f_c) {
+                constexpr int F = decltype(f_c)::value;
+                if constexpr (!(ABL & 8) && !((ABL & 4) && F < NF_EXP && F % NF_PAIR < 16)) filler<F, SUMV>(S[PAR], S[PAR ^ 1], pf, m00, m01, m10, m11, mx0, mx1, l00, l01, l10, l11);
+            });
             // (3) later requests
-            if constexpr (gp == 22) read_v(cV, std::integral_constant<int, 3>{});      // slot 0: unit 0's PV MFMAs are gaps 16-19
-            if constexpr (HAS_NEXT && gp == 18) dma_v(std::integral_constant<int, PAR ^ 1>{}, kt + 1);
+            if constexpr (gp == 16 + PVG && !(ABL & 16)) read_v(cV, std::integral_constant<int, 3>{});      // slot 0: unit 0's PV MFMAs are gaps 16-19
+            if constexpr (HAS_NEXT && gp == 18 && !(ABL & 32)) dma_v(std::integral_constant<int, PAR ^ 1>{}, kt + 1);
             // (4) between the two MFMA phases: everything this wave has in flight by DMA has landed, then all waves meet.  Only now
             // is V^T(kt) (issued one tile ago) complete for EVERY wave, so its fragments are requested here and a burst of the
             // softmax stream covers their LDS latency; K(kt + 1) is no longer read by anybody and V^T(kt - 1) neither: their
             // slots take K(kt + 3) (here) and V^T(kt + 1) (three gaps on, beside the MFMAs)
             if constexpr (gp == 15) {
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0x0f70);
-                __builtin_amdgcn_s_barrier();
-                read_v(cV, C0{});
-                read_v(cV, C1{});
-                read_v(cV, std::integral_constant<int, 2>{});
-                if constexpr (HAS_NEXT) {
+                if constexpr (!(ABL & 1)) __builtin_amdgcn_s_waitcnt(0x0f70);
+                if constexpr (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+                if constexpr (!(ABL & 16)) {
+                    read_v(cV, C0{});
+                    read_v(cV, C1{});
+                    read_v(cV, std::integral_constant<int, 2>{});
+                }
+                if constexpr (HAS_NEXT && !(ABL & 32)) {
                     if (kt + 3 < ntiles) dma_k(std::integral_constant<int, PAR ^ 1>{}, kt + 3);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                sfor<fmid, f1>([&](auto f_c) { filler<decltype(f_c)::value>(S[PAR], S[PAR ^ 1], pf, m00, m01, m10, m11, mx0, mx1); });
+                sfor<fmid, f1>([&](auto f_c) {
+                    constexpr int F = decltype(f_c)::value;
+                    if constexpr (!(ABL & 8) && !((ABL & 4) && F < NF_EXP && F % NF_PAIR < 16)) filler<F, SUMV>(S[PAR], S[PAR ^ 1], pf, m00, m01, m10, m11, mx0, mx1, l00, l01, l10, l11);
+                });
                 __builtin_amdgcn_s_waitcnt(0xc07f);        // V^T units 0-2
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -438,9 +483,13 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
                 float delta[2], alpha[2];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    delta[b] = fmaxf(b ? mx1 : mx0, 0.f);
+                    delta[b] = fmaxf(row_max_across_halves(b ? mx1 : mx0), 0.f);
                     alpha[b] = __builtin_amdgcn_exp2f(-delta[b]);
                     negm[b] -= delta[b];
+                    if constexpr (SUMV) {
+                        if (b == 0) { l00 *= alpha[0]; l01 *= alpha[0]; }
+                        else { l10 *= alpha[1]; l11 *= alpha[1]; }
+                    }
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         S[PAR ^ 1][b][0][i] -= delta[b];
@@ -469,7 +518,14 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
     // ---- epilogue: O[q][d] = O^T[d][q] / l
     sfor<0, 2>([&](auto b_c) {
         constexpr int b = decltype(b_c)::value;
-        const float inv = 1.0f / acc_read_l<b>();         // both key halves of the row are in the MFMA row sum already
+        float l_tot;
+        if constexpr (SUMV) {
+            const float lsum = b == 0 ? l00 + l01 : l10 + l11;
+            l_tot = lsum + __shfl_xor(lsum, 32);
+        } else {
+            l_tot = acc_read_l<b>();                       // both key halves of the row are in the MFMA row sum already
+        }
+        const float inv = 1.0f / l_tot;
         f16v o[2];
         acc_read_o<2 * b>(o[0]);
         acc_read_o<2 * b + 1>(o[1]);
@@ -492,6 +548,28 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
 
 int vcx_flash2_launch(const Flash2Args& a, hipStream_t s) {
     const int prob_pad = (a.nprob + 7) / 8 * 8;
-    hipLaunchKernelGGL(flash2_d64_kernel, dim3((unsigned)(a.nqb * prob_pad)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)(a.nqb * prob_pad));
+    const int abl = vcx_tune(VCX_TUNE_EXP0), sumv = vcx_tune(VCX_TUNE_EXP1);      // timing-only ablations / A-B (tools/flash_ab.py); 0, 0 = the product
+#define F2_LAUNCH(A, SV) hipLaunchKernelGGL((flash2_d64_kernel<A, SV>), grid, dim3(256), 0, s, a)
+    if (abl == 0 && sumv == 0) F2_LAUNCH(0, F2_SUMV_DEFAULT);
+#ifdef VCX_FLASH2_ABLATIONS
+    else if (abl == 0 && sumv == 1) F2_LAUNCH(0, 1);
+    else if (abl == 0 && sumv == 2) F2_LAUNCH(0, 0);
+    else if (abl == 1) F2_LAUNCH(1, F2_SUMV_DEFAULT);
+    else if (abl == 3) F2_LAUNCH(3, F2_SUMV_DEFAULT);
+    else if (abl == 4) F2_LAUNCH(4, F2_SUMV_DEFAULT);
+    else if (abl == 8) F2_LAUNCH(8, F2_SUMV_DEFAULT);
+    else if (abl == 16) F2_LAUNCH(16, F2_SUMV_DEFAULT);
+    else if (abl == 32) F2_LAUNCH(32, F2_SUMV_DEFAULT);
+    else if (abl == 35) F2_LAUNCH(35, F2_SUMV_DEFAULT);
+    else if (abl == 64) F2_LAUNCH(64, F2_SUMV_DEFAULT);
+    else if (abl == 72) F2_LAUNCH(72, F2_SUMV_DEFAULT);
+    else if (abl == 59) F2_LAUNCH(59, F2_SUMV_DEFAULT);
+#endif
+    else {
+        vcx_set_error("vcx_attn_flash_d64_f16(v2): variant EXP0=%d EXP1=%d is not compiled in (build with -DVCX_FLASH2_ABLATIONS)", abl, sumv);
+        return VCX_EINVAL;
+    }
+#undef F2_LAUNCH
     return vcx_check_launch("vcx_attn_flash_d64_f16(v2)");
 }
