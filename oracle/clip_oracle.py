@@ -17,8 +17,10 @@ What it restates, and how it is pinned:
   (open_clip's CLIP / VisionTransformer / ResidualAttentionBlock module tree and parameter names, built on
   torch.nn.MultiheadAttention exactly as open_clip does; kornia's "gaussian blur with sigma = (factor - 1) / 2, kernel
   2 * 2 * sigma made odd, reflect border, then F.interpolate(bicubic, align_corners=True)") and serve as the stand-ins the
-  golden generator installs under those module names.  PARITY UNPINNED for these two restatements: no golden vector of
-  the real packages can be produced here.
+  golden generator installs under those module names.  No golden vector of the real packages can be produced here; the tower
+  internals (clip_text_forward, clip_image_tower) are pinned instead to an INDEPENDENT third-party implementation of the same
+  architecture that is in the image: transformers' CLIPTextModel / CLIPVisionModel (oracle/clip_hf.py,
+  tests/test_oracle_golden.py::test_clip_towers_match_transformers).  The kornia resize restatement stays PARITY UNPINNED.
 """
 import math
 from collections import OrderedDict
@@ -187,10 +189,16 @@ def clip_text_forward(sd, tokens, heads, layers, layer_idx=1):
 
 def clip_image_forward(sd, img, heads, layers, patch, antialias=True):
     """condition.py:325-378: img [B, 3, H, W] in [-1, 1] -> [B, grid^2 + 1, width] (tokens after the last block, no ln_post)."""
-    sd = {k: v.float() for k, v in sd.items()}
     x = kornia_resize(img.float(), (224, 224), antialias)
     x = kornia_normalize((x + 1.0) / 2.0, CLIP_MEAN, CLIP_STD)
-    x = F.conv2d(x, sd["model.visual.conv1.weight"], stride=patch)
+    return clip_image_tower(sd, x, heads, layers, patch)
+
+
+def clip_image_tower(sd, x, heads, layers, patch):
+    """The vision tower proper on pre-processed pixels [B, 3, S, S] (open_clip VisionTransformer.forward up to and including
+    the last residual block; checked against transformers' independent CLIPVisionModel in oracle/clip_hf.py)."""
+    sd = {k: v.float() for k, v in sd.items()}
+    x = F.conv2d(x.float(), sd["model.visual.conv1.weight"], stride=patch)
     x = x.flatten(2).transpose(1, 2)                                   # [B, grid^2, width]
     cls = sd["model.visual.class_embedding"].expand(x.shape[0], 1, -1)
     x = torch.cat([cls, x], 1) + sd["model.visual.positional_embedding"]

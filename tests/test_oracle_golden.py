@@ -181,3 +181,30 @@ def test_clip_encoders_oracle_matches_reference():
         y = C.clip_image_forward(sd, x, v["width"] // v["head_width"], v["layers"], v["patch_size"])
         assert y.shape == g[f"clip_image_{tag}"].shape
         assert max_rel(y.numpy(), g[f"clip_image_{tag}"]) <= 2e-5, tag
+
+
+def test_clip_towers_match_transformers():
+    """Third-party pin of the OpenCLIP tower internals: Hugging Face transformers ships an independent
+    implementation of the CLIP architecture; its random-initialised towers, with their parameters renamed to open_clip's
+    state-dict names (oracle/clip_hf.py), must agree with the oracle's restatement at the points the reference taps: the text
+    tower at layer 'penultimate' through ln_final (condition.py:218-237) and the vision tower's token stream after the last block
+    (condition.py:347-378)."""
+    pytest.importorskip("transformers")
+    from oracle import clip_hf as H
+    from oracle import clip_oracle as C
+    t, v = H.HF_TINY_CFG["text"], H.HF_TINY_CFG["vision"]
+    tm, tsd = H.build_text()
+    g = torch.Generator().manual_seed(3)
+    tokens = torch.randint(2, t["vocab_size"], (3, 77), generator=g)
+    tokens[:, 0] = 0
+    ref = H.hf_text_penultimate(tm, tokens)
+    y = C.clip_text_forward(tsd, tokens, t["heads"], t["layers"], layer_idx=1)
+    assert max_rel(y.numpy(), ref.numpy()) <= 2e-5
+    y_last = C.clip_text_forward(tsd, tokens, t["heads"], t["layers"], layer_idx=0)       # layer='last' differs: the tap is real
+    assert max_rel(y_last.numpy(), ref.numpy()) > 1e-2
+    vm, vsd = H.build_vision()
+    x = torch.randn(2, 3, 224, 224, generator=g)
+    ref = H.hf_vision_tokens(vm, x)
+    y = C.clip_image_tower(vsd, x, v["width"] // v["head_width"], v["layers"], v["patch_size"])
+    assert y.shape == ref.shape == (2, 17, v["width"])
+    assert max_rel(y.numpy(), ref.numpy()) <= 2e-5
