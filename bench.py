@@ -66,24 +66,44 @@ def synth_conditioning(T, h, w, device, seed=123, B=1):
     return x_T.to(device), cond, uc
 
 
-def cpu_baseline(model, hp, flops_per_step_full, budget_s=75.0):
-    """The fp32 oracle (oracle/lvdm_oracle.py, a port of the reference algorithm) timed on the host cores for one UNet forward
-    at BASELINE configs[0]'s shapes (16 frames, 40x64 latent, the full 1.44 B-parameter width), after a
-    warm-up call; one DDIM step = 2 forwards; FLOP-scaled to the bench workload (labelled extrapolated).  The same 16 frames
-    at 24x40 are timed first; a host too slow for the 40x64 call within `budget_s` (predicted from that run) reports those.  Only this function, the
-    two legs below and nothing in the timed region touch oracle/."""
+def cpu_baseline(model, hp, dd, flops_per_step_full, budget_s=75.0):
+    """The reference's own code on the host cores: `UNetModel.forward` (openaimodel3d.py:548-603) fp32 at BASELINE
+    configs[0]'s shapes (16 frames, 40x64 latent, the full 1.44 B-parameter width), after a warm-up call; one DDIM step = 2
+    forwards; FLOP-scaled to the bench workload (labelled extrapolated) - and one `AutoencoderKL.decode` of a 40x64 latent
+    (320x512 frame).  The code that runs is the reference's, imported from oracle/_ref/ (bytecode compiled from /root/reference by
+    oracle/build_ref.py at build time: `"kind": "reference"`); if that tree is missing the oracle restatement is timed instead
+    (`"kind": "port"`).  The same 16 frames at 24x40 are timed first; a host too slow for the 40x64 call within `budget_s`
+    (predicted from that run) reports those.  Only this function, gpu_legs() below and nothing in the timed region touch oracle/."""
     from oracle import lvdm_oracle as O
+    from oracle import ref_runner as R
     unet = model.model.diffusion_model
     sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    vsd = {k: v.detach().float().cpu() for k, v in model.first_stage_model.state_dict().items()}
     g = torch.Generator().manual_seed(7)
     ts, fs = torch.tensor([499]), torch.tensor([10])
+    kind = "reference" if R.available() else "port"
+    if kind == "reference":
+        ref_unet = R.reference_unet(hp, sd)
+        ref_vae = R.reference_vae(dd, state_dict=vsd)
+
+        def forward(x, ctx):
+            return ref_unet(x, ts, context=ctx, fs=fs)
+
+        def decode(z):
+            return ref_vae.decode(z)
+    else:
+        def forward(x, ctx):
+            return O.unet_forward(sd, hp, x, ts, ctx, fs)
+
+        def decode(z):
+            return O.vae_decode(vsd, dd, z)
 
     def run(T, h, w):
         x = torch.randn(1, 8, T, h, w, generator=g)
         ctx = torch.randn(1, 77 + 256, 1024, generator=g)
         t0 = time.perf_counter()
         with torch.no_grad():
-            y = O.unet_forward(sd, hp, x, ts, ctx, fs)
+            y = forward(x, ctx)
         assert torch.isfinite(y).all()
         return time.perf_counter() - t0
     run(2, 8, 8)                                         # threads, allocator, oneDNN primitives
@@ -95,11 +115,21 @@ def cpu_baseline(model, hp, flops_per_step_full, budget_s=75.0):
     flops = UNET_TFLOP.get((T, h, w))
     step_s = 2.0 * dt
     scale = flops_per_step_full / (2.0 * flops * 1e12) if flops else None
-    return dict(value=(1.0 / (step_s * scale)) if scale else None, unit="DDIM steps/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"fp32 oracle UNet forward on the host, full 1.44B-param width, latent {T}x{h}x{w} (BASELINE configs[0] shapes"
+    with torch.no_grad():
+        decode(torch.randn(1, 4, 8, 8, generator=g))     # warm-up
+        z = torch.randn(1, 4, 40, 64, generator=g) / 0.18215
+        t0 = time.perf_counter()
+        frame = decode(z)
+        dec_s = time.perf_counter() - t0
+    assert frame.shape == (1, 3, 320, 512) and torch.isfinite(frame).all()
+    what = ("the reference's own UNetModel.forward / AutoencoderKL.decode (oracle/_ref: bytecode of /root/reference's lvdm, compiled at build time)"
+            if kind == "reference" else "fp32 oracle restatement (oracle/_ref not built)")
+    return dict(value=(1.0 / (step_s * scale)) if scale else None, unit="DDIM steps/s", cores=torch.get_num_threads(), kind=kind,
+                sample=f"{what} on the host, full 1.44B-param width, latent {T}x{h}x{w} (BASELINE configs[0] shapes"
                        f"{'' if (h, w) == (40, 64) else ' reduced to fit the time budget'}): {dt:.1f} s/forward = {step_s:.1f} s per DDIM "
-                       f"step there ({flops} TFLOP/forward) -> x{scale:.1f} FLOP-scaled to the bench workload (extrapolated)",
-                sec_per_step_at_sample=step_s, sample_latent=[T, h, w])
+                       f"step there ({flops} TFLOP/forward) -> x{scale:.1f} FLOP-scaled to the bench workload (extrapolated); "
+                       f"VAE decode of one 320x512 frame (1.564 TFLOP): {dec_s:.2f} s",
+                sec_per_step_at_sample=step_s, sample_latent=[T, h, w], vae_decode_s_per_frame=dec_s, vae_decode_frame=[320, 512])
 
 
 # UNet forward TFLOP of the reference graph by latent (torch.utils.flop_counter on meta tensors; 16x24x40
@@ -510,7 +540,7 @@ def main():
         if gather_s is not None:
             out["gather_s"] = gather_s
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, hp, flops_per_step)
+            out["cpu_baseline"] = cpu_baseline(model, hp, dict(mp_["first_stage_config"]["params"]["ddconfig"]), flops_per_step)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -208,3 +208,33 @@ def test_clip_towers_match_transformers():
     y = C.clip_image_tower(vsd, x, v["width"] // v["head_width"], v["layers"], v["patch_size"])
     assert y.shape == ref.shape == (2, 17, v["width"])
     assert max_rel(y.numpy(), ref.numpy()) <= 2e-5
+
+
+def test_oracle_matches_the_reference_code_itself_when_oracle_ref_is_built():
+    """oracle/_ref (oracle/build_ref.py: bytecode of the reference's own modules) run next to the oracle restatement on fresh
+    inputs and the deterministic synthetic weights: UNet forward (both image-token branches) and VAE decode / encode.  This is
+    the same check the committed goldens make, but on the code itself, wherever the _ref tree travelled to."""
+    from oracle import ref_runner as R
+    if not R.available():
+        pytest.skip("oracle/_ref not built (python oracle/build_ref.py needs /root/reference)")
+    from oracle.weights import synth_state_dict
+    from tests.tiny_config import TINY_DDCONFIG, TINY_UNET
+    ref = R.reference_unet(TINY_UNET)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, seed=0)
+    ref.load_state_dict(sd, strict=True)
+    for T, L in ((4, 77 + 64), (3, 77 + 256)):            # per-frame image tokens (77 + 16 T) / shared ones
+        x = synth_input(f"ref_x_{T}", (1, 8, T, 16, 16))
+        ctx = synth_input(f"ref_ctx_{T}", (1, L, TINY_UNET["context_dim"]))
+        ts, fs = torch.tensor([640]), torch.tensor([12])
+        with torch.no_grad():
+            want = ref(x, ts, context=ctx, fs=fs)
+            got = O.unet_forward(sd, TINY_UNET, x, ts, ctx, fs)
+        assert max_rel(got.numpy(), want.numpy()) <= 2e-5, T
+    vae = R.reference_vae(TINY_DDCONFIG)
+    vsd = synth_state_dict({k: tuple(v.shape) for k, v in vae.state_dict().items()}, seed=0)
+    vae.load_state_dict(vsd, strict=True)
+    z = synth_input("ref_z", (2, 4, 8, 16))
+    img = synth_input("ref_img", (1, 3, 64, 32), scale=0.5)
+    with torch.no_grad():
+        assert max_rel(O.vae_decode(vsd, TINY_DDCONFIG, z).numpy(), vae.decode(z).numpy()) <= 2e-5
+        assert max_rel(O.vae_encode_moments(vsd, TINY_DDCONFIG, img).numpy(), vae.encode(img).parameters.numpy()) <= 2e-5
