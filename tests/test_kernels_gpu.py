@@ -637,6 +637,29 @@ def test_gelu_f16_exact_erf():
     check(y, ref, tol=1e-3, name="gelu")
 
 
+def test_gelu_every_fp16_input_rounds_like_the_fp64_erf_form():
+    """The exp2-of-a-polynomial normal tail behind gelu_erf (csrc/gemm_args.h; also the GEGLU epilogue): ALL 63488 finite fp16
+    inputs against x Phi(x) evaluated in fp64.  The fp32 result is within 2e-6 absolute of the exact value, so the fp16 output may
+    differ from the correctly rounded one by at most one unit in the last place, and only where the exact value sits at a
+    rounding boundary."""
+    from viewcrafter_amd import ops
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(torch.float16)
+    x = x[torch.isfinite(x)]
+    pad = (-x.numel()) % 8
+    xin = torch.cat([x, torch.zeros(pad, dtype=torch.float16)]).to(DEV)
+    y = ops.gelu_(xin.clone())[:x.numel()].cpu()
+    xd = x.double()
+    exact = 0.5 * xd * (1.0 + torch.erf(xd / 2.0 ** 0.5))
+    want = exact.half()                       # correctly rounded
+    assert torch.isfinite(y).all()
+    ulp = torch.maximum(want.float().abs(), torch.tensor(6.1e-5)) * 2.0 ** -10        # one fp16 ulp at the result's magnitude (normal range)
+    err = (y.double() - exact).abs()
+    assert float((err / ulp.double()).max()) <= 1.01, float((err / ulp.double()).max())
+    assert float((y != want).float().mean()) < 0.02           # a handful of boundary cases at most
+    assert float(err.max()) < 20.0                            # the largest outputs (x = 65504) are exact to an ulp too
+
+
 def test_stale_not_ready_status_is_not_a_launch_failure():
     """hipEventQuery on a pending event leaves hipErrorNotReady as the thread's last error (the host framework's allocator polls
     events like this); the next libvcx launch must not report it as its own failure."""

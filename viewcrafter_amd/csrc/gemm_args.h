@@ -33,8 +33,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-// exact-erf GELU (F.gelu default) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the fp16 output
-// rounding): ~14 VALU ops instead of libm erff's ~40 — the GEGLU epilogue otherwise costs as much as a K=320 main loop.
+// exact-erf GELU (F.gelu default): gelu(x) = x Phi(x) with the normal tail Phi(-|x|) = exp2(q(|x|)), q a degree-6 polynomial.
+// log2 of the Gaussian tail is almost a parabola, so six Horner steps reproduce it on [0, 9] (weighted minimax fit against
+// scipy's erfc; beyond 9 the tail is < 1e-19 and |x| is clamped): evaluated in fp32, max |gelu error| is 3.7e-7 over EVERY finite
+// fp16 input and the fp16 result is within one unit in the last place of the correctly rounded value everywhere
+// (tests/test_kernels_gpu.py::test_gelu_every_fp16_input...) - the accuracy of the Abramowitz-Stegun 7.1.26 form used in rounds
+// 1-2 (4.5e-7), with ONE transcendental (v_exp) instead of two (v_rcp + v_exp), 10 instead of 14 VALU operations and no
+// reciprocal at the head of the dependent chain.  The GEGLU epilogue runs this once per output element and was 28 % of the
+// level-0 GEGLU layer (profiles/r02_experiments.md section 9); same-box effect: GEGLU layers -4 ... -6 % (profiles/r03_experiments.md).
+#ifdef VCX_GELU_AS7126      // the round 1-2 form, kept for the A/B build of tools/gelu_ab.py only
 __device__ __forceinline__ float gelu_erf(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
@@ -42,6 +49,20 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erf(|x|/sqrt2)
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
+#else
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float a = fminf(fabsf(x), 9.0f);
+    float q = 3.3093042e-05f;
+    q = __builtin_fmaf(q, a, -7.6922239e-04f);
+    q = __builtin_fmaf(q, a, 8.0807274e-03f);
+    q = __builtin_fmaf(q, a, -5.3412125e-02f);
+    q = __builtin_fmaf(q, a, -4.5877096e-01f);
+    q = __builtin_fmaf(q, a, -1.1512017e+00f);
+    q = __builtin_fmaf(q, a, -9.9999309e-01f);
+    const float e = __builtin_amdgcn_exp2f(q);          // Phi(-|x|)
+    return x * (x > 0.f ? 1.0f - e : e);
+}
+#endif
 
 
 // XCD-aware persistent tile walk: tile ids congruent mod 8 form a contiguous band of (tile_m, tile_n).
