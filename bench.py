@@ -445,13 +445,13 @@ def main():
         ftraffic = None       # same rule as above: only a number measured on the attention kernels as they are now, on this workload
         try:
             ff = tr["families"]["flash_attn"]
-            if args.workload == tr.get("workload") and tr.get("attention_sha256") == csrc_hash(("attention.hip",)):
+            if args.workload == tr.get("workload") and tr.get("attention_sha256") == csrc_hash(("attention.hip", "attention_v2.hip")):
                 ftraffic = ff["hbm_bytes_per_launch"]
         except Exception:
             pass
         out["roofline_flash"] = {"bound": "mfma", "achieved": fach, "peak": MI355X_FP16_DENSE_TFLOPS, "unit": "TFLOP/s",
                                  "frac": fach / MI355X_FP16_DENSE_TFLOPS, "traffic": ftraffic,
-                                 "kernel": "flash_d64_kernel<2,...> / xattn_resident_d64_kernel (csrc/attention.hip); FLOP = 4 N_q N_k d per head",
+                                 "kernel": "flash2_d64_kernel (csrc/attention_v2.hip, 9216-key self-attention) / flash_d64_kernel<2,...> / xattn_resident_d64_kernel (csrc/attention.hip); FLOP = 4 N_q N_k d per head",
                                  "launches_per_step": fl["launches"] / args.steps, "avg_launch_ms": fl["ms"] / max(fl["launches"], 1),
                                  "algorithmic_tflop_per_launch_avg": fl["flops"] / max(fl["launches"], 1) / 1e12,
                                  "algorithmic_bytes_per_launch_avg": fl["bytes"] / max(fl["launches"], 1)}

@@ -22,7 +22,7 @@ def per_kernel(path, counter):
     return {k: (n, v) for k, n, v in db.execute(q)}
 
 
-fam = lambda k: ("gemm" if "gemm_" in k else "flash_attn" if ("flash_d64" in k or "xattn_resident" in k) else "temporal_attn" if "tattn" in k else
+fam = lambda k: ("gemm" if "gemm_" in k else "flash_attn" if ("flash_d64" in k or "flash2_d64" in k or "xattn_resident" in k) else "temporal_attn" if "tattn" in k else
                  "groupnorm" if "gn_" in k else "layernorm" if "layernorm" in k else None)
 f = per_kernel(a.fetch_db, "FETCH_SIZE")
 w = per_kernel(a.write_db, "WRITE_SIZE")
@@ -48,7 +48,10 @@ if a.json:
     h = hashlib.sha256()
     for name in ("gemm_dma.hip", "gemm.hip", "gemm_args.h"):
         h.update(open(os.path.join(root, "viewcrafter_amd", "csrc", name), "rb").read())
-    ha = hashlib.sha256(open(os.path.join(root, "viewcrafter_amd", "csrc", "attention.hip"), "rb").read()).hexdigest()
+    hh = hashlib.sha256()
+    for name in ("attention.hip", "attention_v2.hip"):
+        hh.update(open(os.path.join(root, "viewcrafter_amd", "csrc", name), "rb").read())
+    ha = hh.hexdigest()
     n, r, wr = agg["gemm"]
     out = {"family": "gemm", "hbm_bytes_per_launch": (r + wr) / a.gemm_calls_per_step, "hbm_read_gb_per_step": r / 1e9,
            "hbm_write_gb_per_step": wr / 1e9, "kernel_dispatches_per_step": n, "launches_per_step": a.gemm_calls_per_step,
