@@ -475,12 +475,12 @@ def test_batched_posterior_noise_is_the_per_frame_stream():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The newest committed bench line (profiles/r02*_bench.json, written by `python bench.py` on an MI355X) has every field of the
+    """The newest committed bench line (profiles/r0N*_bench.json, written by `python bench.py` on an MI355X) has every field of the
     bench contract with consistent values: value = n_gpus * steps / elapsed, roofline.frac = achieved / peak, inputs HBM-resident
     synthetic data, a bounded CPU sample."""
     import glob
     import json
-    paths = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r02*_bench.json")) if "ViewCrafter" not in os.path.basename(p))
+    paths = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]*_bench.json")) if "ViewCrafter" not in os.path.basename(p))
     assert paths
     d = json.loads(open(paths[-1]).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -495,6 +495,21 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert 3.0 < d["value"] < 8.0           # 576x1024x25 on one MI355X: the measured range of this code base
+    assert c["kind"] == "reference" and c["vae_decode_s_per_frame"] > 0      # round 3: the reference's own code, with a VAE leg
+
+
+def test_readme_and_design_quote_the_drivers_bench_record():
+    """The headline in README.md / DESIGN.md is the DRIVER's measurement, not the builder's best box: both name a BENCH_rNN.json
+    and quote its value and ms_per_step to the printed precision."""
+    import json
+    import re
+    for doc in ("README.md", "DESIGN.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        m = re.search(r"(BENCH_r\d+\.json)`?\)?[:,]?\s*\**([0-9.]+) DDIM steps/s(?: =|,) ([0-9.]+) ms/step", text)
+        assert m, f"{doc}: no 'BENCH_rNN.json ... X DDIM steps/s ... Y ms/step' line"
+        rec = json.load(open(os.path.join(ROOT, m.group(1))))["parsed"]
+        assert abs(rec["value"] - float(m.group(2))) < 0.006, (doc, m.group(0), rec["value"])
+        assert abs(rec["ms_per_step"] - float(m.group(3))) < 0.06, (doc, m.group(0), rec["ms_per_step"])
 
 
 @pytest.mark.parametrize("name", ["inference_pvd_1024", "inference_pvd_512"])
