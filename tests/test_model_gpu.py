@@ -83,6 +83,28 @@ def test_unet_forward_vs_oracle_fresh_inputs_and_cfg_batching(unet):
     assert torch.equal(m(x, ts, context=ctx, fs=fs), y), "forward is not run-to-run reproducible"
     
 
+@pytest.mark.parametrize("h,w", [(24, 40), (8, 24)])
+def test_unet_forward_at_sizes_whose_token_counts_are_not_multiples_of_8(unet, h, w):
+    """--height / --width are free CLI flags of the reference (configs/infer_config.py:33-34).  At 192x320 (latent 24x40) the two
+    deepest levels have 6x10 = 60 and 3x5 = 15 tokens per frame, at 64x192 the deepest has 3: the attention kernels address keys
+    at 16-byte granularity, so SpatialTransformer pads each frame's token rows to a multiple of 8 for the length of the block.
+    Against the fp32 oracle, with the shared CFG prefix on top (replicated padded streams)."""
+    m, sd = unet
+    b, t, L = 1, 3, 77 + 48
+    x = synth_input(f"odd_x_{h}", (b, 8, t, h, w)).to(DEV)
+    ctx = synth_input(f"odd_ctx_{h}", (2, L, TINY_UNET["context_dim"])).to(DEV)
+    ts, fs = torch.tensor([459], device=DEV), torch.tensor([10], device=DEV)
+    with torch.no_grad():
+        y = m(x, ts, context=ctx[:1].contiguous(), fs=fs)
+        y2 = m(x, ts, context=ctx, fs=fs, cfg_repeat=2)
+        ref = O.unet_forward({k: v for k, v in sd.items()}, TINY_UNET, x.cpu(), ts.cpu(), ctx[:1].cpu(), fs.cpu())
+    assert torch.isfinite(y).all()
+    e = rel_l2(y, ref)
+    print(f"unet at latent {h}x{w} (padded token rows): rel-L2 vs oracle = {e:.3e}")
+    assert e <= UNET_TOL
+    assert torch.equal(y2[:1], y)                    # the shared-prefix path pads and replicates consistently
+
+
 @pytest.mark.parametrize("r,t,L", [(2, 4, 77 + 64), (2, 3, 77 + 40), (3, 5, 77 + 24)])
 def test_cfg_shared_prefix_is_bit_identical(unet, r, t, L):
     """Classifier-free guidance evaluates the denoiser on the same x / t / fs under r conditionings.  With cfg_repeat = r the

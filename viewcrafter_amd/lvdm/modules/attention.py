@@ -227,13 +227,22 @@ class SpatialTransformer(PackedModule):
         token stream is replicated r times right before the first cross-attention (context_kv holds r * b videos).  The
         result [r * n, H, W, C] equals the forward of the r-fold replicated input bit for bit."""
         n, H, W, C = x.shape
-        N = H * W
-        if N % 8 != 0:
-            raise ValueError(f"spatial attention needs h*w % 8 == 0 (got {H}x{W})")
+        N_img = H * W
         pk = self.packed()
+        a = ops.group_norm(x.view(n, N_img, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False)
+        # The attention kernels address a frame's keys / values at 16-byte granularity: h*w must be a multiple of 8.  It is at every
+        # level of 576x1024 and 320x512; for other --height / --width (e.g. 384x640: 6x10 = 60 tokens at the deepest level) each
+        # frame's token rows are padded with zero rows up to the next multiple of 8 for the length of this block - all its layers
+        # are row-wise except the attentions, which take nq = padded rows (results of pad rows are dropped) and nk = real keys.
+        N = (N_img + 7) // 8 * 8
+        xin = x.reshape(n * N_img, C)
+        if N != N_img:
+            def pad_frames(src):
+                dst = torch.zeros((n * N, C), dtype=torch.float16, device=x.device)
+                ops.copy2d(src, dst, n, N_img * C, N_img * C, N * C)           # one "row" per frame
+                return dst
+            xin, a = pad_frames(xin), pad_frames(a.view(n * N_img, C))
         tokens = n * N
-        xin = x.reshape(tokens, C)
-        a = ops.group_norm(x.view(n, N, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False)
         t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
         D, heads = t.shape[1], self.n_heads
         for bi, (blk, kv) in enumerate(zip(self.transformer_blocks, context_kv)):
@@ -246,7 +255,7 @@ class SpatialTransformer(PackedModule):
             qk = ops.linear(h1, a1["wqk"], alpha=math.sqrt(blk.attn1.scale * ops.LOG2E))   # [tokens, 2D]
             vt = ops.gemm(a1["wv"], h1, M=D, N=tokens, K=D, lda=D)                   # [D, tokens]
             o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
-            ops.flash_attn(qk, qk[:, D:], vt, o, n_groups=n, heads=heads, nq=N, nk=N, kv_rows=N, kv_div=1, ldq=2 * D,
+            ops.flash_attn(qk, qk[:, D:], vt, o, n_groups=n, heads=heads, nq=N, nk=N_img, kv_rows=N, kv_div=1, ldq=2 * D,
                            ldk=2 * D, ldvt=tokens, ldo=D, scale=blk.attn1.scale, log2_logits=True)
             t = ops.linear(o, a1["wo"], a1["bo"], residual=t)
             # ---- cross-attention: softmax(Q K_txt) V_txt + softmax(Q K_img) V_img
@@ -270,6 +279,10 @@ class SpatialTransformer(PackedModule):
             # ---- feed-forward
             t = blk.ff.run(ops.layer_norm(t, *ln[2]), t)
         out = ops.linear(t, pk["wout"], pk["bout"], residual=xin)
+        if N != N_img:
+            unpadded = torch.empty((n * N_img, C), dtype=torch.float16, device=x.device)
+            ops.copy2d(out, unpadded, n, N_img * C, N * C, N_img * C)
+            out = unpadded
         return out.view(n, H, W, C)
 
 
