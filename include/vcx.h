@@ -131,6 +131,10 @@ int vcx_layernorm_f16(const void* x, void* y, const float* gamma, const float* b
  * scale * log2(e) into Q and/or K (e.g. as the alpha of the projection GEMM), so that
  * Q K^T is already the base-2 logit - `scale` is then ignored and the kernel saves one
  * multiply-add per score.
+ * Two kernels sit behind this entry point: with VCX_ATTN_LOG2_LOGITS, nk a multiple of 64,
+ * nk >= 4096 and no VCX_ATTN_ACCUMULATE the software-pipelined one-wave-per-SIMD kernel
+ * (csrc/attention_v2.hip), otherwise the phased kernel (csrc/attention.hip); same contract,
+ * results agree to fp16 rounding (different summation order).  Knob VCX_TUNE_FLASH_IMPL.
  * ---------------------------------------------------------------------------------- */
 #define VCX_ATTN_ACCUMULATE 1
 #define VCX_ATTN_LOG2_LOGITS 2
