@@ -15,9 +15,10 @@ checkpoints offline), data is synthetic of the real shapes; inputs are resident 
 
 Printed JSON (rank 0): the driver contract + `roofline` (dominant kernel = the MFMA GEMM/conv engine, measured with HIP
 events on the launch stream over the timed region) + `roofline_flash` (second family, same method) + `cpu_baseline` (the
-fp32 oracle = a port of the reference's algorithm, timed on the host cores at BASELINE configs[0]'s shapes 16x40x64 and
-FLOP-scaled) + `gpu_eager_baseline` (the same oracle graph as plain PyTorch-ROCm eager ops under fp16 autocast on this
-MI355X: what the hand-written kernels buy over the libraries) + `parity` (HIP path vs the fp32 oracle run on the GPU at the
+reference's own code from oracle/_ref - or, if that tree is not built, the fp32 oracle port - timed on the host cores at
+BASELINE configs[0]'s shapes 16x40x64 and FLOP-scaled) + `gpu_eager_baseline` (the reference's own UNetModel.forward, or
+the oracle graph, as plain PyTorch-ROCm eager ops under fp16 autocast on this MI355X: what the hand-written kernels buy
+over the libraries) + `parity` (HIP path vs the fp32 oracle run on the GPU at the
 bench's own latent) + `sec_per_video` (a real 50-step sample() + 25-frame decode after the timed region, N = 1).
 N > 1: rank 0 initialises the weights, the others receive them by RCCL broadcast (`broadcast_s`), all ranks assert equal
 checksums, and the decoded clips are gathered on rank 0 (`gather_s`) - both outside the timed region.
@@ -139,8 +140,8 @@ UNET_TFLOP = {(25, 72, 128): 82.761, (16, 72, 128): 52.336, (25, 40, 64): 20.187
 
 def gpu_legs(model, hp, dd, T, h, w, device, x, ts, ctx, fs, z_dec):
     """On the MI355X, outside the timed region: (a) parity of the HIP path against the fp32 oracle at the bench's own
-    latent (UNet forward; VAE decode of 2 frames), (b) the oracle graph as PyTorch eager ops under fp16 autocast =
-    the un-accelerated same-GPU baseline (hipBLASLt / rocBLAS / MIOpen kernels, vanilla attention, NCHW)."""
+    latent (UNet forward; VAE decode of 2 frames), (b) the reference's own UNetModel (oracle/_ref; the oracle graph if that is missing) as PyTorch eager
+    ops under fp16 autocast = the un-accelerated same-GPU baseline (hipBLASLt / rocBLAS / MIOpen kernels, vanilla attention, NCHW)."""
     from oracle import lvdm_oracle as O
     unet = model.model.diffusion_model
     sd = {k: v.detach() for k, v in unet.state_dict().items()}
@@ -157,19 +158,31 @@ def gpu_legs(model, hp, dd, T, h, w, device, x, ts, ctx, fs, z_dec):
         out["parity"] = {"unet_forward_rel_l2": rel, "vae_decode_rel_l2": drel, "latent": [T, h, w],
                          "oracle": "fp32 oracle/lvdm_oracle.py run on the same MI355X, same weights and inputs",
                          "bounds": {"unet_forward": 5e-3, "vae_decode": 8e-3}}
+        from oracle import ref_runner as R
+        if R.available():       # the reference's own UNetModel (oracle/_ref bytecode), sharing the product's fp32 parameter tensors
+            with torch.device("meta"):
+                ref_unet = R.reference_unet(hp)
+            ref_unet.load_state_dict(sd, strict=True, assign=True)
+
+            def eager(xx):
+                return ref_unet(xx, ts, context=ctx, fs=fs)
+            kind = ("the reference's own UNetModel.forward (oracle/_ref: bytecode of /root/reference's lvdm; fp32 weights, vanilla attention - "
+                    "xformers is not in this image) under torch.autocast(fp16) as viewcrafter.py:98 runs it, on this MI355X")
+        else:
+            def eager(xx):
+                return O.unet_forward(sd, hp, xx, ts, ctx, fs)
+            kind = "oracle graph as PyTorch-ROCm eager ops under torch.autocast(fp16) on this MI355X (oracle/_ref not built)"
         with torch.autocast("cuda", dtype=torch.float16):
-            O.unet_forward(sd, hp, x, ts, ctx, fs)                       # warm-up: MIOpen find, hipBLASLt heuristics
+            eager(x)                                                    # warm-up: MIOpen find, hipBLASLt heuristics
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(2):                                          # cond + uncond = one DDIM step of the reference
-                ye = O.unet_forward(sd, hp, x, ts, ctx, fs)
+                ye = eager(x)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         erel = float((ye.double() - ref.double()).norm() / ref.double().norm())
         out["gpu_eager_baseline"] = {"value": 1.0 / dt, "unit": "DDIM steps/s", "ms_per_step": 1e3 * dt,
-                                     "kind": "oracle graph as PyTorch-ROCm eager ops under torch.autocast(fp16) on this MI355X "
-                                             "(2 sequential B=1 forwards, vanilla attention in batch-head chunks, no DDIM update)",
-                                     "rel_l2_vs_fp32": erel}
+                                     "kind": kind + " (2 sequential B=1 forwards, no DDIM update)", "rel_l2_vs_fp32": erel}
     torch.cuda.empty_cache()
     return out
 
