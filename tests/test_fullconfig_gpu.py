@@ -380,3 +380,61 @@ def test_reference_code_itself_at_576x1024_on_gpu_pins_oracle_and_hip_path(T):
         torch.cuda.empty_cache()
         assert e_oracle <= 2e-5
         assert e_hip <= DEC_TOL
+
+
+def test_ddim_trajectory_vs_the_reference_sampler_itself_at_576x1024x25():
+    """The whole loop through the reference's own classes on the MI355X, fp32: VIPLatentDiffusion.apply_model -> DiffusionWrapper ->
+    UNetModel.forward driven by DDIMSampler.sample (ddim.py:42-281: make_schedule, CFG 7.5 as two B = 1 forwards, guidance rescale 0.7,
+    v-prediction, dynamic rescale, eta = 0) for 10 steps at latent 25x72x128 from an injected x_T, then decode_first_stage of two
+    frames - all of it oracle/_ref bytecode.  Against it: (a) the oracle sampler on the oracle UNet (pins the restated LOOP at the
+    headline size; fp32 on both sides), (b) the product sampler on the HIP UNet, final latent and decoded frames."""
+    from oracle import ref_runner as R
+    if not R.available():
+        pytest.skip("oracle/_ref not built (python oracle/build_ref.py needs /root/reference)")
+    from viewcrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    from tests.util import psnr
+    T, h, w, steps = 25, 72, 128, 10
+    model, params = _model("inference_pvd_1024.yaml")
+    unet = model.model.diffusion_model
+    hp = dict(params["unet_config"]["params"])
+    sd = {k: v.detach() for k, v in unet.state_dict().items()}
+    vsd = {k: v.detach() for k, v in model.first_stage_model.state_dict().items()}
+    g = torch.Generator().manual_seed(321)
+    x_T = torch.randn(1, 4, T, h, w, generator=g).to(DEV)
+    cat = (torch.randn(1, 4, T, h, w, generator=g) * 0.8).to(DEV)
+    ctx = torch.randn(1, 77 + 256, 1024, generator=g).to(DEV)
+    uctx = torch.randn(1, 77 + 256, 1024, generator=g).to(DEV)
+    cond = {"c_crossattn": [ctx], "c_concat": [cat]}
+    uc = {"c_crossattn": [uctx], "c_concat": [cat]}
+    fs = torch.tensor([10], device=DEV)
+    kw = dict(S=steps, conditioning=cond, batch_size=1, shape=[4, T, h, w], verbose=False, unconditional_guidance_scale=7.5,
+              unconditional_conditioning=uc, eta=0.0, cfg_img=None, mask=None, x0=None, fs=fs, timestep_spacing="uniform_trailing",
+              guidance_rescale=0.7, x_T=x_T, log_every_t=1, unconditional_conditioning_img_nonetext=None)
+    ref_model = R.reference_diffusion(params, sd, vsd, DEV)
+    from lvdm.models.samplers.ddim import DDIMSampler as RefSampler            # the reference's (sys.path set by ref_runner)
+    assert RefSampler is not DDIMSampler
+    with torch.no_grad():
+        want, want_inter = RefSampler(ref_model).sample(**kw)
+        want_frames = ref_model.decode_first_stage(want[:, :, :2].contiguous())
+        torch.cuda.empty_cache()
+        ours, inter = DDIMSampler(model).sample(**kw)
+        ours_frames = model.decode_first_stage(ours[:, :, :2].contiguous())
+    tables = O.diffusion_tables(params["timesteps"], params["linear_start"], params["linear_end"], params["rescale_betas_zero_snr"])
+    scale_arr = O.dynamic_rescale_table(params["timesteps"], params["base_scale"])
+    assert torch.allclose(scale_arr, ref_model.scale_arr.cpu()) and torch.allclose(tables["alphas_cumprod"], ref_model.alphas_cumprod.cpu())
+
+    def apply_oracle(x, t, c):
+        return O.unet_forward(sd, hp, torch.cat([x, c["c_concat"][0]], dim=1), t.to(DEV), c["c_crossattn"][0], fs)
+    with torch.no_grad():
+        got, _ = O.ddim_sample(apply_oracle, tables, scale_arr, x_T, cond, uc, steps=steps, eta=0.0, cfg_scale=7.5,
+                               guidance_rescale=0.7, spacing="uniform_trailing", parameterization="v")
+    e_oracle, e_hip = rel_l2(got, want), rel_l2(ours, want)
+    e_first = rel_l2(inter["pred_x0"][1], want_inter["pred_x0"][1])
+    e_frames, p = rel_l2(ours_frames, want_frames), psnr(ours_frames, want_frames)
+    print(f"\n[reference DDIMSampler + VIPLatentDiffusion + UNetModel, fp32, MI355X, 25x72x128, {steps} steps] oracle loop vs reference: "
+          f"{e_oracle:.2e};  HIP path vs reference: final latent {e_hip:.3e} (first pred_x0 {e_first:.3e}), decoded 576x1024 frames "
+          f"rel-L2 {e_frames:.3e} / PSNR {p:.1f} dB")
+    del ref_model
+    torch.cuda.empty_cache()
+    assert e_oracle <= 1e-4
+    assert e_hip <= TRAJ_TOL and p >= 30.0

@@ -217,9 +217,13 @@ def test_oracle_matches_the_reference_code_itself_when_oracle_ref_is_built():
     from oracle import ref_runner as R
     if not R.available():
         pytest.skip("oracle/_ref not built (python oracle/build_ref.py needs /root/reference)")
+    import sys
     from oracle.weights import synth_state_dict
     from tests.tiny_config import TINY_DDCONFIG, TINY_UNET
     ref = R.reference_unet(TINY_UNET)
+    # the stand-ins for cv2 / pytorch_lightning / torchvision exist only while the reference is being imported: a fake package left
+    # in sys.modules breaks `import transformers...CLIP*` later in the same process (it probes find_spec("torchvision"))
+    assert all(n not in sys.modules or hasattr(sys.modules[n], "__file__") for n in ("cv2", "pytorch_lightning", "torchvision"))
     sd = synth_state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, seed=0)
     ref.load_state_dict(sd, strict=True)
     for T, L in ((4, 77 + 64), (3, 77 + 256)):            # per-frame image tokens (77 + 16 T) / shared ones
