@@ -32,7 +32,7 @@ extern "C" {
 #define VCX_ELAUNCH (-2)  /* HIP launch or runtime error                 */
 #define VCX_ENODEV (-3)   /* no gfx950 device                            */
 
-#define VCX_ABI_VERSION 2   /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*; fused-norm entry points */
+#define VCX_ABI_VERSION 3   /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*.  3: vcx_gemm_desc grows ln_stats / ln_colsum (VCX_GEMM_LNFOLD*), vcx_rowstats_f16 */
 
 int vcx_abi_version(void);
 const char* vcx_last_error(void);
@@ -72,6 +72,16 @@ int vcx_device_arch(char* name_host, int len);
                                    rows [64b+32, 64b+64) their gates; out has N/2 columns */
 #define VCX_GEMM_OUT_F32 0x20   /* store fp32 instead of fp16                             */
 #define VCX_GEMM_CONV_SLABK 0x40 /* mode 1: W rows are ordered (c / 64, ky, kx, c % 64)     */
+/* LayerNorm folded into the projection that consumes it (nn.LayerNorm -> nn.Linear pairs of BasicTransformerBlock,
+ * attention.py:226-246): with W' = gamma o W (fp16), colsum = sum_k W'[., k] (fp32, of the ROUNDED W') and
+ * bias' = bias + W beta, LN(x) W^T + bias = rstd (x W'^T - mean colsum) + bias' exactly; the GEMM reads the un-normalised
+ * rows and the epilogue applies out = alpha rstd (acc - mean colsum) + bias'.  ln_stats = (mean, rstd) pairs from
+ * vcx_rowstats_f16.  Linear mode, K % 64 == 0 only.
+ *   VCX_GEMM_LNFOLD    X rows are the normalised operand: ln_stats[m], ln_colsum[n], bias'[n] (BIAS_N); with GEGLU too
+ *   VCX_GEMM_LNFOLD_T  W rows are the normalised operand (the transposed V projection out[d, token]): ln_stats[n],
+ *                      ln_colsum[m], bias'[m] (BIAS_M)                                                                   */
+#define VCX_GEMM_LNFOLD 0x80
+#define VCX_GEMM_LNFOLD_T 0x100
 
 typedef struct vcx_gemm_desc {
     const void* A;        /* fp16 activations                                             */
@@ -88,6 +98,8 @@ typedef struct vcx_gemm_desc {
     int32_t rowadd_div;
     int32_t flags;
     float alpha;
+    const float* ln_stats;  /* VCX_GEMM_LNFOLD[_T]: fp32 (mean, rstd) per normalised row            */
+    const float* ln_colsum; /* VCX_GEMM_LNFOLD[_T]: fp32 row sums of the folded weight              */
 } vcx_gemm_desc;
 
 int vcx_gemm_f16(const vcx_gemm_desc* desc_host, void* stream);
@@ -113,6 +125,9 @@ int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stats, const fl
                             float eps, int silu, void* stream);
 
 /* LayerNorm over the last dim (nn.LayerNorm, attention.py:226-228), fp32 statistics. */
+/* (mean, rstd) of every row, stats[rows][2] fp32: the read-only half of LayerNorm in front of a VCX_GEMM_LNFOLD projection
+ * (same summation order as vcx_layernorm_f16: the statistics are bit-identical to the ones it normalises with). */
+int vcx_rowstats_f16(const void* x, float* stats, int64_t rows, int C, float eps, void* stream);
 int vcx_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,
                       int64_t rows, int C, float eps, void* stream);
 

@@ -48,11 +48,24 @@ def test_tune_knobs_default_to_the_product_and_round_trip():
 
 
 def test_gemm_desc_layout_matches_header():
-    """Field order/types of the ctypes mirror follow the C struct (checked by total size: 6 pointers, one int64, 21 int32,
-    one float, padded to 8)."""
-    assert ctypes.sizeof(_lib.GemmDesc) == 6 * 8 + 8 + 21 * 4 + 4
-    fields = [f[0] for f in _lib.GemmDesc._fields_]
-    assert fields[:7] == ["A", "W", "C", "bias", "rowadd", "residual", "lda"] and fields[-1] == "alpha"
+    """The ctypes mirror follows the C struct of include/vcx.h field by field (names and order parsed from the header; C types
+    mapped to ctypes) and in total size: 8 pointers, one int64, 21 int32, one float - 160 bytes, no padding."""
+    src = open(os.path.join(ROOT, "include", "vcx.h")).read()
+    body = re.search(r"typedef struct vcx_gemm_desc \{(.*?)\} vcx_gemm_desc;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    want = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.rsplit(None, 1)[0], decl.split(",")
+        first = names[0].rsplit(None, 1)
+        ctype, names = first[0], [first[1]] + [n.strip() for n in names[1:]]
+        for n in names:
+            ptr = "*" in ctype or n.startswith("*")
+            want.append((n.lstrip("*"), ctypes.c_void_p if ptr else {"int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "float": ctypes.c_float}[ctype]))
+    assert [(f[0], f[1]) for f in _lib.GemmDesc._fields_] == want
+    assert ctypes.sizeof(_lib.GemmDesc) == 8 * 8 + 8 + 21 * 4 + 4 == 160
 
 
 def test_argument_validation_without_gpu():

@@ -253,6 +253,104 @@ def test_layernorm(rows, C):
     check(out, F.layer_norm(x.float(), (C,), g, b, 1e-5), name="layernorm")
 
 
+# ---------------------------------------------------------------- LayerNorm folded into the consuming projection
+def _ln_linear_ref(x, gamma, beta, w, bias, eps=1e-5):
+    """fp64 LayerNorm -> Linear of the fp16 rows actually stored in x (reference attention.py:226-246 pairs)."""
+    xd = x.double()
+    mu = xd.mean(-1, keepdim=True)
+    var = ((xd - mu) ** 2).mean(-1, keepdim=True)
+    y = (xd - mu) / torch.sqrt(var + eps) * gamma.double() + beta.double()
+    out = y @ w.double().t()
+    return out + bias.double() if bias is not None else out
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (37, 1280), (4100, 64)])
+def test_rowstats_are_layernorms_statistics(rows, C):
+    from viewcrafter_amd import ops
+    x = (rnd(rows, C, seed=46) * 3 + 1).to(DEV).half()
+    st = ops.row_stats(x, 1e-5)
+    xd = x.double()
+    mu, var = xd.mean(-1), xd.var(-1, unbiased=False)
+    assert float((st[:, 0].double() - mu).abs().max()) <= 1e-5 * float(mu.abs().max() + 1)
+    assert rel_l2(st[:, 1], 1.0 / torch.sqrt(var + 1e-5)) <= 1e-6
+
+
+@pytest.mark.parametrize("M,N,K,alpha,offset", [(1000, 320, 320, 1.0, 0.0), (700, 960, 320, 0.37, 0.0), (40000, 960, 320, 1.0, 0.0),
+                                                (5000, 1280, 640, 1.0, 0.0), (3000, 640, 640, 1.0, 900.0), (513, 72, 128, 1.0, 0.0)])
+def test_gemm_lnfold_matches_layernorm_then_linear(M, N, K, alpha, offset):
+    """VCX_GEMM_LNFOLD: row_stats + ONE projection of the un-normalised rows against fp64 LayerNorm -> Linear, next to the
+    unfused pair (layer_norm kernel, then linear).  The folded form must be at least as close (it skips the fp16 rounding of the
+    normalised rows) - including rows whose common offset dwarfs their spread (offset 900, spread 8: x W'^T and mean colsum are
+    ~1e4 each and cancel to O(1); exact because colsum is the row sum of the SAME fp16 weights the MFMA multiplies)."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import fold_layernorm
+    x = (rnd(M, K, seed=201) * (8.0 if offset else 2.0) + offset + 0.3).to(DEV).half()
+    gamma = (1 + 0.3 * rnd(K, seed=202)).to(DEV)
+    beta = (0.2 * rnd(K, seed=203)).to(DEV)
+    w = (rnd(N, K, seed=204) / math.sqrt(K)).to(DEV)
+    bias = (0.1 * rnd(N, seed=205)).to(DEV)
+    ref = alpha * _ln_linear_ref(x, gamma, beta, w, None) + bias.double()
+    wf, colsum, bias_f = fold_layernorm(w, gamma, beta, None)          # alpha scales the projection, the bias is added after it
+    # bias' = w beta is scaled by alpha too, the layer's own bias is not: hand it over separately folded
+    out = ops.linear(x, wf, alpha * bias_f + bias, alpha=alpha, ln_stats=ops.row_stats(x, 1e-5), ln_colsum=colsum)
+    unfused = ops.linear(ops.layer_norm(x, gamma, beta, 1e-5), w.half(), bias, alpha=alpha)
+    e_fold, e_unf = rel_l2(out, ref), rel_l2(unfused, ref)
+    print(f"\n[lnfold {M}x{N}x{K} alpha {alpha} offset {offset}] folded {e_fold:.2e}  layer_norm+linear {e_unf:.2e}")
+    assert torch.isfinite(out.float()).all()
+    assert e_fold <= 1e-3 and e_fold <= 1.2 * e_unf + 1e-4
+
+
+def test_gemm_lnfold_rejects_what_the_kernel_cannot_do():
+    from viewcrafter_amd import ops
+    from viewcrafter_amd._lib import VcxError
+    x = rnd(64, 72, seed=1).to(DEV).half()          # K = 72: not a multiple of 64 -> no DMA kernel -> no folded epilogue
+    w = rnd(64, 72, seed=2).to(DEV).half()
+    with pytest.raises(VcxError, match="LNFOLD"):
+        ops.linear(x, w, None, ln_stats=torch.zeros(64, 2, device=DEV), ln_colsum=torch.zeros(64, device=DEV))
+
+
+@pytest.mark.parametrize("D,tokens", [(320, 2000), (640, 36000), (1280, 777 * 8)])
+def test_gemm_lnfold_transposed_v_projection(D, tokens):
+    """VCX_GEMM_LNFOLD_T: out[d, token] = V^T of LayerNorm'ed tokens (the flash kernels read V^T); the normalised rows are the W
+    operand, so the statistics index the output COLUMNS and colsum / bias' the rows."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import fold_layernorm
+    x = (rnd(tokens, D, seed=211) * 2 + 0.5).to(DEV).half()
+    gamma = (1 + 0.3 * rnd(D, seed=212)).to(DEV)
+    beta = (0.2 * rnd(D, seed=213)).to(DEV)
+    wv = (rnd(D, D, seed=214) / math.sqrt(D)).to(DEV)
+    ref = _ln_linear_ref(x, gamma, beta, wv, None).t()
+    wf, colsum, bias_f = fold_layernorm(wv, gamma, beta, None)
+    out = ops.gemm(wf, x, M=D, N=tokens, K=D, lda=D, bias=bias_f, bias_m=True, ln_stats=ops.row_stats(x, 1e-5), ln_colsum=colsum, ln_t=True)
+    unfused = ops.gemm(wv.half(), ops.layer_norm(x, gamma, beta, 1e-5), M=D, N=tokens, K=D, lda=D)
+    e_fold, e_unf = rel_l2(out, ref), rel_l2(unfused, ref)
+    print(f"\n[lnfold_t {D}x{tokens}] folded {e_fold:.2e}  layer_norm+gemm {e_unf:.2e}")
+    assert e_fold <= 1e-3 and e_fold <= 1.2 * e_unf + 1e-4
+
+
+@pytest.mark.parametrize("C,M", [(320, 3000), (640, 70000), (64, 500)])
+def test_gemm_lnfold_geglu(C, M):
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import fold_layernorm, pack_geglu
+    x = (rnd(M, C, seed=221) * 2 - 0.4).to(DEV).half()
+    gamma = (1 + 0.3 * rnd(C, seed=222)).to(DEV)
+    beta = (0.2 * rnd(C, seed=223)).to(DEV)
+    w = (rnd(8 * C, C, seed=224) / math.sqrt(C)).to(DEV)
+    b = (0.1 * rnd(8 * C, seed=225)).to(DEV)
+    h = _ln_linear_ref(x, gamma, beta, w, b)
+    a, g = h.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    wf, colsum, bias_f = fold_layernorm(w, gamma, beta, b)
+    wp, bp = pack_geglu(wf, bias_f)
+    _, cp = pack_geglu(wf, colsum)
+    out = ops.linear(x, wp, bp, geglu=True, ln_stats=ops.row_stats(x, 1e-5), ln_colsum=cp)
+    w0, b0 = pack_geglu(w, b)
+    unfused = ops.linear(ops.layer_norm(x, gamma, beta, 1e-5), w0.half(), b0, geglu=True)
+    e_fold, e_unf = rel_l2(out, ref), rel_l2(unfused, ref)
+    print(f"\n[lnfold geglu C {C} M {M}] folded {e_fold:.2e}  layer_norm+geglu {e_unf:.2e}")
+    assert e_fold <= 1.5e-3 and e_fold <= 1.2 * e_unf + 1e-4
+
+
 # ---------------------------------------------------------------- attention
 def attn_ref(q, k, v, scale):
     s = torch.einsum("bid,bjd->bij", q.float(), k.float()) * scale

@@ -105,6 +105,41 @@ def test_unet_forward_at_sizes_whose_token_counts_are_not_multiples_of_8(unet, h
     assert torch.equal(y2[:1], y)                    # the shared-prefix path pads and replicates consistently
 
 
+def test_unet_forward_with_and_without_the_folded_layernorm(unet, monkeypatch):
+    """The three ways a LayerNorm -> Linear pair of BasicTransformerBlock can run (reference attention.py:226-246): separate
+    LayerNorm kernel (VCX_LN_FOLD=0), folded into the attention projections (the default), folded into the GEGLU projection as well
+    (VCX_LN_FOLD_FF=1) - each against the reference golden, and against each other (they differ by fp16 rounding of the normalised rows
+    only)."""
+    from viewcrafter_amd.lvdm.modules import attention as A
+    m, _ = unet
+    g = golden("unet_tiny")["unet_out_perframe"]
+    x = synth_input("unet_x_perframe", (1, 8, 4, 32, 16)).to(DEV)
+    ctx = synth_input("unet_ctx_perframe", (1, 77 + 64, TINY_UNET["context_dim"])).to(DEV)
+    outs, packs = {}, {}
+    try:
+        for tag, fold, fold_ff in (("separate", False, False), ("attention", True, False), ("attention+geglu", True, True)):
+            monkeypatch.setattr(A, "FOLD_LAYERNORM", fold)
+            monkeypatch.setattr(A, "FOLD_LAYERNORM_FF", fold_ff)
+            for mod in m.modules():
+                if hasattr(mod, "_drop_packed"):
+                    mod._drop_packed()
+            with torch.no_grad():
+                outs[tag] = m(x, torch.tensor([999], device=DEV), context=ctx, fs=torch.tensor([10], device=DEV))
+            blk = m.input_blocks[1][1].transformer_blocks[0]
+            packs[tag] = (blk.attn1.packed()["qk"]["colsum"] is not None, blk.ff.packed()["colsum"] is not None)
+    finally:
+        monkeypatch.undo()
+        for mod in m.modules():
+            if hasattr(mod, "_drop_packed"):
+                mod._drop_packed()
+    assert packs == {"separate": (False, False), "attention": (True, False), "attention+geglu": (True, True)}
+    errs = {k: rel_l2(v, g) for k, v in outs.items()}
+    print("unet vs reference golden by LayerNorm mode:", {k: f"{e:.3e}" for k, e in errs.items()},
+          "| attention-folded vs separate:", f"{rel_l2(outs['attention'], outs['separate']):.3e}")
+    assert all(e <= UNET_TOL for e in errs.values())
+    assert rel_l2(outs["attention"], outs["separate"]) <= 3e-3 and rel_l2(outs["attention+geglu"], outs["separate"]) <= 3e-3
+
+
 @pytest.mark.parametrize("r,t,L", [(2, 4, 77 + 64), (2, 3, 77 + 40), (3, 5, 77 + 24)])
 def test_cfg_shared_prefix_is_bit_identical(unet, r, t, L):
     """Classifier-free guidance evaluates the denoiser on the same x / t / fs under r conditionings.  With cfg_repeat = r the

@@ -415,6 +415,16 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     VCX_REQUIRE(!(geglu && (f32 || (flags & (VCX_GEMM_ROWADD | VCX_GEMM_RESIDUAL | VCX_GEMM_BIAS_M)))),
                 "vcx_gemm_f16: GEGLU combines only with BIAS_N");
     VCX_REQUIRE(!geglu || d->N % 64 == 0, "vcx_gemm_f16: GEGLU needs N %% 64 == 0 (N=%d)", d->N);
+    const int lnf = (flags & VCX_GEMM_LNFOLD) ? 1 : (flags & VCX_GEMM_LNFOLD_T) ? 2 : 0;
+    if (lnf) {
+        VCX_REQUIRE(!((flags & VCX_GEMM_LNFOLD) && (flags & VCX_GEMM_LNFOLD_T)), "vcx_gemm_f16: LNFOLD and LNFOLD_T are exclusive");
+        VCX_REQUIRE(d->ln_stats && d->ln_colsum && ((uintptr_t)d->ln_stats & 15) == 0 && ((uintptr_t)d->ln_colsum & 15) == 0,
+                    "vcx_gemm_f16: LNFOLD needs 16-byte aligned ln_stats and ln_colsum");
+        VCX_REQUIRE(!conv && !f32 && !(flags & VCX_GEMM_ROWADD), "vcx_gemm_f16: LNFOLD is for linear layers with fp16 output, without ROWADD");
+        VCX_REQUIRE(lnf == 1 ? !(flags & VCX_GEMM_BIAS_M) : !(flags & VCX_GEMM_BIAS_N) && !geglu,
+                    "vcx_gemm_f16: LNFOLD takes BIAS_N (and GEGLU), LNFOLD_T takes BIAS_M");
+        VCX_REQUIRE((lnf == 1 ? d->N : d->M) % 4 == 0 && (lnf == 1 ? d->N : d->M) >= 4, "vcx_gemm_f16: LNFOLD needs the colsum side to be a multiple of 4");
+    }
     if (conv) {
         VCX_REQUIRE(d->cin > 0 && d->cin % 8 == 0 && d->kh > 0 && d->kw > 0 && d->K == d->kh * d->kw * d->cin,
                     "vcx_gemm_f16: conv needs cin %% 8 == 0 and K == kh*kw*cin (cin=%d kh=%d kw=%d K=%d)", d->cin,
@@ -454,6 +464,8 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.tiles_m = (d->M + BM - 1) / BM;
     a.tiles_n = (d->N + bn - 1) / bn;
     a.m_begin = 0;
+    a.ln_stats = d->ln_stats;
+    a.ln_colsum = d->ln_colsum;
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * (double)d->N * d->K;
     const double bytes = 2.0 * ((double)d->M * d->K / (conv ? d->kh * d->kw : 1) + (double)d->N * d->K + (double)d->M * d->N);
@@ -517,5 +529,6 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
         }
         return cfg >= 2 ? big(a, cfg) : launch_dma(a, cfg, conv, geglu, f32, s);
     }
+    VCX_REQUIRE(!lnf, "vcx_gemm_f16: LNFOLD needs the DMA kernel (K %% 64 == 0, N %% 8 == 0, extents < 4 GiB); K=%d N=%d", d->K, d->N);
     return use160 ? dispatch<160>(a, conv, geglu, f32, s) : dispatch<128>(a, conv, geglu, f32, s);
 }

@@ -26,6 +26,8 @@ struct GemmArgs {
     unsigned a_bytes, w_bytes;   // operand extents for the DMA kernel's buffer descriptors (whole problem, not the launch's rows)
     unsigned c_bytes, r_bytes;   // output / residual extents (the DMA kernel's epilogue addresses them through descriptors too)
     int m_begin;   // first output row of this launch (tail split of large-tile launches); rows are < M
+    const float* ln_stats;    // VCX_GEMM_LNFOLD[_T]: (mean, rstd) pairs
+    const float* ln_colsum;   // VCX_GEMM_LNFOLD[_T]: row sums of the folded weight
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -92,6 +94,6 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
 }
 
 int persistent_grid(int ntiles, int blocks_per_cu = 2);
-int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);
+int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);   // a.flags & VCX_GEMM_LNFOLD[_T] selects the folded-LayerNorm epilogue
 
 }  // namespace vcxgemm

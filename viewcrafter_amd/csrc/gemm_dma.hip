@@ -41,10 +41,14 @@ struct TileCfg {
     static constexpr int WROWS = TBN * 8 / THREADS;
     static constexpr int RSTEP = THREADS / 8;         // tile rows covered by one DMA instruction of the block
     static constexpr size_t STAGES = (size_t)2 * (TBM + TBN) * BK * sizeof(half_t);
-    static constexpr size_t SMEM = STAGES + (size_t)TBN * NWM * sizeof(float);   // + one bias strip per wave (epilogue)
+    static constexpr size_t STRIP = (size_t)TBN * NWM * sizeof(float);            // one strip of column addends per wave (epilogue)
+    static constexpr size_t SMEM = STAGES + STRIP;
+    static constexpr size_t SMEM_LNF = STAGES + 2 * STRIP;                        // + a second strip (folded-LayerNorm epilogue)
 };
 
-template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32>
+// LNF: 0 = plain epilogue, 1 = VCX_GEMM_LNFOLD, 2 = VCX_GEMM_LNFOLD_T (linear mode only; separate instantiations, so the
+// convolution and plain kernels keep their register allocation)
+template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32, int LNF = 0>
 __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the body uses device-only types)
     constexpr int TBM = Cfg::TBM, BN = Cfg::TBN;
@@ -207,6 +211,24 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
         if (more) load_tile(lkt, cur ^ 1, 3 & ~late_parts);        // async: lands in the other buffer while this one is consumed
         const half_t* cx = sX + cur * TBM * BK;
         const half_t* cw = sW + cur * BN * BK;
+        // folded LayerNorm: the lane's per-row terms (LNF 1: mean, rstd of its 4 rows; LNF 2: colsum, bias' of them) are fetched
+        // ahead of the tile's last K-step, so that the epilogue does not start with an exposed global-memory round trip
+        [[maybe_unused]] float ln_r0[LNF ? MFRAG : 1], ln_r1[LNF ? MFRAG : 1];
+        if (LNF && ckt == nk - 1) {
+            const int mrow = p.m_begin + tile_m * TBM + wm * WM + lr;
+#pragma unroll
+            for (int b = 0; b < MFRAG; ++b) {
+                const int mc = min(mrow + b * 16, p.M - 1);
+                if (LNF == 1) {
+                    const float2 st = reinterpret_cast<const float2*>(p.ln_stats)[mc];
+                    ln_r0[b] = st.x;
+                    ln_r1[b] = st.y;
+                } else {
+                    ln_r0[b] = p.ln_colsum[mc];
+                    ln_r1[b] = (p.flags & VCX_GEMM_BIAS_M) ? p.bias[mc] : 0.f;
+                }
+            }
+        }
         // Fragment reads are software-pipelined by hand: the next weight fragment is requested before the 8-16 MFMAs that
         // use the current one, and the activation fragments of the second K half are re-requested right after their last
         // use in the first half.  (Left to itself hipcc issues every ds_read immediately before the MFMA that needs it -
@@ -238,7 +260,8 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
         }
         if (ckt == nk - 1) {
             float* sB = reinterpret_cast<float*>(smem_raw + Cfg::STAGES) + wave * WN;   // the wave's private strip of column addends
-            gemm_epilogue<Cfg, GEGLU, OUT_F32>(p, acc, tile_m, tile_n, wm, wn, lane, sB);
+            gemm_epilogue<Cfg, GEGLU, OUT_F32, LNF>(p, acc, tile_m, tile_n, wm, wn, lane, sB,
+                                                    reinterpret_cast<float*>(smem_raw + Cfg::STAGES + Cfg::STRIP) + wave * WN, ln_r0, ln_r1);
 #pragma unroll
             for (int a = 0; a < NFRAG; ++a)
 #pragma unroll
@@ -258,19 +281,27 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
 #endif
 }
 
-template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32>
+template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32, int LNF = 0>
 int launch(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
-    auto kern = gemm_dma_kernel<Cfg, CONV, GEGLU, OUT_F32>;
-    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)Cfg::SMEM, "vcx_gemm_f16(dma)")) return VCX_ELAUNCH;
+    auto kern = gemm_dma_kernel<Cfg, CONV, GEGLU, OUT_F32, LNF>;
+    constexpr size_t smem = LNF ? Cfg::SMEM_LNF : Cfg::SMEM;
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)smem, "vcx_gemm_f16(dma)")) return VCX_ELAUNCH;
     const int blocks_per_cu = Cfg::SMEM > 80 * 1024 ? 1 : 2;
     const int nb = persistent_grid(a.tiles_m * a.tiles_n, blocks_per_cu);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(Cfg::THREADS), Cfg::SMEM, s, a, a.a_bytes, a.w_bytes);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(Cfg::THREADS), smem, s, a, a.a_bytes, a.w_bytes);
     return vcx_check_launch("vcx_gemm_f16(dma)");
 }
 
 template <class Cfg>
 int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) {
+    if (a.flags & (VCX_GEMM_LNFOLD | VCX_GEMM_LNFOLD_T)) {      // linear, fp16 output (checked by vcx_gemm_f16)
+        if (a.flags & VCX_GEMM_LNFOLD_T) return launch<Cfg, false, false, false, 2>(a, s);
+        if (!geglu) return launch<Cfg, false, false, false, 1>(a, s);
+        if constexpr (Cfg::NF % 4 == 0) return launch<Cfg, false, true, false, 1>(a, s);
+        vcx_set_error("vcx_gemm_f16(dma): GEGLU needs whole 64-column packed blocks per wave");
+        return VCX_EINVAL;
+    }
     if (geglu) {
         if constexpr (Cfg::NF % 4 == 0) return conv ? launch<Cfg, true, true, false>(a, s) : launch<Cfg, false, true, false>(a, s);
         vcx_set_error("vcx_gemm_f16(dma): GEGLU needs whole 64-column packed blocks per wave");

@@ -9,10 +9,16 @@ namespace vcxgemm {
 
 [[maybe_unused]] constexpr unsigned EPI_OOB = 0xFFFFFFFFu;
 
-// sB: the wave's private LDS strip of WN floats (column addends).
-template <class Cfg, bool GEGLU, bool OUT_F32>
+// sB: the wave's private LDS strip of WN floats (column addends); sS: a second one, only allocated for LNF != 0.
+// LNF (folded LayerNorm, include/vcx.h VCX_GEMM_LNFOLD*): the accumulator holds x W'^T of the UN-normalised rows;
+//   LNF = 1  out = alpha rstd_m (acc - mean_m colsum_n) + bias'_n  = fma(acc, rb, fma(qb, colsum_n, bias'_n)),  rb = alpha rstd_m, qb = -rb mean_m
+//   LNF = 2  out = alpha rstd_n (acc - mean_n colsum_m) + bias'_m  = fma(acc, cs_n, fma(cq_n, colsum_m, bias'_m)), cs / cq in the two strips
+template <class Cfg, bool GEGLU, bool OUT_F32, int LNF = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::NF][Cfg::MF], int tile_m, int tile_n, int wm, int wn,
-                                              int lane, float* sB) {
+                                              int lane, float* sB, [[maybe_unused]] float* sS = nullptr,
+                                              [[maybe_unused]] const float* ln_r0 = nullptr, [[maybe_unused]] const float* ln_r1 = nullptr) {
+    // ln_r0 / ln_r1 [MFRAG]: per-lane row terms fetched by the caller ahead of the last K-step - LNF 1: (mean, rstd) of row
+    // mbase + 16 b, LNF 2: (colsum, bias') of it
     constexpr int TBM = Cfg::TBM, BN = Cfg::TBN, NFRAG = Cfg::NF, MFRAG = Cfg::MF;
     constexpr int WM = TBM / Cfg::NWM, WN = BN / Cfg::NWN;
     [[maybe_unused]] constexpr unsigned OOB = EPI_OOB;
@@ -26,11 +32,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
         // 4j + 1 are values, 4j + 2 and 4j + 3 their gates; output fragment a = 2j + i pairs xfrag(a) with xfrag(a) + 2.
         auto xfrag = [](int a) { return 4 * (a >> 1) + (a & 1); };
         f4 bx[NFRAG / 2 + 1], bg[NFRAG / 2 + 1];
+        [[maybe_unused]] f4 sx[LNF ? NFRAG / 2 + 1 : 1], sg[LNF ? NFRAG / 2 + 1 : 1];
 #pragma unroll
         for (int a = 0; a < NFRAG / 2; ++a) {
             const int nx = min(nbase + xfrag(a) * 16, p.N - 36);
             bx[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nx) : f4{0.f, 0.f, 0.f, 0.f};
             bg[a] = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nx + 32) : f4{0.f, 0.f, 0.f, 0.f};
+            if (LNF) {
+                sx[a] = *reinterpret_cast<const f4*>(p.ln_colsum + nx);
+                sg[a] = *reinterpret_cast<const f4*>(p.ln_colsum + nx + 32);
+            }
         }
         // output through a buffer descriptor (rows >= M dropped by the range check), fragment pairs widened to dwordx4
         // with v_permlane16_swap exactly as in the plain epilogue below
@@ -45,13 +56,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
 #pragma unroll
         for (int b = 0; b < MFRAG; ++b) {
             u2v packed[NOUT];
+            [[maybe_unused]] float rb = 0.f, qb = 0.f;
+            if (LNF) {
+                rb = p.alpha * ln_r1[b];
+                qb = -rb * ln_r0[b];
+            }
 #pragma unroll
             for (int a = 0; a < NOUT; ++a) {
                 half_t o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float xv = acc[xfrag(a)][b][r] * p.alpha + bx[a][r];
-                    const float gv = acc[xfrag(a) + 2][b][r] * p.alpha + bg[a][r];
+                    float xv, gv;
+                    if (LNF) {
+                        xv = __builtin_fmaf(acc[xfrag(a)][b][r], rb, __builtin_fmaf(qb, sx[a][r], bx[a][r]));
+                        gv = __builtin_fmaf(acc[xfrag(a) + 2][b][r], rb, __builtin_fmaf(qb, sg[a][r], bg[a][r]));
+                    } else {
+                        xv = acc[xfrag(a)][b][r] * p.alpha + bx[a][r];
+                        gv = acc[xfrag(a) + 2][b][r] * p.alpha + bg[a][r];
+                    }
                     o[r] = (half_t)(xv * gelu_erf(gv));
                 }
                 packed[a] = __builtin_bit_cast(u2v, h4{o[0], o[1], o[2], o[3]});
@@ -132,18 +154,47 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
         // LDS strip of the wave, not in registers: a 160-column strip would pin 40 VGPRs through the whole epilogue.
         if (lane < WN / 4) {
             const int nc = min(nstrip + lane * 4, p.N - 4);
-            f4 t = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nc) : f4{0.f, 0.f, 0.f, 0.f};
-            if (radd_tile) {
-                const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)radd_row * p.N + nc);
+            if (LNF == 2) {         // per-column (alpha rstd_n, -alpha rstd_n mean_n)
+                const f4 s01 = *reinterpret_cast<const f4*>(p.ln_stats + 2 * nc), s23 = *reinterpret_cast<const f4*>(p.ln_stats + 2 * nc + 4);
+                const f4 cs = {p.alpha * s01[1], p.alpha * s01[3], p.alpha * s23[1], p.alpha * s23[3]};
+                *reinterpret_cast<f4*>(sB + lane * 4) = cs;
+                *reinterpret_cast<f4*>(sS + lane * 4) = f4{-cs[0] * s01[0], -cs[1] * s01[2], -cs[2] * s23[0], -cs[3] * s23[2]};
+            } else {
+                f4 t = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nc) : f4{0.f, 0.f, 0.f, 0.f};
+                if (radd_tile) {
+                    const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)radd_row * p.N + nc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] += rv[r];
+                    for (int r = 0; r < 4; ++r) t[r] += rv[r];
+                }
+                *reinterpret_cast<f4*>(sB + lane * 4) = t;
+                if (LNF == 1) *reinterpret_cast<f4*>(sS + lane * 4) = *reinterpret_cast<const f4*>(p.ln_colsum + nc);
             }
-            *reinterpret_cast<f4*>(sB + lane * 4) = t;
+        }
+        // per-lane row terms of the folded LayerNorm: LNF 1 (rb, qb) of the lane's row in each 16-row group, LNF 2 (colsum_m, bias'_m)
+        [[maybe_unused]] float ln_a[LNF ? MFRAG : 1], ln_b[LNF ? MFRAG : 1];
+        if (LNF) {
+#pragma unroll
+            for (int b = 0; b < MFRAG; ++b) {
+                if (LNF == 1) {
+                    ln_a[b] = p.alpha * ln_r1[b];
+                    ln_b[b] = -ln_a[b] * ln_r0[b];
+                } else {
+                    ln_a[b] = ln_r0[b];
+                    ln_b[b] = ln_r1[b];
+                }
+            }
         }
         int bopaque = 0;     // re-read per 16-row group (an address the compiler cannot prove loop-invariant)
         // value of accumulator fragment (a, b) with bias / addend applied (everything but the residual)
         auto finish = [&](int a, int b, float (&v)[4]) {
-            if (per_row) {      // rare: V^T projections (per-row bias) and tiles that straddle two addend rows
+            if (LNF) {
+                const f4 t = *reinterpret_cast<const f4*>(sB + bopaque + a * 16 + lg * 4);
+                const f4 u = *reinterpret_cast<const f4*>(sS + bopaque + a * 16 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = LNF == 1 ? __builtin_fmaf(acc[a][b][r], ln_a[b], __builtin_fmaf(ln_b[b], u[r], t[r]))
+                                    : __builtin_fmaf(acc[a][b][r], t[r], __builtin_fmaf(u[r], ln_a[b], ln_b[b]));
+            } else if (per_row) {      // rare: V^T projections (per-row bias) and tiles that straddle two addend rows
                 // same arithmetic as the tile-uniform case, (bias + addend) first and one fma: a row's result must
                 // not depend on how the batch happens to align tiles with frames (bit-exact batch invariance)
                 const int mc = min(mbase + b * 16, p.M - 1);

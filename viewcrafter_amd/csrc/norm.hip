@@ -228,7 +228,9 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
 // LayerNorm: LPR lanes per row (8..64, chosen so a lane holds <= 4 chunks of 8 channels), the row stays in registers:
 // one HBM read, mean then centred variance from the registers (as torch computes them), one HBM write.
 // ---------------------------------------------------------------------------------------
-template <int LPR, int CPL>
+// STATS: write (mean, rstd) per row instead of the normalised row - the read-only pass in front of a projection that has the
+// LayerNorm folded into its weights and epilogue (VCX_GEMM_LNFOLD_*): same summation order, hence the same statistics bit for bit.
+template <int LPR, int CPL, bool STATS = false>
 __global__ void __launch_bounds__(256) layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int64_t rows, int C, float eps) {
@@ -267,6 +269,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const half_t* __restrict
     for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = rsqrtf(q / (float)C + eps);
     if (!rvalid) return;
+    if (STATS) {
+        if (sub == 0) reinterpret_cast<float2*>(y)[row] = make_float2(mean, rstd);
+        return;
+    }
     half_t* yr = y + row * C;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -288,7 +294,24 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const half_t* __restrict
 template <int LPR, int CPL>
 void launch_ln(const half_t* x, half_t* y, const float* g, const float* b, int64_t rows, int C, float eps, hipStream_t s) {
     constexpr int RPB = 256 / LPR;
-    hipLaunchKernelGGL((layernorm_kernel<LPR, CPL>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, x, y, g, b, rows, C, eps);
+    const dim3 grid((unsigned)((rows + RPB - 1) / RPB));
+    if (g) hipLaunchKernelGGL((layernorm_kernel<LPR, CPL, false>), grid, dim3(256), 0, s, x, y, g, b, rows, C, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<LPR, CPL, true>), grid, dim3(256), 0, s, x, y, g, b, rows, C, eps);   // y = float2 stats
+}
+
+void dispatch_ln(const half_t* xp, half_t* yp, const float* gamma, const float* beta, int64_t rows, int C, float eps, hipStream_t s) {
+    const int nc8 = C >> 3;
+    if (nc8 <= 8) launch_ln<8, 1>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 16) launch_ln<8, 2>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 32) launch_ln<16, 2>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 48) launch_ln<16, 3>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 64) launch_ln<16, 4>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 96) launch_ln<32, 3>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 128) launch_ln<32, 4>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 192) launch_ln<64, 3>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 256) launch_ln<64, 4>(xp, yp, gamma, beta, rows, C, eps, s);
+    else if (nc8 <= 512) launch_ln<64, 8>(xp, yp, gamma, beta, rows, C, eps, s);
+    else launch_ln<64, 16>(xp, yp, gamma, beta, rows, C, eps, s);
 }
 
 // thread geometry shared by the two GroupNorm kernels: cw channel chunks x pl pixel lanes, ~320 threads
@@ -369,19 +392,17 @@ extern "C" int vcx_layernorm_f16(const void* x, void* y, const float* gamma, con
     VCX_REQUIRE(rows < (1ll << 31) && C <= 8192, "vcx_layernorm_f16: too many rows or C > 8192");
     hipStream_t s = (hipStream_t)stream;
     VcxProfScope prof(VCX_FAM_LN, s, 0.0, 4.0 * rows * (double)C);
-    const half_t* xp = (const half_t*)x;
-    half_t* yp = (half_t*)y;
-    const int nc8 = C >> 3;
-    if (nc8 <= 8) launch_ln<8, 1>(xp, yp, gamma, beta, rows, C, eps, s);
-    else if (nc8 <= 16) launch_ln<8, 2>(xp, yp, gamma, beta, rows, C, eps, s);
-    else if (nc8 <= 32) launch_ln<16, 2>(xp, yp, gamma, beta, rows, C, eps, s);
-    else if (nc8 <= 48) launch_ln<16, 3>(xp, yp, gamma, beta, rows, C, eps, s);
-    else if (nc8 <= 64) launch_ln<16, 4>(xp, yp, gamma, beta, rows, C, eps, s);
-    else if (nc8 <= 96) launch_ln<32, 3>(xp, yp, gamma, beta, rows, C, eps, s);
-    else if (nc8 <= 128) launch_ln<32, 4>(xp, yp, gamma, beta, rows, C, eps, s);
-    else if (nc8 <= 192) launch_ln<64, 3>(xp, yp, gamma, beta, rows, C, eps, s);
-    else if (nc8 <= 256) launch_ln<64, 4>(xp, yp, gamma, beta, rows, C, eps, s);
-    else if (nc8 <= 512) launch_ln<64, 8>(xp, yp, gamma, beta, rows, C, eps, s);
-    else launch_ln<64, 16>(xp, yp, gamma, beta, rows, C, eps, s);
+    dispatch_ln((const half_t*)x, (half_t*)y, gamma, beta, rows, C, eps, s);
     return vcx_check_launch("vcx_layernorm_f16");
+}
+
+extern "C" int vcx_rowstats_f16(const void* x, float* stats, int64_t rows, int C, float eps, void* stream) {
+    VCX_REQUIRE(x && stats, "vcx_rowstats_f16: null pointer");
+    VCX_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "vcx_rowstats_f16: need C %% 8 == 0 (C=%d)", C);
+    VCX_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)stats & 7) == 0, "vcx_rowstats_f16: x must be 16-byte, stats 8-byte aligned");
+    VCX_REQUIRE(rows < (1ll << 31) && C <= 8192, "vcx_rowstats_f16: too many rows or C > 8192");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_LN, s, 0.0, 2.0 * rows * (double)C + 8.0 * rows);
+    dispatch_ln((const half_t*)x, reinterpret_cast<half_t*>(stats), nullptr, nullptr, rows, C, eps, s);
+    return vcx_check_launch("vcx_rowstats_f16");
 }

@@ -11,11 +11,13 @@ SAME row order (Linear/LayerNorm are row-wise, so no '(b t) c h w <-> (b h w) t 
 temporal attention kernel itself walks frames with a stride of h*w rows).
 """
 import math
+import os
+
 import torch
 from torch import nn
 
 from ... import ops
-from ...packing import pack_geglu
+from ...packing import fold_layernorm, pack_geglu
 from ..common import default
 
 
@@ -25,6 +27,27 @@ def _f16(t):
 
 def _f32(t):
     return t.detach().to(torch.float32).contiguous()
+
+
+# nn.LayerNorm -> nn.Linear pairs of BasicTransformerBlock run as row statistics + ONE projection of the un-normalised token rows
+# (VCX_GEMM_LNFOLD, include/vcx.h): the normalised copy of the token stream is neither written nor re-read.  Needs the DMA GEMM
+# kernel (channel count % 64 == 0); VCX_LN_FOLD=0 keeps the separate LayerNorm kernel (A/B runs, tools/lnfold_ab.py).
+FOLD_LAYERNORM = os.environ.get("VCX_LN_FOLD", "1") != "0"
+# ... except in front of the GEGLU projection: its epilogue is arithmetic-bound (GELU) and the two extra multiply-adds per output pair
+# cost more than the LayerNorm write they save (profiles/r03_experiments.md section 8: +2.6 ... +7.5 % on the pair) - opt-in only.
+FOLD_LAYERNORM_FF = os.environ.get("VCX_LN_FOLD_FF", "0") == "1"
+
+
+def _ln_projection(w, ln, alpha=1.0, bias=None):
+    """Packed form of `Linear(w, bias)(LayerNorm(.)) * alpha` (alpha scales the product, not the layer's own bias): folded
+    (w', colsum, bias') when `ln` is given, plain fp16 weights otherwise (colsum None: the caller normalises first)."""
+    if ln is not None:
+        wf, colsum, bias_f = fold_layernorm(w, ln.weight, ln.bias, None)
+        bias_f = bias_f * alpha
+        if bias is not None:
+            bias_f = bias_f + bias.detach().float()
+        return dict(w=wf, colsum=colsum, bias=bias_f.contiguous(), eps=ln.eps)
+    return dict(w=_f16(w), colsum=None, bias=None if bias is None else _f32(bias), eps=None)
 
 
 class PackedModule(nn.Module):
@@ -87,13 +110,25 @@ class CrossAttention(PackedModule):
         if image_cross_attention:
             self.to_k_ip = nn.Linear(context_dim, inner_dim, bias=False)
             self.to_v_ip = nn.Linear(context_dim, inner_dim, bias=False)
+        self.query_dim = query_dim
+        self._pre_norm = None      # [LayerNorm] in front of the query-side projections (set by BasicTransformerBlock; a list so
+        self.kind = None           # that it is not registered as a sub-module);  kind: "spatial" | "temporal" (owner's layout)
 
     def _pack(self):
-        pk = dict(wo=_f16(self.to_out[0].weight), bo=_f32(self.to_out[0].bias), wq=_f16(self.to_q.weight),
-                  wk=_f16(self.to_k.weight), wv=_f16(self.to_v.weight))
-        if self.is_self:
-            pk["wqk"] = _f16(torch.cat([self.to_q.weight, self.to_k.weight], 0))                       # spatial
-            pk["wqkv"] = _f16(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0))    # temporal
+        """wo / bo always; the query-side projections in the form their owner launches them - spatial self-attention: Q|K as one
+        [tokens, 2D] projection carrying sqrt(scale log2 e) each + V^T; temporal: Q|K|V as one; cross-attention: Q carrying
+        scale log2 e, and K / V (+ image K / V) weights for the context side - with the preceding LayerNorm folded in where possible."""
+        pk = dict(wo=_f16(self.to_out[0].weight), bo=_f32(self.to_out[0].bias))
+        ln = self._pre_norm[0] if (self._pre_norm and FOLD_LAYERNORM and self.query_dim % 64 == 0) else None
+        wq, wk, wv = self.to_q.weight.detach(), self.to_k.weight.detach(), self.to_v.weight.detach()
+        if not self.is_self:
+            pk["q"] = _ln_projection(wq, ln, alpha=self.scale * ops.LOG2E)
+            pk["wk"], pk["wv"] = _f16(wk), _f16(wv)
+        elif self.kind == "temporal":
+            pk["qkv"] = _ln_projection(torch.cat([wq, wk, wv], 0), ln)
+        else:
+            pk["qk"] = _ln_projection(torch.cat([wq, wk], 0), ln, alpha=math.sqrt(self.scale * ops.LOG2E))
+            pk["v"] = _ln_projection(wv, ln)
         if self.image_cross_attention:
             pk["wk_ip"], pk["wv_ip"] = _f16(self.to_k_ip.weight), _f16(self.to_v_ip.weight)
         return pk
@@ -119,15 +154,25 @@ class FeedForward(PackedModule):
         inner_dim = int(dim * mult)
         dim_out = default(dim_out, dim)
         self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
+        self.dim = dim
+        self._pre_norm = None      # [LayerNorm] in front of the GEGLU projection (set by BasicTransformerBlock)
 
     def _pack(self):
-        w1, b1 = pack_geglu(self.net[0].proj.weight.detach(), self.net[0].proj.bias.detach())
-        return dict(w1=_f16(w1), b1=_f32(b1), w2=_f16(self.net[2].weight), b2=_f32(self.net[2].bias))
+        proj = self.net[0].proj
+        ln = self._pre_norm[0] if (self._pre_norm and FOLD_LAYERNORM and FOLD_LAYERNORM_FF and self.dim % 64 == 0) else None
+        p1 = _ln_projection(proj.weight.detach(), ln, bias=proj.bias)
+        w1, b1 = pack_geglu(p1["w"], p1["bias"])
+        colsum = None if p1["colsum"] is None else pack_geglu(p1["w"], p1["colsum"])[1]
+        return dict(w1=w1, b1=b1, colsum=colsum, w2=_f16(self.net[2].weight), b2=_f32(self.net[2].bias))
 
-    def run(self, x_norm, residual):
+    def run(self, t, ln_params):
+        """t + FF(LayerNorm(t)); ln_params = (gamma, beta, eps) of the LayerNorm in front (used when it is not folded into w1)."""
         pk = self.packed()
-        g = ops.linear(x_norm, pk["w1"], pk["b1"], geglu=True)
-        return ops.linear(g, pk["w2"], pk["b2"], residual=residual)
+        if pk["colsum"] is not None:
+            g = ops.linear(t, pk["w1"], pk["b1"], geglu=True, ln_stats=ops.row_stats(t, ln_params[2]), ln_colsum=pk["colsum"])
+        else:
+            g = ops.linear(ops.layer_norm(t, *ln_params), pk["w1"], pk["b1"], geglu=True)
+        return ops.linear(g, pk["w2"], pk["b2"], residual=t)
 
 
 class BasicTransformerBlock(PackedModule):
@@ -152,6 +197,15 @@ class BasicTransformerBlock(PackedModule):
         self.norm2 = nn.LayerNorm(dim)
         self.norm3 = nn.LayerNorm(dim)
         self.checkpoint = checkpoint
+        self.attn1._pre_norm, self.attn2._pre_norm, self.ff._pre_norm = [self.norm1], [self.norm2], [self.norm3]
+
+    def set_kind(self, kind):
+        self.attn1.kind = self.attn2.kind = kind
+
+    def _drop_packed(self):
+        super()._drop_packed()
+        for m in (self.attn1, self.attn2, self.ff):      # their packs hold this block's LayerNorm parameters
+            m._drop_packed()
 
     def _pack(self):
         return [(_f32(n.weight), _f32(n.bias), n.eps) for n in (self.norm1, self.norm2, self.norm3)]
@@ -207,6 +261,8 @@ class SpatialTransformer(PackedModule):
                                   video_length=video_length, image_cross_attention=image_cross_attention,
                                   image_cross_attention_scale_learnable=image_cross_attention_scale_learnable)
             for _ in range(depth)])
+        for blk in self.transformer_blocks:
+            blk.set_kind("spatial")
         self.proj_out = nn.Linear(inner_dim, in_channels)
         nn.init.zeros_(self.proj_out.weight)
         nn.init.zeros_(self.proj_out.bias)
@@ -249,18 +305,29 @@ class SpatialTransformer(PackedModule):
             ln = blk.ln_params()
             a1, a2 = blk.attn1.packed(), blk.attn2.packed()
             # ---- self-attention over the h*w tokens of each frame
-            h1 = ops.layer_norm(t, *ln[0])
             # scale * log2(e) rides in the projections (sqrt of it on Q and on K: one fp16 rounding each, as without it), so the
             # attention kernel gets base-2 logits and its running max can live in the MFMA accumulator (VCX_ATTN_LOG2_LOGITS)
-            qk = ops.linear(h1, a1["wqk"], alpha=math.sqrt(blk.attn1.scale * ops.LOG2E))   # [tokens, 2D]
-            vt = ops.gemm(a1["wv"], h1, M=D, N=tokens, K=D, lda=D)                   # [D, tokens]
+            pqk, pv, qk_alpha = a1["qk"], a1["v"], math.sqrt(blk.attn1.scale * ops.LOG2E)
+            if pqk["colsum"] is not None:      # norm1 folded into both projections: they read the token stream itself
+                st = ops.row_stats(t, ln[0][2])
+                qk = ops.linear(t, pqk["w"], pqk["bias"], alpha=qk_alpha, ln_stats=st, ln_colsum=pqk["colsum"])   # [tokens, 2D]
+                vt = ops.gemm(pv["w"], t, M=D, N=tokens, K=D, lda=D, bias=pv["bias"], bias_m=True, ln_stats=st,
+                              ln_colsum=pv["colsum"], ln_t=True)                                                    # [D, tokens]
+            else:
+                h1 = ops.layer_norm(t, *ln[0])
+                qk = ops.linear(h1, pqk["w"], alpha=qk_alpha)
+                vt = ops.gemm(pv["w"], h1, M=D, N=tokens, K=D, lda=D)
             o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
             ops.flash_attn(qk, qk[:, D:], vt, o, n_groups=n, heads=heads, nq=N, nk=N_img, kv_rows=N, kv_div=1, ldq=2 * D,
                            ldk=2 * D, ldvt=tokens, ldo=D, scale=blk.attn1.scale, log2_logits=True)
             t = ops.linear(o, a1["wo"], a1["bo"], residual=t)
             # ---- cross-attention: softmax(Q K_txt) V_txt + softmax(Q K_img) V_img
-            h2 = ops.layer_norm(t, *ln[1])
-            q2 = ops.linear(h2, a2["wq"], alpha=blk.attn2.scale * ops.LOG2E)
+            pq = a2["q"]
+            if pq["colsum"] is not None:
+                q2 = ops.linear(t, pq["w"], pq["bias"], alpha=blk.attn2.scale * ops.LOG2E, ln_stats=ops.row_stats(t, ln[1][2]),
+                                ln_colsum=pq["colsum"])
+            else:
+                q2 = ops.linear(ops.layer_norm(t, *ln[1]), pq["w"], alpha=blk.attn2.scale * ops.LOG2E)
             if bi == 0 and cfg_repeat > 1:      # from here on the r conditionings differ
                 t, q2, xin = ops.repeat_rows(t, cfg_repeat), ops.repeat_rows(q2, cfg_repeat), ops.repeat_rows(xin, cfg_repeat)
                 n, tokens = n * cfg_repeat, tokens * cfg_repeat
@@ -277,7 +344,7 @@ class SpatialTransformer(PackedModule):
                                log2_logits=True)
             t = ops.linear(o2, a2["wo"], a2["bo"], residual=t)
             # ---- feed-forward
-            t = blk.ff.run(ops.layer_norm(t, *ln[2]), t)
+            t = blk.ff.run(t, ln[2])
         out = ops.linear(t, pk["wout"], pk["bout"], residual=xin)
         if N != N_img:
             unpadded = torch.empty((n * N_img, C), dtype=torch.float16, device=x.device)
@@ -315,6 +382,8 @@ class TemporalTransformer(PackedModule):
         self.transformer_blocks = nn.ModuleList([
             BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=None,
                                   attention_cls=attention_cls, checkpoint=use_checkpoint) for _ in range(depth)])
+        for blk in self.transformer_blocks:
+            blk.set_kind("temporal")
         self.use_linear = use_linear
 
     def _pack(self):
@@ -336,11 +405,15 @@ class TemporalTransformer(PackedModule):
             ln = blk.ln_params()
             for attn, lnp in ((blk.attn1, ln[0]), (blk.attn2, ln[1])):
                 ap = attn.packed()
-                qkv = ops.linear(ops.layer_norm(t, *lnp), ap["wqkv"])                 # [tokens, 3D]
+                pj = ap["qkv"]
+                if pj["colsum"] is not None:
+                    qkv = ops.linear(t, pj["w"], pj["bias"], ln_stats=ops.row_stats(t, lnp[2]), ln_colsum=pj["colsum"])   # [tokens, 3D]
+                else:
+                    qkv = ops.linear(ops.layer_norm(t, *lnp), pj["w"])
                 o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
                 ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D, ldo=D,
                                   scale=attn.scale)
                 t = ops.linear(o, ap["wo"], ap["bo"], residual=t)
-            t = blk.ff.run(ops.layer_norm(t, *ln[2]), t)
+            t = blk.ff.run(t, ln[2])
         out = ops.linear(t, pk["wout"], pk["bout"], residual=xin)
         return out.view(B, T, P, C)

@@ -11,7 +11,7 @@ attention.py:175,187, the DDIM update ddim.py:228-279, ...) is tabulated in INTE
 import ctypes
 import torch
 
-from ._lib import (GEMM_BIAS_M, GEMM_BIAS_N, GEMM_CONV_SLABK, GEMM_GEGLU, GEMM_OUT_F32, GEMM_RESIDUAL, GEMM_ROWADD, PROF_FAMILIES,
+from ._lib import (GEMM_BIAS_M, GEMM_BIAS_N, GEMM_CONV_SLABK, GEMM_GEGLU, GEMM_LNFOLD, GEMM_LNFOLD_T, GEMM_OUT_F32, GEMM_RESIDUAL, GEMM_ROWADD, PROF_FAMILIES,
                    TUNE, GemmDesc, VcxError, check, lib)
 from .packing import conv_slab_major
 
@@ -52,9 +52,10 @@ def require_gpu():
 # GEMM / convolution
 # ------------------------------------------------------------------------------------------
 def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, residual=None, ldr=None, rowadd=None,
-         rowadd_div=0, geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None):
+         rowadd_div=0, geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None, ln_stats=None, ln_colsum=None, ln_t=False):
     """out[M, N] = epilogue(alpha * X W^T); see include/vcx.h.  `conv` = dict(in_h, in_w, out_h, out_w, cin, kh, kw,
-    stride, pad_h, pad_w, ups) switches X to the im2col gather of a channels-last image."""
+    stride, pad_h, pad_w, ups) switches X to the im2col gather of a channels-last image.  `ln_stats` (from row_stats) +
+    `ln_colsum` select the folded-LayerNorm epilogue (VCX_GEMM_LNFOLD; `ln_t`: the normalised rows are the W operand)."""
     n_out = N // 2 if geglu else N
     _dev16(a, w, residual)
     _dev32(bias, rowadd)
@@ -81,6 +82,10 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
         flags |= GEMM_GEGLU
     if out_f32:
         flags |= GEMM_OUT_F32
+    if ln_stats is not None:
+        _dev32(ln_stats, ln_colsum)
+        d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), ln_colsum.data_ptr()
+        flags |= GEMM_LNFOLD_T if ln_t else GEMM_LNFOLD
     d.lda, d.M, d.N, d.K = lda, M, N, K
     d.ldw = ldw if ldw is not None else K
     d.ldc = ldc
@@ -147,6 +152,15 @@ def group_norm(x, gamma, beta, eps, silu, groups=32, out=None):
     check(L.vcx_groupnorm_apply_f16(x.data_ptr(), out.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                     n_outer, pixels, C, groups, eps, 1 if silu else 0, s), "groupnorm_apply")
     return out
+
+
+def row_stats(x, eps=1e-5):
+    """(mean, rstd) of every row of x [rows, C] fp16 -> [rows, 2] fp32: LayerNorm's statistics for a VCX_GEMM_LNFOLD projection."""
+    rows, C = x.shape
+    _dev16(x)
+    stats = torch.empty((rows, 2), dtype=_f32, device=x.device)
+    check(lib().vcx_rowstats_f16(x.data_ptr(), stats.data_ptr(), rows, C, eps, _stream()), "rowstats")
+    return stats
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):

@@ -43,3 +43,18 @@ def pack_geglu(w, b):
     idx = torch.arange(d, device=w.device).view(-1, 32)
     perm = torch.cat([idx, idx + d], dim=1).reshape(-1)     # [x0..x31, g0..g31, x32.., ...]
     return w[perm].contiguous(), (b[perm].contiguous() if b is not None else None)
+
+
+def fold_layernorm(w, gamma, beta, bias=None):
+    """nn.LayerNorm(gamma, beta) followed by nn.Linear(w [N, K], bias) as ONE projection of the un-normalised rows
+    (VCX_GEMM_LNFOLD, include/vcx.h):  LN(x) w^T + bias = rstd (x w'^T - mean colsum) + bias'  with
+    w' = gamma o w rounded to fp16, colsum = the fp32 row sums of that ROUNDED w' (so that x w'^T - mean colsum is
+    sum_k (x_k - mean) w'_k exactly, whatever the common offset of the row), bias' = bias + w beta in fp32.
+    Returns (w' fp16, colsum fp32, bias' fp32)."""
+    w32, g32, b32 = w.detach().float(), gamma.detach().float(), beta.detach().float()
+    wf = (w32 * g32[None, :]).to(torch.float16)
+    colsum = wf.float().sum(dim=1)
+    bias_f = w32 @ b32
+    if bias is not None:
+        bias_f = bias_f + bias.detach().float()
+    return wf.contiguous(), colsum.contiguous(), bias_f.contiguous()
