@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
         // folded LayerNorm: the lane's per-row terms (LNF 1: mean, rstd of its 4 rows; LNF 2: colsum, bias' of them) are fetched
         // ahead of the tile's last K-step, so that the epilogue does not start with an exposed global-memory round trip
         [[maybe_unused]] float ln_r0[LNF ? MFRAG : 1], ln_r1[LNF ? MFRAG : 1];
-        if (LNF && ckt == nk - 1) {
+        if ((LNF == 1 || LNF == 2) && ckt == nk - 1) {
             const int mrow = p.m_begin + tile_m * TBM + wm * WM + lr;
 #pragma unroll
             for (int b = 0; b < MFRAG; ++b) {
@@ -302,6 +302,15 @@ int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) 
         vcx_set_error("vcx_gemm_f16(dma): GEGLU needs whole 64-column packed blocks per wave");
         return VCX_EINVAL;
     }
+#ifdef VCX_GN_EPI_ABLATION
+    if (conv && !geglu && !f32 && vcx_tune(VCX_TUNE_EXP0) == 1) {      // timing-only: per-column moments in the conv epilogue
+        static float* scratch = nullptr;
+        if (!scratch && hipMalloc(&scratch, (size_t)256 << 20) != hipSuccess) return VCX_ELAUNCH;
+        GemmArgs b = a;
+        b.ln_stats = scratch;
+        return launch<Cfg, true, false, false, 3>(b, s);
+    }
+#endif
     if (geglu) {
         if constexpr (Cfg::NF % 4 == 0) return conv ? launch<Cfg, true, true, false>(a, s) : launch<Cfg, false, true, false>(a, s);
         vcx_set_error("vcx_gemm_f16(dma): GEGLU needs whole 64-column packed blocks per wave");

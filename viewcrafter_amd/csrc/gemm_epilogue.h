@@ -171,8 +171,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
             }
         }
         // per-lane row terms of the folded LayerNorm: LNF 1 (rb, qb) of the lane's row in each 16-row group, LNF 2 (colsum_m, bias'_m)
-        [[maybe_unused]] float ln_a[LNF ? MFRAG : 1], ln_b[LNF ? MFRAG : 1];
-        if (LNF) {
+        constexpr bool FOLD = LNF == 1 || LNF == 2;      // (LNF 3 is the timing-only GroupNorm experiment below)
+        [[maybe_unused]] float ln_a[FOLD ? MFRAG : 1], ln_b[FOLD ? MFRAG : 1];
+        if (FOLD) {
 #pragma unroll
             for (int b = 0; b < MFRAG; ++b) {
                 if (LNF == 1) {
@@ -184,10 +185,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
                 }
             }
         }
+#ifdef VCX_GN_EPI_ABLATION
+        // TIMING-ONLY experiment (tools/gn_epilogue_ablate.py, never in libvcx.so): what per-column moments of the tile's outputs -
+        // the raw material of GroupNorm statistics "from the producing epilogue" - cost here: sum and sum of squares per column over
+        // the lane's rows, a 16-lane butterfly (4 DPP adds per value), one partial per (tile, wave, column) stored.  No shift /
+        // re-basing for robustness: a LOWER bound of the real cost.
+        float gs[LNF == 3 ? UNITS : 1][8], gq[LNF == 3 ? UNITS : 1][8];
+        if (LNF == 3) {
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gs[u][e] = gq[u][e] = 0.f;
+        }
+#endif
         int bopaque = 0;     // re-read per 16-row group (an address the compiler cannot prove loop-invariant)
         // value of accumulator fragment (a, b) with bias / addend applied (everything but the residual)
         auto finish = [&](int a, int b, float (&v)[4]) {
-            if (LNF) {
+            if (FOLD) {
                 const f4 t = *reinterpret_cast<const f4*>(sB + bopaque + a * 16 + lg * 4);
                 const f4 u = *reinterpret_cast<const f4*>(sS + bopaque + a * 16 + lg * 4);
 #pragma unroll
@@ -246,6 +260,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v0[r] += (float)r0[r]; v1[r] += (float)r1[r]; }
                 }
+#ifdef VCX_GN_EPI_ABLATION
+                if (LNF == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gs[u][r] += v0[r];
+                        gq[u][r] = __builtin_fmaf(v0[r], v0[r], gq[u][r]);
+                        gs[u][4 + r] += v1[r];
+                        gq[u][4 + r] = __builtin_fmaf(v1[r], v1[r], gq[u][4 + r]);
+                    }
+                }
+#endif
                 if (OUT_F32) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, f4{v0[0], v0[1], v0[2], v0[3]}), srd_c, voff, 0, 0);
                 } else {
@@ -266,6 +291,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
                 }
             }
         }
+#ifdef VCX_GN_EPI_ABLATION
+        if (LNF == 3) {
+            auto row_sum = [](float x) {      // sum over the 16 lanes of a DPP row (the 16 tile rows a fragment spans)
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));   // row_mirror
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));   // row_half_mirror
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+                return x;
+            };
+            float* dst = const_cast<float*>(p.ln_stats) + (((size_t)(tile_m * p.tiles_n + tile_n) * (Cfg::NWM * Cfg::NWN) + (wn * Cfg::NWM + wm)) * WN) * 2;
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u) {
+                f4 o0, o1, o2, o3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = row_sum(gs[u][e]);
+                    o1[e] = row_sum(gq[u][e]);
+                    o2[e] = row_sum(gs[u][4 + e]);
+                    o3[e] = row_sum(gq[u][4 + e]);
+                }
+                if (lr == 0) {
+                    float* d = dst + (u * 16 + lg * 4) * 4;
+                    *reinterpret_cast<f4*>(d) = o0;
+                    *reinterpret_cast<f4*>(d + 4) = o1;
+                    *reinterpret_cast<f4*>(d + 8) = o2;
+                    *reinterpret_cast<f4*>(d + 12) = o3;
+                }
+            }
+        }
+#endif
     }
 }
 
