@@ -4,7 +4,10 @@ accumulates per-column sum / sum of squares of its outputs over the tile rows, r
 partial per (tile, wave, column) - a LOWER bound of the real thing (no robust shift, no finalize kernel).  The saving side is the
 gn_stats kernel's share of the trace (profiles/r03j_kernel_stats.txt).  Convolution shapes and launch counts of one DDIM step at
 576x1024x25 from profiles/r02_gemm_shapes.txt.
-  build: see profiles/r03_experiments.md section 9;  run: python tools/gn_epilogue_ablate.py"""
+  build (from viewcrafter_amd/csrc, after `make`):
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -DVCX_GN_EPI_ABLATION -c gemm_dma.hip -o /tmp/abl/gemm_dma_gn.o
+    hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_abl/libvcx_gnepi.so build/{api,gemm,attention,attention_v2,norm,elementwise}.o /tmp/abl/gemm_dma_gn.o
+  run: python tools/gn_epilogue_ablate.py"""
 import os
 import sys
 
