@@ -362,6 +362,35 @@ def test_clip_tokenizer_contract(tmp_path, monkeypatch):
     cond._bpe_from_env.cache_clear()
 
 
+def test_fold_layernorm_is_the_exact_algebra_of_layernorm_then_linear():
+    """packing.fold_layernorm (VCX_GEMM_LNFOLD, include/vcx.h): with the ROUNDED fp16 weights w', colsum = their fp32 row sums and
+    bias' = bias + w beta,  rstd (x w'^T - mean colsum) + bias'  IS  LayerNorm(x) w^T + bias  up to the fp16 rounding of gamma o w -
+    for rows with any common offset, because x w'^T - mean colsum = sum_k (x_k - mean) w'_k term by term.  fp64 on the host."""
+    from viewcrafter_amd.packing import fold_layernorm, pack_geglu
+    g = torch.Generator().manual_seed(5)
+    K, N = 128, 96
+    w, bias = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    gamma, beta = 1 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    wf, colsum, bias_f = fold_layernorm(w, gamma, beta, bias)
+    assert wf.dtype == torch.float16 and colsum.dtype == bias_f.dtype == torch.float32
+    assert torch.equal(colsum, wf.double().sum(1).float())              # of the rounded weights, not of gamma o w
+    for offset in (0.0, 900.0):
+        x = (torch.randn(50, K, generator=g) * 8 + offset).half().double()
+        mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        folded = rstd * (x @ wf.double().t() - mean * colsum.double()) + bias_f.double()
+        exact_for_wf = ((x - mean) * rstd) @ wf.double().t() + bias_f.double()            # same weights: identical up to fp64 rounding
+        assert float((folded - exact_for_wf).abs().max()) <= 1e-6        # colsum is fp32: |mean| rstd ulp(colsum) at offset 900
+        ref = ((x - mean) * rstd * gamma.double() + beta.double()) @ w.double().t() + bias.double()
+        assert float((folded - ref).norm() / ref.norm()) <= 5e-4                          # fp16 rounding of gamma o w only
+    # GEGLU: colsum travels through pack_geglu like the bias
+    w8, b8 = torch.randn(128, K, generator=g), torch.randn(128, generator=g)
+    wf, colsum, bias_f = fold_layernorm(w8, gamma, beta, b8)
+    wp, bp = pack_geglu(wf, bias_f)
+    _, cp = pack_geglu(wf, colsum)
+    assert torch.equal(cp, wp.double().sum(1).float())
+
+
 def test_pack_conv_slab_major_order_for_64_channel_multiples():
     """cin % 64 == 0 and more than one tap: K is ordered (c / 64, tap, c % 64) - VCX_GEMM_CONV_SLABK, the order both GEMM
     kernels walk when ops.conv2d / temporal_conv3 set the flag from the same predicate."""

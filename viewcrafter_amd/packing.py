@@ -53,7 +53,7 @@ def fold_layernorm(w, gamma, beta, bias=None):
     Returns (w' fp16, colsum fp32, bias' fp32)."""
     w32, g32, b32 = w.detach().float(), gamma.detach().float(), beta.detach().float()
     wf = (w32 * g32[None, :]).to(torch.float16)
-    colsum = wf.float().sum(dim=1)
+    colsum = wf.double().sum(dim=1).float()        # exact sum of the fp16 values, rounded once
     bias_f = w32 @ b32
     if bias is not None:
         bias_f = bias_f + bias.detach().float()
