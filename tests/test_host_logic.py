@@ -380,7 +380,8 @@ def test_fold_layernorm_is_the_exact_algebra_of_layernorm_then_linear():
         rstd = 1.0 / torch.sqrt(var + 1e-5)
         folded = rstd * (x @ wf.double().t() - mean * colsum.double()) + bias_f.double()
         exact_for_wf = ((x - mean) * rstd) @ wf.double().t() + bias_f.double()            # same weights: identical up to fp64 rounding
-        assert float((folded - exact_for_wf).abs().max()) <= 1e-6        # colsum is fp32: |mean| rstd ulp(colsum) at offset 900
+        # colsum is held in fp32: the residue is |mean| rstd ulp32(colsum) / 2 ~ 900 / 8 x 6e-8 at offset 900 (fp16 output ulp: 5e-4)
+        assert float((folded - exact_for_wf).abs().max()) <= (2e-5 if offset else 1e-7)
         ref = ((x - mean) * rstd * gamma.double() + beta.double()) @ w.double().t() + bias.double()
         assert float((folded - ref).norm() / ref.norm()) <= 5e-4                          # fp16 rounding of gamma o w only
     # GEGLU: colsum travels through pack_geglu like the bias
