@@ -44,7 +44,7 @@ WORKLOADS = {
 }
 
 
-def csrc_hash(names=("gemm_dma.hip", "gemm.hip", "gemm_args.h")):
+def csrc_hash(names=("gemm_dma.hip", "gemm.hip", "gemm_args.h", "gemm_epilogue.h")):
     """sha256 over kernel sources (default: the GEMM engine): profiles/pmc_traffic.json records the hashes it was measured on."""
     import hashlib
     hsh = hashlib.sha256()

@@ -46,7 +46,7 @@ for k, (n, r, wr) in agg.items():
 if a.json:
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for name in ("gemm_dma.hip", "gemm.hip", "gemm_args.h"):
+    for name in ("gemm_dma.hip", "gemm.hip", "gemm_args.h", "gemm_epilogue.h"):
         h.update(open(os.path.join(root, "viewcrafter_amd", "csrc", name), "rb").read())
     hh = hashlib.sha256()
     for name in ("attention.hip", "attention_v2.hip"):
