@@ -32,7 +32,7 @@ extern "C" {
 #define VCX_ELAUNCH (-2)  /* HIP launch or runtime error                 */
 #define VCX_ENODEV (-3)   /* no gfx950 device                            */
 
-#define VCX_ABI_VERSION 3   /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*.  3: vcx_gemm_desc grows ln_stats / ln_colsum (VCX_GEMM_LNFOLD*), vcx_rowstats_f16 */
+#define VCX_ABI_VERSION 4   /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*.  3: vcx_gemm_desc grows ln_stats / ln_colsum (VCX_GEMM_LNFOLD*), vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32 */
 
 int vcx_abi_version(void);
 const char* vcx_last_error(void);
@@ -82,6 +82,13 @@ int vcx_device_arch(char* name_host, int len);
  *                      ln_colsum[m], bias'[m] (BIAS_M)                                                                   */
 #define VCX_GEMM_LNFOLD 0x80
 #define VCX_GEMM_LNFOLD_T 0x100
+/* GroupNorm statistics from the producing convolution: besides out, the epilogue writes colstats[M / 64][N][2] fp32 - for every
+ * 64-row strip of output rows and every output column the (mean, M2 = sum of squared deviations) of the fp16-rounded outputs,
+ * accumulated around a per-strip shift (robust to |mean| >> std).  vcx_groupnorm_stats_from_colstats_f32 merges them into the
+ * (mean, variance) pairs vcx_groupnorm_apply_f16 takes, so the GroupNorm behind the convolution (ResBlock out_layers, the norms
+ * of TemporalConvBlock: openaimodel3d.py:174-186,255-266) needs no statistics pass over the tensor.  Convolution mode with
+ * cin % 64 == 0, fp16 output, M % 64 == 0, no GEGLU. */
+#define VCX_GEMM_COLSTATS 0x200
 
 typedef struct vcx_gemm_desc {
     const void* A;        /* fp16 activations                                             */
@@ -100,6 +107,7 @@ typedef struct vcx_gemm_desc {
     float alpha;
     const float* ln_stats;  /* VCX_GEMM_LNFOLD[_T]: fp32 (mean, rstd) per normalised row            */
     const float* ln_colsum; /* VCX_GEMM_LNFOLD[_T]: fp32 row sums of the folded weight              */
+    float* colstats;        /* VCX_GEMM_COLSTATS: out, fp32 [M / 64][N][2]                          */
 } vcx_gemm_desc;
 
 int vcx_gemm_f16(const vcx_gemm_desc* desc_host, void* stream);
@@ -123,6 +131,11 @@ int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, int n_outer, 
 int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stats, const float* gamma,
                             const float* beta, int n_outer, int64_t pixels, int C, int groups,
                             float eps, int silu, void* stream);
+/* stats[n_outer][groups][2] from the column moments a VCX_GEMM_COLSTATS convolution wrote (colstats[n_outer * pixels / 64][C][2];
+ * pixels % 64 == 0): the strips and then the columns of a group are merged Chan-style in a fixed order (bit-reproducible,
+ * independent of the batch size); ws as for vcx_groupnorm_stats_f16 (vcx_groupnorm_ws_bytes). */
+int vcx_groupnorm_stats_from_colstats_f32(const float* colstats, float* stats, void* ws, int n_outer, int64_t pixels, int C,
+                                          int groups, void* stream);
 
 /* LayerNorm over the last dim (nn.LayerNorm, attention.py:226-228), fp32 statistics. */
 /* (mean, rstd) of every row, stats[rows][2] fp32: the read-only half of LayerNorm in front of a VCX_GEMM_LNFOLD projection

@@ -49,7 +49,7 @@ def test_tune_knobs_default_to_the_product_and_round_trip():
 
 def test_gemm_desc_layout_matches_header():
     """The ctypes mirror follows the C struct of include/vcx.h field by field (names and order parsed from the header; C types
-    mapped to ctypes) and in total size: 8 pointers, one int64, 21 int32, one float - 160 bytes, no padding."""
+    mapped to ctypes) and in total size: 9 pointers, one int64, 21 int32, one float - 168 bytes, no padding."""
     src = open(os.path.join(ROOT, "include", "vcx.h")).read()
     body = re.search(r"typedef struct vcx_gemm_desc \{(.*?)\} vcx_gemm_desc;", src, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
@@ -65,7 +65,7 @@ def test_gemm_desc_layout_matches_header():
             ptr = "*" in ctype or n.startswith("*")
             want.append((n.lstrip("*"), ctypes.c_void_p if ptr else {"int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "float": ctypes.c_float}[ctype]))
     assert [(f[0], f[1]) for f in _lib.GemmDesc._fields_] == want
-    assert ctypes.sizeof(_lib.GemmDesc) == 8 * 8 + 8 + 21 * 4 + 4 == 160
+    assert ctypes.sizeof(_lib.GemmDesc) == 9 * 8 + 8 + 21 * 4 + 4 == 168
 
 
 def test_argument_validation_without_gpu():

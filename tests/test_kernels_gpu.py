@@ -243,6 +243,72 @@ def test_groupnorm_large_common_offset(n, pix, C, offset, std):
     check(out, ref.float(), tol=3e-3, name="groupnorm offset")
 
 
+@pytest.mark.parametrize("kind,n,H,W,cin,cout,offset", [
+    ("3x3", 3, 16, 32, 64, 320, 0.0),            # group width 10: a lane's 4-column piece straddles two groups
+    ("3x3", 2, 8, 8, 128, 640, 0.0),             # one 64-row strip per frame
+    ("3x3", 50, 32, 64, 64, 320, 0.0),           # 400 tiles: the 256x320 configuration (+ its small-tile tail)
+    ("3x3", 2, 16, 16, 64, 1280, 0.0),
+    ("3x1", 2, 16, 8, 320, 320, 0.0),            # temporal (3,1,1) convolution, statistics per VIDEO (T x P rows)
+    ("3x3", 3, 24, 40, 64, 320, 0.0),            # M = 2880 = 45 strips: the last 128-row tile holds one strip inside M and one beyond it
+    ("3x3", 2, 16, 32, 64, 320, 100.0),          # |mean| >> std: outputs 100 +- 0.1 (fp16 spacing 0.06)
+    ("3x1", 1, 32, 8, 64, 640, -300.0)])
+def test_conv_colstats_feed_the_groupnorm_behind_it(kind, n, H, W, cin, cout, offset):
+    """VCX_GEMM_COLSTATS + vcx_groupnorm_stats_from_colstats_f32: the statistics of the GroupNorm that consumes a convolution's output,
+    from the convolution's own epilogue (reference: conv -> GroupNorm chains of ResBlock / TemporalConvBlock, openaimodel3d.py:174-186,
+    255-266).  Against fp64 statistics of the very fp16 tensor the convolution stored, and the normalised output against torch's
+    group_norm of that tensor next to the three-pass path - with residual / per-image addend in the epilogue, and with a common
+    offset 1000x the spread (the gate of test_groupnorm_large_common_offset)."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import pack_conv
+    T = 5
+    scale = 0.1 if offset else 1.0
+    if kind == "3x3":
+        x = rnd(n, H, W, cin, seed=301).to(DEV).half()
+        w = pack_conv(rnd(cout, cin, 3, 3, seed=302) * scale / math.sqrt(9 * cin)).to(DEV).half()
+        M, n_outer, pixels = n * H * W, n, H * W
+    else:
+        x = rnd(n, T, H * W, cin, seed=303).to(DEV).half()
+        w = pack_conv(rnd(cout, cin, 3, 1, 1, seed=304) * scale / math.sqrt(3 * cin)).to(DEV).half()
+        M, n_outer, pixels = n * T * H * W, n, T * H * W
+    b = (rnd(cout, seed=305) * 0.1 * scale + offset).to(DEV)
+    res = (rnd(M, cout, seed=306) * 0.5 * scale).to(DEV).half()
+    assert ops.colstats_ok(M, pixels, cin, cout)
+    guard = torch.full((M // 64 + 4, cout, 2), 7.0, device=DEV)      # the moments buffer with four sentinel strips behind it
+    cs = guard[:M // 64]
+    if kind == "3x3":
+        rowadd = (rnd(n, cout, seed=307) * 0.2 * scale).to(DEV)
+        y = ops.conv2d(x, w, b, kh=3, kw=3, residual=res, rowadd=rowadd, rowadd_div=H * W, colstats=cs).reshape(n_outer, pixels, cout)
+        y_plain = ops.conv2d(x, w, b, kh=3, kw=3, residual=res, rowadd=rowadd, rowadd_div=H * W).reshape(n_outer, pixels, cout)
+    else:
+        y = ops.temporal_conv3(x, w, b, residual=res, colstats=cs).reshape(n_outer, pixels, cout)
+        y_plain = ops.temporal_conv3(x, w, b, residual=res).reshape(n_outer, pixels, cout)
+    assert torch.equal(y, y_plain)                                  # the moments are a by-product: the output does not change
+    assert bool((guard[M // 64:] == 7.0).all()), "column moments written beyond the last strip"
+    stats = ops.group_norm_stats_from_colstats(cs, n_outer, pixels, cout)
+    yd = y.double().reshape(n_outer, pixels, 32, cout // 32)
+    mean, var = yd.mean(dim=(1, 3)), yd.var(dim=(1, 3), unbiased=False)
+    assert float((stats[..., 0].double() - mean).abs().max()) <= 2e-6 * float(mean.abs().max() + 1)
+    assert rel_l2(stats[..., 1], var) <= 2e-5, (stats[0, :4, 1], var[0, :4])
+    g = (1 + 0.2 * rnd(cout, seed=308)).to(DEV)
+    be = (0.1 * rnd(cout, seed=309)).to(DEV)
+    out = ops.group_norm(y, g, be, 1e-5, True, stats=stats)
+    three_pass = ops.group_norm(y, g, be, 1e-5, True)
+    ref = F.silu(F.group_norm(y.double().permute(0, 2, 1), 32, g.double(), be.double(), 1e-5)).permute(0, 2, 1)
+    check(out, ref.float(), tol=3e-3 if offset else 2e-3, name="groupnorm from colstats")
+    assert rel_l2(out, three_pass) <= 1e-3
+
+
+def test_conv_colstats_rejects_what_the_kernel_cannot_do():
+    from viewcrafter_amd import ops
+    from viewcrafter_amd._lib import VcxError
+    from viewcrafter_amd.packing import pack_conv
+    assert not ops.colstats_ok(2 * 9 * 16, 9 * 16, 64, 320) and not ops.colstats_ok(128, 64, 8, 320)
+    x = rnd(2, 8, 8, 8, seed=1).to(DEV).half()              # cin = 8: register-staged kernel, no column moments
+    w = pack_conv(rnd(64, 8, 3, 3, seed=2)).to(DEV).half()
+    with pytest.raises(VcxError, match="COLSTATS"):
+        ops.conv2d(x, w, None, kh=3, kw=3, colstats=ops.colstats_buffer(128, 64, DEV))
+
+
 @pytest.mark.parametrize("rows,C", [(10, 64), (1001, 320), (333, 1280), (5, 512)])
 def test_layernorm(rows, C):
     from viewcrafter_amd import ops

@@ -14,19 +14,19 @@ LIB_PATH = os.path.join(_HERE, "libvcx.so")
 # every symbol include/vcx.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
     "vcx_abi_version", "vcx_last_error", "vcx_device_arch", "vcx_gemm_f16",
-    "vcx_groupnorm_ws_bytes", "vcx_groupnorm_stats_f16", "vcx_groupnorm_apply_f16", "vcx_layernorm_f16", "vcx_rowstats_f16",
+    "vcx_groupnorm_ws_bytes", "vcx_groupnorm_stats_f16", "vcx_groupnorm_apply_f16", "vcx_groupnorm_stats_from_colstats_f32", "vcx_layernorm_f16", "vcx_rowstats_f16",
     "vcx_attn_flash_d64_f16", "vcx_attn_flash_dual_d64_f16", "vcx_attn_temporal_d64_f16", "vcx_softmax_rows_f16",
     "vcx_silu_f32", "vcx_gelu_f16", "vcx_timestep_embedding_f32", "vcx_cast_f32_to_f16", "vcx_cast_f16_to_f32",
     "vcx_copy2d_f16", "vcx_ncthw_f32_to_nthwc_f16", "vcx_nthwc_to_ncthw_f32", "vcx_ddim_step_f32", "vcx_ddim_step3_f32",
     "vcx_profile_begin", "vcx_profile_end", "vcx_tune_set", "vcx_tune_get",
 ]
 
-ABI_VERSION = 3          # include/vcx.h VCX_ABI_VERSION
+ABI_VERSION = 4          # include/vcx.h VCX_ABI_VERSION
 # experiment knobs (include/vcx.h VCX_TUNE_*): name -> (index, default)
 TUNE = {"GEMM_CFG": (0, -1), "GEMM_DMA": (1, 1), "FLASH_QB": (2, 0), "XATTN_RESIDENT": (3, 1), "FLASH_IMPL": (4, 0), "EXP0": (5, 0),
         "EXP1": (6, 0)}
 GEMM_BIAS_N, GEMM_BIAS_M, GEMM_ROWADD, GEMM_RESIDUAL, GEMM_GEGLU, GEMM_OUT_F32, GEMM_CONV_SLABK = 1, 2, 4, 8, 16, 32, 64
-GEMM_LNFOLD, GEMM_LNFOLD_T = 0x80, 0x100
+GEMM_LNFOLD, GEMM_LNFOLD_T, GEMM_COLSTATS = 0x80, 0x100, 0x200
 PROF_FAMILIES = ("gemm", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "elementwise")
 
 
@@ -38,7 +38,7 @@ class GemmDesc(ctypes.Structure):
         ("in_h", c_int32), ("in_w", c_int32), ("out_h", c_int32), ("out_w", c_int32), ("cin", c_int32),
         ("kh", c_int32), ("kw", c_int32), ("stride", c_int32), ("pad_h", c_int32), ("pad_w", c_int32),
         ("ups", c_int32), ("rowadd_div", c_int32), ("flags", c_int32), ("alpha", c_float),
-        ("ln_stats", c_void_p), ("ln_colsum", c_void_p),
+        ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("colstats", c_void_p),
     ]
 
 
@@ -75,6 +75,7 @@ def lib():
                                           c_int, c_float, c_int, c_void_p]
     L.vcx_layernorm_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]
     L.vcx_rowstats_f16.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]
+    L.vcx_groupnorm_stats_from_colstats_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]
     L.vcx_attn_flash_d64_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p]
     L.vcx_attn_flash_dual_d64_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -425,6 +425,11 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
                     "vcx_gemm_f16: LNFOLD takes BIAS_N (and GEGLU), LNFOLD_T takes BIAS_M");
         VCX_REQUIRE((lnf == 1 ? d->N : d->M) % 4 == 0 && (lnf == 1 ? d->N : d->M) >= 4, "vcx_gemm_f16: LNFOLD needs the colsum side to be a multiple of 4");
     }
+    if (flags & VCX_GEMM_COLSTATS) {
+        VCX_REQUIRE(d->colstats && ((uintptr_t)d->colstats & 15) == 0, "vcx_gemm_f16: COLSTATS needs a 16-byte aligned colstats buffer");
+        VCX_REQUIRE(conv && !geglu && !f32 && !lnf && d->M % 64 == 0 && d->N % 8 == 0,
+                    "vcx_gemm_f16: COLSTATS is for fp16 convolutions with M %% 64 == 0 and N %% 8 == 0 (M=%d N=%d)", d->M, d->N);
+    }
     if (conv) {
         VCX_REQUIRE(d->cin > 0 && d->cin % 8 == 0 && d->kh > 0 && d->kw > 0 && d->K == d->kh * d->kw * d->cin,
                     "vcx_gemm_f16: conv needs cin %% 8 == 0 and K == kh*kw*cin (cin=%d kh=%d kw=%d K=%d)", d->cin,
@@ -466,6 +471,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.m_begin = 0;
     a.ln_stats = d->ln_stats;
     a.ln_colsum = d->ln_colsum;
+    a.colstats = d->colstats;
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * (double)d->N * d->K;
     const double bytes = 2.0 * ((double)d->M * d->K / (conv ? d->kh * d->kw : 1) + (double)d->N * d->K + (double)d->M * d->N);
@@ -529,6 +535,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
         }
         return cfg >= 2 ? big(a, cfg) : launch_dma(a, cfg, conv, geglu, f32, s);
     }
+    VCX_REQUIRE(!(flags & VCX_GEMM_COLSTATS), "vcx_gemm_f16: COLSTATS needs the DMA kernel (cin %% 64 == 0, extents < 4 GiB); cin=%d", d->cin);
     VCX_REQUIRE(!lnf, "vcx_gemm_f16: LNFOLD needs the DMA kernel (K %% 64 == 0, N %% 8 == 0, extents < 4 GiB); K=%d N=%d", d->K, d->N);
     return use160 ? dispatch<160>(a, conv, geglu, f32, s) : dispatch<128>(a, conv, geglu, f32, s);
 }

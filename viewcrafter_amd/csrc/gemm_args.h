@@ -28,6 +28,7 @@ struct GemmArgs {
     int m_begin;   // first output row of this launch (tail split of large-tile launches); rows are < M
     const float* ln_stats;    // VCX_GEMM_LNFOLD[_T]: (mean, rstd) pairs
     const float* ln_colsum;   // VCX_GEMM_LNFOLD[_T]: row sums of the folded weight
+    float* colstats;          // VCX_GEMM_COLSTATS: (mean, M2) per 64-row strip and output column
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {

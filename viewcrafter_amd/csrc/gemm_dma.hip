@@ -46,8 +46,8 @@ struct TileCfg {
     static constexpr size_t SMEM_LNF = STAGES + 2 * STRIP;                        // + a second strip (folded-LayerNorm epilogue)
 };
 
-// LNF: 0 = plain epilogue, 1 = VCX_GEMM_LNFOLD, 2 = VCX_GEMM_LNFOLD_T (linear mode only; separate instantiations, so the
-// convolution and plain kernels keep their register allocation)
+// LNF: 0 = plain epilogue, 1 = VCX_GEMM_LNFOLD, 2 = VCX_GEMM_LNFOLD_T (linear mode only), 3 = VCX_GEMM_COLSTATS (convolutions only);
+// separate instantiations, so the plain kernels keep their register allocation
 template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32, int LNF = 0>
 __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the body uses device-only types)
@@ -302,15 +302,7 @@ int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) 
         vcx_set_error("vcx_gemm_f16(dma): GEGLU needs whole 64-column packed blocks per wave");
         return VCX_EINVAL;
     }
-#ifdef VCX_GN_EPI_ABLATION
-    if (conv && !geglu && !f32 && vcx_tune(VCX_TUNE_EXP0) == 1) {      // timing-only: per-column moments in the conv epilogue
-        static float* scratch = nullptr;
-        if (!scratch && hipMalloc(&scratch, (size_t)256 << 20) != hipSuccess) return VCX_ELAUNCH;
-        GemmArgs b = a;
-        b.ln_stats = scratch;
-        return launch<Cfg, true, false, false, 3>(b, s);
-    }
-#endif
+    if (a.flags & VCX_GEMM_COLSTATS) return launch<Cfg, true, false, false, 3>(a, s);      // convolution, fp16 output (checked by vcx_gemm_f16)
     if (geglu) {
         if constexpr (Cfg::NF % 4 == 0) return conv ? launch<Cfg, true, true, false>(a, s) : launch<Cfg, false, true, false>(a, s);
         vcx_set_error("vcx_gemm_f16(dma): GEGLU needs whole 64-column packed blocks per wave");

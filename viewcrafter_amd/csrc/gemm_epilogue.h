@@ -171,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
             }
         }
         // per-lane row terms of the folded LayerNorm: LNF 1 (rb, qb) of the lane's row in each 16-row group, LNF 2 (colsum_m, bias'_m)
-        constexpr bool FOLD = LNF == 1 || LNF == 2;      // (LNF 3 is the timing-only GroupNorm experiment below)
+        constexpr bool FOLD = LNF == 1 || LNF == 2;      // (LNF 3 = VCX_GEMM_COLSTATS, below)
         [[maybe_unused]] float ln_a[FOLD ? MFRAG : 1], ln_b[FOLD ? MFRAG : 1];
         if (FOLD) {
 #pragma unroll
@@ -185,19 +185,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
                 }
             }
         }
-#ifdef VCX_GN_EPI_ABLATION
-        // TIMING-ONLY experiment (tools/gn_epilogue_ablate.py, never in libvcx.so): what per-column moments of the tile's outputs -
-        // the raw material of GroupNorm statistics "from the producing epilogue" - cost here: sum and sum of squares per column over
-        // the lane's rows, a 16-lane butterfly (4 DPP adds per value), one partial per (tile, wave, column) stored.  No shift /
-        // re-basing for robustness: a LOWER bound of the real cost.
-        float gs[LNF == 3 ? UNITS : 1][8], gq[LNF == 3 ? UNITS : 1][8];
+        // LNF 3 (VCX_GEMM_COLSTATS): moments of the tile's OUTPUT columns for the GroupNorm that consumes them - per lane and column the
+        // sum and sum of squares of (value - shift) over the lane's four rows, the shift being the first value of the lane's
+        // 4-column piece in the first row of the wave's strip (uniform over the strip's rows: read with a row-share DPP), so
+        // that rows whose common offset dwarfs their spread keep their digits (test_groupnorm_large_common_offset).  The values
+        // are the fp16-ROUNDED outputs, the numbers the apply pass will read.
+        [[maybe_unused]] float gs[LNF == 3 ? UNITS : 1][8], gq[LNF == 3 ? UNITS : 1][8], gk[LNF == 3 ? UNITS : 1][2];
         if (LNF == 3) {
 #pragma unroll
             for (int u = 0; u < UNITS; ++u)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gs[u][e] = gq[u][e] = 0.f;
         }
-#endif
         int bopaque = 0;     // re-read per 16-row group (an address the compiler cannot prove loop-invariant)
         // value of accumulator fragment (a, b) with bias / addend applied (everything but the residual)
         auto finish = [&](int a, int b, float (&v)[4]) {
@@ -260,24 +259,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v0[r] += (float)r0[r]; v1[r] += (float)r1[r]; }
                 }
-#ifdef VCX_GN_EPI_ABLATION
+                // the fp16 values that are stored (converted once: the column moments below are taken of exactly these numbers)
+                [[maybe_unused]] const h4 o0 = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]};
+                [[maybe_unused]] const h4 o1 = {(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
                 if (LNF == 3) {
+                    float w0[4], w1[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        gs[u][r] += v0[r];
-                        gq[u][r] = __builtin_fmaf(v0[r], v0[r], gq[u][r]);
-                        gs[u][4 + r] += v1[r];
-                        gq[u][4 + r] = __builtin_fmaf(v1[r], v1[r], gq[u][4 + r]);
+                        w0[r] = (float)o0[r];
+                        w1[r] = (float)o1[r];
+                    }
+                    if (b == 0) {       // lane lr = 0 of the DPP row holds the strip's first row: its value is everybody's shift
+                        gk[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w0[0]), 0x150, 0xf, 0xf, true));
+                        gk[u][1] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w1[0]), 0x150, 0xf, 0xf, true));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d0 = w0[r] - gk[u][0], d1 = w1[r] - gk[u][1];
+                        gs[u][r] += d0;
+                        gq[u][r] = __builtin_fmaf(d0, d0, gq[u][r]);
+                        gs[u][4 + r] += d1;
+                        gq[u][4 + r] = __builtin_fmaf(d1, d1, gq[u][4 + r]);
                     }
                 }
-#endif
                 if (OUT_F32) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, f4{v0[0], v0[1], v0[2], v0[3]}), srd_c, voff, 0, 0);
                 } else {
-                    const h4 o0 = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]};
                     const u2v p0 = __builtin_bit_cast(u2v, o0);
                     if (wide) {
-                        const h4 o1 = {(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
                         const u2v p1 = __builtin_bit_cast(u2v, o1);
                         const unsigned a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1];
                         // vdst = fragment a, src = fragment a + 1: even lanes end up with [own a | odd lane's a],
@@ -291,36 +300,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
                 }
             }
         }
-#ifdef VCX_GN_EPI_ABLATION
         if (LNF == 3) {
-            auto row_sum = [](float x) {      // sum over the 16 lanes of a DPP row (the 16 tile rows a fragment spans)
+            auto row_sum = [](float x) {      // sum over the 16 lanes of a DPP row (the 16 tile rows a fragment spans), same value in all of them
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));   // row_mirror
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));   // row_half_mirror
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
                 return x;
             };
-            float* dst = const_cast<float*>(p.ln_stats) + (((size_t)(tile_m * p.tiles_n + tile_n) * (Cfg::NWM * Cfg::NWN) + (wn * Cfg::NWM + wm)) * WN) * 2;
+            // one (mean, M2) pair per 64-row strip and column: colstats[strip][N][2], strip = first row of the wave's rows / 64
+            const int strip = (p.m_begin + tile_m * TBM + wm * WM) >> 6;
+            float* dst = p.colstats + ((size_t)strip * p.N + nstrip) * 2;
 #pragma unroll
             for (int u = 0; u < UNITS; ++u) {
-                f4 o0, o1, o2, o3;
+                float mo[8], qo[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o0[e] = row_sum(gs[u][e]);
-                    o1[e] = row_sum(gq[u][e]);
-                    o2[e] = row_sum(gs[u][4 + e]);
-                    o3[e] = row_sum(gq[u][4 + e]);
+                for (int e = 0; e < 8; ++e) {
+                    const float s1 = row_sum(gs[u][e]), s2 = row_sum(gq[u][e]);
+                    mo[e] = gk[u][e >> 2] + s1 * (1.0f / 64.0f);
+                    qo[e] = __builtin_fmaf(-s1 * (1.0f / 64.0f), s1, s2);
                 }
-                if (lr == 0) {
-                    float* d = dst + (u * 16 + lg * 4) * 4;
-                    *reinterpret_cast<f4*>(d) = o0;
-                    *reinterpret_cast<f4*>(d + 4) = o1;
-                    *reinterpret_cast<f4*>(d + 8) = o2;
-                    *reinterpret_cast<f4*>(d + 12) = o3;
+                if (lr == 0 && strip * 64 < p.M) {     // (a tile's last strips may lie beyond M: M is a multiple of 64, not of the tile height)
+                    const bool wide = u < NPAIRF;
+                    const int c0 = wide ? (2 * u) * 16 + lg * 4 : (2 * NPAIRF + (u - NPAIRF)) * 16 + lg * 4;
+                    if (nstrip + c0 < p.N) {
+                        *reinterpret_cast<f4*>(dst + c0 * 2) = f4{mo[0], qo[0], mo[1], qo[1]};
+                        *reinterpret_cast<f4*>(dst + c0 * 2 + 4) = f4{mo[2], qo[2], mo[3], qo[3]};
+                    }
+                    if (wide && nstrip + c0 + 16 < p.N) {
+                        *reinterpret_cast<f4*>(dst + (c0 + 16) * 2) = f4{mo[4], qo[4], mo[5], qo[5]};
+                        *reinterpret_cast<f4*>(dst + (c0 + 16) * 2 + 4) = f4{mo[6], qo[6], mo[7], qo[7]};
+                    }
                 }
             }
         }
-#endif
     }
 }
 

@@ -332,7 +332,64 @@ int64_t pick_pix_per_block(int n_outer, int64_t pixels) {
     return ppb;
 }
 
+// ---------------------------------------------------------------------------------------
+// GroupNorm statistics from column moments (VCX_GEMM_COLSTATS): colstats[n * strips + s][C] = (mean, M2) of 64 values each.  A block
+// takes `spb` consecutive strips of one n and ALL columns (thread = column: coalesced 8-byte reads, 16 loads in flight), folds the
+// strips of a column in order (gn_merge, equal counts), then the columns of each group in order, and writes (count, mean, M2) per
+// (n, chunk, group) in gn_stats_kernel's layout - the same finalize kernels then merge the chunks.  No atomics: bit-reproducible and
+// independent of the batch size.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_colstats_partials_kernel(const float2* __restrict__ cs, float* __restrict__ partials, int64_t strips,
+                                                                   int C, int groups, int spb) {
+    extern __shared__ float red[];                      // [C][3]
+    const int n = blockIdx.y;
+    const int64_t s0 = (int64_t)blockIdx.x * spb, s1 = (s0 + spb < strips) ? s0 + spb : strips;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float2* src = cs + ((int64_t)n * strips) * C + c;
+        float na = 0.f, a = 0.f, q = 0.f;
+        for (int64_t sb = s0; sb < s1; sb += 16) {
+            float2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[(sb + u < s1 ? sb + u : s1 - 1) * C];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) gn_merge(na, a, q, sb + u < s1 ? 64.f : 0.f, v[u].x, sb + u < s1 ? v[u].y : 0.f);
+        }
+        red[c * 3] = na; red[c * 3 + 1] = a; red[c * 3 + 2] = q;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+        const int cpg = C / groups, c0 = threadIdx.x * cpg;
+        float na = red[c0 * 3], a = red[c0 * 3 + 1], q = red[c0 * 3 + 2];
+        for (int c = c0 + 1; c < c0 + cpg; ++c) gn_merge(na, a, q, red[c * 3], red[c * 3 + 1], red[c * 3 + 2]);
+        float* dst = partials + (((int64_t)n * gridDim.x + blockIdx.x) * groups + threadIdx.x) * 3;
+        dst[0] = na; dst[1] = a; dst[2] = q;
+    }
+}
+
 }  // namespace
+
+extern "C" int vcx_groupnorm_stats_from_colstats_f32(const float* colstats, float* stats, void* ws, int n_outer, int64_t pixels, int C,
+                                                     int groups, void* stream) {
+    VCX_REQUIRE(colstats && stats && ws, "vcx_groupnorm_stats_from_colstats_f32: null pointer");
+    VCX_REQUIRE(n_outer > 0 && n_outer <= 65535 && pixels > 0 && pixels % 64 == 0 && C > 0 && C <= MAXC && groups > 0 && groups <= 64 && C % groups == 0,
+                "vcx_groupnorm_stats_from_colstats_f32: need pixels %% 64 == 0, C %% groups == 0, groups <= 64 (pixels=%lld C=%d groups=%d)",
+                (long long)pixels, C, groups);
+    VCX_REQUIRE(((uintptr_t)colstats & 7) == 0 && ((uintptr_t)ws & 3) == 0, "vcx_groupnorm_stats_from_colstats_f32: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_GN, s, 0.0, 8.0 * n_outer * (double)(pixels / 64) * C);
+    const int64_t strips = pixels / 64;
+    // <= 1024 chunks per n (the workspace of vcx_groupnorm_ws_bytes), a function of `pixels` only: same bits for any batch size
+    int64_t spb = (strips + 1023) / 1024;
+    if (spb < 16) spb = 16;
+    const int chunks = (int)((strips + spb - 1) / spb);
+    hipLaunchKernelGGL(gn_colstats_partials_kernel, dim3((unsigned)chunks, (unsigned)n_outer), dim3(256), sizeof(float) * 3 * (size_t)C, s,
+                       reinterpret_cast<const float2*>(colstats), (float*)ws, strips, C, groups, (int)spb);
+    int rc = vcx_check_launch("vcx_groupnorm_stats_from_colstats_f32");
+    if (rc) return rc;
+    if (chunks <= 64) hipLaunchKernelGGL(gn_finalize_small_kernel, dim3(n_outer), dim3(256), 0, s, (const float*)ws, stats, chunks, groups);
+    else hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_outer * groups), dim3(64), 0, s, (const float*)ws, stats, chunks, groups);
+    return vcx_check_launch("vcx_groupnorm_stats_from_colstats_f32(finalize)");
+}
 
 extern "C" size_t vcx_groupnorm_ws_bytes(int n_outer, int64_t pixels, int groups) {
     if (n_outer <= 0 || pixels <= 0 || groups <= 0) return 0;

@@ -13,12 +13,18 @@ MI355X-first differences from the reference implementation (none changes the res
   * cond/uncond (CFG) run as one B=2 forward, halving weight traffic.
 There is no PyTorch compute fallback: without libvcx.so and a gfx950 device forward() raises.
 """
+import os
+
 import torch
 from torch import nn
 
 from .... import ops
 from ....packing import pack_conv
 from ..attention import PackedModule, SpatialTransformer, TemporalTransformer, _f16, _f32
+
+# GroupNorm statistics from the producing convolution's epilogue where the chain allows it (ResBlock / TemporalConvBlock);
+# VCX_GN_EPILOGUE_STATS=0 keeps the statistics pass over the tensor everywhere (A/B runs).
+GN_EPILOGUE_STATS = os.environ.get("VCX_GN_EPILOGUE_STATS", "1") != "0"
 
 
 class TimestepBlock(nn.Module):
@@ -118,15 +124,21 @@ class TemporalConvBlock(PackedModule):
             out.append((_f32(gn.weight), _f32(gn.bias), gn.eps, _f16(pack_conv(conv.weight.detach())), _f32(conv.bias)))
         return out
 
-    def forward(self, x):
-        """x [B, T, P, C] fp16."""
+    def forward(self, x, colstats=None):
+        """x [B, T, P, C] fp16.  `colstats`: column moments of x written by the convolution that produced it (ops.gemm colstats=):
+        the first norm then needs no statistics pass; the three inner norms get theirs from this block's own convolutions."""
         B, T, P, C = x.shape
         y = x
         stages = self.packed()
         for i, (gw, gb, eps, w, b) in enumerate(stages):
-            a = ops.group_norm(y.reshape(B, T * P, y.shape[-1]), gw, gb, eps, True)
+            cy = y.shape[-1]
+            stats = None if colstats is None else ops.group_norm_stats_from_colstats(colstats, B, T * P, cy)
+            a = ops.group_norm(y.reshape(B, T * P, cy), gw, gb, eps, True, stats=stats)
             last = i == len(stages) - 1
-            y = ops.temporal_conv3(a.view(B, T, P, -1), w, b, residual=x.reshape(B * T * P, C) if last else None)
+            cout = w.shape[0]
+            colstats = (ops.colstats_buffer(B * T * P, cout, x.device)
+                        if (GN_EPILOGUE_STATS and not last and ops.colstats_ok(B * T * P, T * P, cy, cout)) else None)
+            y = ops.temporal_conv3(a.view(B, T, P, -1), w, b, residual=x.reshape(B * T * P, C) if last else None, colstats=colstats)
         return y
 
 
@@ -176,15 +188,24 @@ class ResBlock(PackedModule, TimestepBlock):
         B = emb.shape[0]
         a = ops.group_norm(x.view(n, H * W, cin), *pk["g1"], True)
         emb_out = ops.linear(emb, pk["we"], pk["be"], out_f32=True)                           # [B, Cout] fp32
-        h = ops.conv2d(a.view(n, H, W, cin), pk["w1"], pk["b1"], kh=3, kw=3, rowadd=emb_out, rowadd_div=(n // B) * H * W)
-        a = ops.group_norm(h.view(n, H * W, cout), *pk["g2"], True)
+        # The norms behind this block's own convolutions take their statistics from those convolutions' epilogues (column moments
+        # per 64-row strip, VCX_GEMM_COLSTATS) instead of a pass over the tensor: out_layers' norm (per frame) from conv 1, the
+        # first norm of the temporal block (per video) from conv 2 - where frames are whole strips (not at 9x16 = 144 pixels).
+        M = n * H * W
+        cs1 = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and ops.colstats_ok(M, H * W, cin, cout)) else None
+        h = ops.conv2d(a.view(n, H, W, cin), pk["w1"], pk["b1"], kh=3, kw=3, rowadd=emb_out, rowadd_div=(n // B) * H * W, colstats=cs1)
+        stats = None if cs1 is None else ops.group_norm_stats_from_colstats(cs1, n, H * W, cout)
+        a = ops.group_norm(h.view(n, H * W, cout), *pk["g2"], True, stats=stats)
         if "ws" in pk:
             skip = ops.conv2d(x, pk["ws"], pk["bs"], kh=1, kw=1).view(n * H * W, cout)
         else:
             skip = x.reshape(n * H * W, cout)
-        h = ops.conv2d(a.view(n, H, W, cout), pk["w2"], pk["b2"], kh=3, kw=3, residual=skip)
-        if self.use_temporal_conv and batch_size:
-            h = self.temopral_conv(h.view(batch_size, n // batch_size, H * W, cout)).view(n, H, W, cout)
+        temporal = self.use_temporal_conv and batch_size
+        cs2 = (ops.colstats_buffer(M, cout, x.device)
+               if (GN_EPILOGUE_STATS and temporal and ops.colstats_ok(M, (n // batch_size) * H * W, cout, cout)) else None)
+        h = ops.conv2d(a.view(n, H, W, cout), pk["w2"], pk["b2"], kh=3, kw=3, residual=skip, colstats=cs2)
+        if temporal:
+            h = self.temopral_conv(h.view(batch_size, n // batch_size, H * W, cout), colstats=cs2).view(n, H, W, cout)
         return h
 
 

@@ -11,7 +11,7 @@ attention.py:175,187, the DDIM update ddim.py:228-279, ...) is tabulated in INTE
 import ctypes
 import torch
 
-from ._lib import (GEMM_BIAS_M, GEMM_BIAS_N, GEMM_CONV_SLABK, GEMM_GEGLU, GEMM_LNFOLD, GEMM_LNFOLD_T, GEMM_OUT_F32, GEMM_RESIDUAL, GEMM_ROWADD, PROF_FAMILIES,
+from ._lib import (GEMM_BIAS_M, GEMM_BIAS_N, GEMM_COLSTATS, GEMM_CONV_SLABK, GEMM_GEGLU, GEMM_LNFOLD, GEMM_LNFOLD_T, GEMM_OUT_F32, GEMM_RESIDUAL, GEMM_ROWADD, PROF_FAMILIES,
                    TUNE, GemmDesc, VcxError, check, lib)
 from .packing import conv_slab_major
 
@@ -52,10 +52,12 @@ def require_gpu():
 # GEMM / convolution
 # ------------------------------------------------------------------------------------------
 def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, residual=None, ldr=None, rowadd=None,
-         rowadd_div=0, geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None, ln_stats=None, ln_colsum=None, ln_t=False):
+         rowadd_div=0, geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None, ln_stats=None, ln_colsum=None, ln_t=False, colstats=None):
     """out[M, N] = epilogue(alpha * X W^T); see include/vcx.h.  `conv` = dict(in_h, in_w, out_h, out_w, cin, kh, kw,
     stride, pad_h, pad_w, ups) switches X to the im2col gather of a channels-last image.  `ln_stats` (from row_stats) +
-    `ln_colsum` select the folded-LayerNorm epilogue (VCX_GEMM_LNFOLD; `ln_t`: the normalised rows are the W operand)."""
+    `ln_colsum` select the folded-LayerNorm epilogue (VCX_GEMM_LNFOLD; `ln_t`: the normalised rows are the W operand).
+    `colstats` (fp32 [M / 64, N, 2], see colstats_buffer) makes a convolution write the column moments of its output for the
+    GroupNorm behind it (VCX_GEMM_COLSTATS)."""
     n_out = N // 2 if geglu else N
     _dev16(a, w, residual)
     _dev32(bias, rowadd)
@@ -86,6 +88,12 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
         _dev32(ln_stats, ln_colsum)
         d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), ln_colsum.data_ptr()
         flags |= GEMM_LNFOLD_T if ln_t else GEMM_LNFOLD
+    if colstats is not None:
+        _dev32(colstats)
+        if colstats.numel() != (M // 64) * n_out * 2:
+            raise VcxError(f"colstats must hold [M / 64, N, 2] floats (M={M}, N={n_out}), got {tuple(colstats.shape)}")
+        d.colstats = colstats.data_ptr()
+        flags |= GEMM_COLSTATS
     d.lda, d.M, d.N, d.K = lda, M, N, K
     d.ldw = ldw if ldw is not None else K
     d.ldc = ldc
@@ -137,16 +145,44 @@ def temporal_conv3(x, w, bias, **kwargs):
 # ------------------------------------------------------------------------------------------
 # normalisation
 # ------------------------------------------------------------------------------------------
-def group_norm(x, gamma, beta, eps, silu, groups=32, out=None):
-    """x [n_outer, pixels, C] fp16 (contiguous).  Statistics over (pixels, C/groups)."""
+def colstats_ok(M, pixels, cin, cout, in_rows=None):
+    """Can the convolution producing an [M, cout] output from a cin-channel image write column moments for a GroupNorm whose
+    statistics span `pixels` consecutive output rows?  (VCX_GEMM_COLSTATS: DMA kernel - cin % 64 == 0, cout % 8 == 0, 32-bit byte
+    offsets - whole 64-row strips per statistics unit.)"""
+    lim = 0xFFFF0000
+    return (pixels % 64 == 0 and M % 64 == 0 and cin % 64 == 0 and cout % 8 == 0 and 2 * (M + 256) * cout < lim
+            and 2 * (in_rows if in_rows is not None else M) * cin < lim)
+
+
+def colstats_buffer(M, cout, device):
+    return torch.empty((M // 64, cout, 2), dtype=_f32, device=device)
+
+
+def group_norm_stats_from_colstats(colstats, n_outer, pixels, C, groups=32):
+    """(mean, variance) per (n, group) from the column moments a colstats= convolution wrote: what group_norm(stats=) takes."""
+    _dev32(colstats)
+    stats = torch.empty((n_outer, groups, 2), dtype=_f32, device=colstats.device)
+    L = lib()
+    ws = torch.empty((L.vcx_groupnorm_ws_bytes(n_outer, pixels, groups),), dtype=torch.uint8, device=colstats.device)
+    check(L.vcx_groupnorm_stats_from_colstats_f32(colstats.data_ptr(), stats.data_ptr(), ws.data_ptr(), n_outer, pixels, C, groups, _stream()),
+          "groupnorm_stats_from_colstats")
+    return stats
+
+
+def group_norm(x, gamma, beta, eps, silu, groups=32, out=None, stats=None):
+    """x [n_outer, pixels, C] fp16 (contiguous).  Statistics over (pixels, C/groups) - computed here, or handed in (`stats`
+    [n_outer, groups, 2] = (mean, variance), from group_norm_stats_from_colstats)."""
     n_outer, pixels, C = x.shape
     _dev16(x, out)
     _dev32(gamma, beta)
-    stats = torch.empty((n_outer, groups, 2), dtype=_f32, device=x.device)
     L = lib()
     s = _stream()
-    ws = torch.empty((L.vcx_groupnorm_ws_bytes(n_outer, pixels, groups),), dtype=torch.uint8, device=x.device)
-    check(L.vcx_groupnorm_stats_f16(x.data_ptr(), stats.data_ptr(), ws.data_ptr(), n_outer, pixels, C, groups, s), "groupnorm_stats")
+    if stats is None:
+        stats = torch.empty((n_outer, groups, 2), dtype=_f32, device=x.device)
+        ws = torch.empty((L.vcx_groupnorm_ws_bytes(n_outer, pixels, groups),), dtype=torch.uint8, device=x.device)
+        check(L.vcx_groupnorm_stats_f16(x.data_ptr(), stats.data_ptr(), ws.data_ptr(), n_outer, pixels, C, groups, s), "groupnorm_stats")
+    else:
+        _dev32(stats)
     if out is None:
         out = torch.empty_like(x)
     check(L.vcx_groupnorm_apply_f16(x.data_ptr(), out.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
