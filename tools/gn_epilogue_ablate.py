@@ -1,13 +1,8 @@
-"""Timing-only ablation: what would GroupNorm statistics "from the producing epilogue" cost the convolutions?
-tools/_abl/libvcx_gnepi.so = libvcx with gemm_dma.hip built -DVCX_GN_EPI_ABLATION: with knob EXP0 = 1 every fp16 convolution
-accumulates per-column sum / sum of squares of its outputs over the tile rows, reduces them over the 16-lane rows (DPP) and stores one
-partial per (tile, wave, column) - a LOWER bound of the real thing (no robust shift, no finalize kernel).  The saving side is the
-gn_stats kernel's share of the trace (profiles/r03j_kernel_stats.txt).  Convolution shapes and launch counts of one DDIM step at
-576x1024x25 from profiles/r02_gemm_shapes.txt.
-  build (from viewcrafter_amd/csrc, after `make`):
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -DVCX_GN_EPI_ABLATION -c gemm_dma.hip -o /tmp/abl/gemm_dma_gn.o
-    hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_abl/libvcx_gnepi.so build/{api,gemm,attention,attention_v2,norm,elementwise}.o /tmp/abl/gemm_dma_gn.o
-  run: python tools/gn_epilogue_ablate.py"""
+"""What do GroupNorm column moments in the convolution epilogue (VCX_GEMM_COLSTATS) cost the convolutions?  Every 3x3 / (3,1,1)
+convolution shape of one DDIM step at 576x1024x25 (launch counts from profiles/r02_gemm_shapes.txt) with and without `colstats=`,
+interleaved in one process.  (profiles/r03s_gn_epilogue_ablate.txt was taken with the timing-only precursor of the feature: plain
+sums without the robust shift, built -DVCX_GN_EPI_ABLATION into a side library; the shipped epilogue replaced that code.)
+  python tools/gn_epilogue_ablate.py"""
 import os
 import sys
 
@@ -15,8 +10,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from viewcrafter_amd import _lib  # noqa: E402
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "_abl", "libvcx_gnepi.so")
 from viewcrafter_amd import ops  # noqa: E402
 from viewcrafter_amd.packing import pack_conv  # noqa: E402
 
@@ -46,20 +39,20 @@ def main():
             x = torch.randn(n, H, W, cin, device=DEV).half()
             w = pack_conv(torch.randn(cout, cin, 3, 3, device=DEV) / (3 * cin ** 0.5)).half()
             b = torch.randn(cout, device=DEV) * 0.1
-            run = lambda: ops.conv2d(x, w, b, kh=3, kw=3)
+            cs = ops.colstats_buffer(n * H * W, cout, DEV)
+            run = lambda k=0: ops.conv2d(x, w, b, kh=3, kw=3, colstats=cs if k else None)
         else:
             x = torch.randn(n, 25, H * W, cin, device=DEV).half()
             w = pack_conv(torch.randn(cout, cin, 3, 1, 1, device=DEV) / (3 * cin) ** 0.5).half()
             b = torch.randn(cout, device=DEV) * 0.1
-            run = lambda: ops.temporal_conv3(x, w, b)
+            cs = ops.colstats_buffer(n * 25 * H * W, cout, DEV)
+            run = lambda k=0: ops.temporal_conv3(x, w, b, colstats=cs if k else None)
         res = {0: [], 1: []}
         for rep in range(3):
             for k in (0, 1):
-                ops.tune_set("EXP0", k)
-                run()
+                run(k)
                 torch.cuda.synchronize()
-                res[k].append(timed(run, 6))
-        ops.tune_set("EXP0", 0)
+                res[k].append(timed(lambda: run(k), 6))
         t0, t1 = sorted(res[0])[1], sorted(res[1])[1]
         tot[0] += t0 * count
         tot[1] += t1 * count
