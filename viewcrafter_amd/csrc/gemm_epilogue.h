@@ -259,16 +259,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v0[r] += (float)r0[r]; v1[r] += (float)r1[r]; }
                 }
-                // the fp16 values that are stored (converted once: the column moments below are taken of exactly these numbers)
+                // the fp16 values that are stored; the column moments below are taken of exactly these numbers
                 [[maybe_unused]] const h4 o0 = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]};
                 [[maybe_unused]] const h4 o1 = {(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
+                [[maybe_unused]] u2v pk0 = __builtin_bit_cast(u2v, o0), pk1 = __builtin_bit_cast(u2v, o1);
                 if (LNF == 3) {
-                    float w0[4], w1[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        w0[r] = (float)o0[r];
-                        w1[r] = (float)o1[r];
-                    }
+                    // read the halves back out of the PACKED words (opaque to the optimiser: otherwise it keeps a second, scalar
+                    // f32 -> f16 conversion per element beside the packed one that feeds the store)
+                    unsigned q0 = pk0[0], q1 = pk0[1], q2 = pk1[0], q3 = pk1[1];
+                    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+                    pk0 = u2v{q0, q1};
+                    pk1 = u2v{q2, q3};
+                    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                    const h2v a01 = __builtin_bit_cast(h2v, q0), a23 = __builtin_bit_cast(h2v, q1);
+                    const h2v b01 = __builtin_bit_cast(h2v, q2), b23 = __builtin_bit_cast(h2v, q3);
+                    const float w0[4] = {(float)a01[0], (float)a01[1], (float)a23[0], (float)a23[1]};
+                    const float w1[4] = {(float)b01[0], (float)b01[1], (float)b23[0], (float)b23[1]};
                     if (b == 0) {       // lane lr = 0 of the DPP row holds the strip's first row: its value is everybody's shift
                         gk[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w0[0]), 0x150, 0xf, 0xf, true));
                         gk[u][1] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w1[0]), 0x150, 0xf, 0xf, true));
@@ -285,9 +291,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
                 if (OUT_F32) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, f4{v0[0], v0[1], v0[2], v0[3]}), srd_c, voff, 0, 0);
                 } else {
-                    const u2v p0 = __builtin_bit_cast(u2v, o0);
+                    const u2v p0 = pk0;
                     if (wide) {
-                        const u2v p1 = __builtin_bit_cast(u2v, o1);
+                        const u2v p1 = pk1;
                         const unsigned a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1];
                         // vdst = fragment a, src = fragment a + 1: even lanes end up with [own a | odd lane's a],
                         // odd lanes with [even lane's a+1 | own a+1]

@@ -275,7 +275,7 @@ class SpatialTransformer(PackedModule):
     def project_context(self, ctx):
         return [project_context(blk.attn2, ctx) for blk in self.transformer_blocks]
 
-    def forward(self, x, context_kv=None, frames_per_video=1, cfg_repeat=1, **kwargs):
+    def forward(self, x, context_kv=None, frames_per_video=1, cfg_repeat=1, colstats=None, **kwargs):
         """x [n, H, W, C] fp16 channels-last, n = b*t frames; context_kv from project_context().
         cfg_repeat = r > 1: x holds ONE copy of a batch whose r conditionings (classifier-free guidance: cond / uncond / ...)
         share everything up to here; everything that does not depend on the context - GroupNorm, proj_in, the whole
@@ -285,7 +285,9 @@ class SpatialTransformer(PackedModule):
         n, H, W, C = x.shape
         N_img = H * W
         pk = self.packed()
-        a = ops.group_norm(x.view(n, N_img, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False)
+        # colstats: column moments of x from the convolution that produced it (ResBlock): the norm then needs no statistics pass
+        stats = None if colstats is None else ops.group_norm_stats_from_colstats(colstats, n, N_img, C)
+        a = ops.group_norm(x.view(n, N_img, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False, stats=stats)
         # The attention kernels address a frame's keys / values at 16-byte granularity: h*w must be a multiple of 8.  It is at every
         # level of 576x1024 and 320x512; for other --height / --width (e.g. 384x640: 6x10 = 60 tokens at the deepest level) each
         # frame's token rows are padded with zero rows up to the next multiple of 8 for the length of this block - all its layers

@@ -39,11 +39,17 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
         """cfg_repeat = r > 1 (only for a block that holds the first SpatialTransformer of the graph): the input is one copy
         of an r-fold replicated batch; the transformer replicates it where the conditionings start to differ and the
         layers after it see batch_size * r videos."""
-        for layer in self:
+        layers = list(self)
+        colstats = None         # column moments of x from the convolution that produced it (for the GroupNorm of a SpatialTransformer right behind a ResBlock)
+        for i, layer in enumerate(layers):
             if isinstance(layer, ResBlock):
-                x = layer(x, emb, batch_size=batch_size)
+                want = i + 1 < len(layers) and isinstance(layers[i + 1], SpatialTransformer)
+                x = layer(x, emb, batch_size=batch_size, want_colstats=want)
+                if want:
+                    x, colstats = x
             elif isinstance(layer, SpatialTransformer):
-                x = layer(x, context_kv=context[id(layer)], frames_per_video=x.shape[0] // batch_size, cfg_repeat=cfg_repeat)
+                x = layer(x, context_kv=context[id(layer)], frames_per_video=x.shape[0] // batch_size, cfg_repeat=cfg_repeat, colstats=colstats)
+                colstats = None
                 if cfg_repeat > 1:
                     # x now holds batch_size * r videos: a ResBlock FOLLOWING the transformer inside this block reads one emb row
                     # per video through a raw pointer (rowadd), so emb must grow with x here, not after the block returns
@@ -124,9 +130,10 @@ class TemporalConvBlock(PackedModule):
             out.append((_f32(gn.weight), _f32(gn.bias), gn.eps, _f16(pack_conv(conv.weight.detach())), _f32(conv.bias)))
         return out
 
-    def forward(self, x, colstats=None):
+    def forward(self, x, colstats=None, want_colstats=False):
         """x [B, T, P, C] fp16.  `colstats`: column moments of x written by the convolution that produced it (ops.gemm colstats=):
-        the first norm then needs no statistics pass; the three inner norms get theirs from this block's own convolutions."""
+        the first norm then needs no statistics pass; the three inner norms get theirs from this block's own convolutions.
+        want_colstats: also return the moments of the OUTPUT (or None), for a per-frame GroupNorm behind this block."""
         B, T, P, C = x.shape
         y = x
         stages = self.packed()
@@ -136,10 +143,10 @@ class TemporalConvBlock(PackedModule):
             a = ops.group_norm(y.reshape(B, T * P, cy), gw, gb, eps, True, stats=stats)
             last = i == len(stages) - 1
             cout = w.shape[0]
-            colstats = (ops.colstats_buffer(B * T * P, cout, x.device)
-                        if (GN_EPILOGUE_STATS and not last and ops.colstats_ok(B * T * P, T * P, cy, cout)) else None)
+            need = (not last and ops.colstats_ok(B * T * P, T * P, cy, cout)) or (last and want_colstats and ops.colstats_ok(B * T * P, P, cy, cout))
+            colstats = ops.colstats_buffer(B * T * P, cout, x.device) if (GN_EPILOGUE_STATS and need) else None
             y = ops.temporal_conv3(a.view(B, T, P, -1), w, b, residual=x.reshape(B * T * P, C) if last else None, colstats=colstats)
-        return y
+        return (y, colstats) if want_colstats else y
 
 
 class ResBlock(PackedModule, TimestepBlock):
@@ -179,9 +186,10 @@ class ResBlock(PackedModule, TimestepBlock):
             pk["bs"] = _f32(self.skip_connection.bias)
         return pk
 
-    def forward(self, x, emb, batch_size=None):
+    def forward(self, x, emb, batch_size=None, want_colstats=False):
         """x [n, H, W, Cin] fp16; emb = SiLU(time+fs embedding) as fp16 [B, emb_channels] (one row per video: the
-        reference repeats it over the T frames, openaimodel3d.py:563)."""
+        reference repeats it over the T frames, openaimodel3d.py:563).  want_colstats: return (h, column moments of h or None)
+        for a per-frame GroupNorm right behind this block (SpatialTransformer.norm)."""
         n, H, W, cin = x.shape
         pk = self.packed()
         cout = self.out_channels
@@ -201,12 +209,17 @@ class ResBlock(PackedModule, TimestepBlock):
         else:
             skip = x.reshape(n * H * W, cout)
         temporal = self.use_temporal_conv and batch_size
-        cs2 = (ops.colstats_buffer(M, cout, x.device)
-               if (GN_EPILOGUE_STATS and temporal and ops.colstats_ok(M, (n // batch_size) * H * W, cout, cout)) else None)
+        need2 = (ops.colstats_ok(M, (n // batch_size) * H * W, cout, cout) if temporal
+                 else (want_colstats and ops.colstats_ok(M, H * W, cout, cout)))
+        cs2 = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and need2) else None
         h = ops.conv2d(a.view(n, H, W, cout), pk["w2"], pk["b2"], kh=3, kw=3, residual=skip, colstats=cs2)
+        cs_out = cs2
         if temporal:
-            h = self.temopral_conv(h.view(batch_size, n // batch_size, H * W, cout), colstats=cs2).view(n, H, W, cout)
-        return h
+            h = self.temopral_conv(h.view(batch_size, n // batch_size, H * W, cout), colstats=cs2, want_colstats=want_colstats)
+            if want_colstats:
+                h, cs_out = h
+            h = h.view(n, H, W, cout)
+        return (h, cs_out) if want_colstats else h
 
 
 class UNetModel(PackedModule):
