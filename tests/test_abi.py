@@ -93,3 +93,19 @@ def test_flash_v2_listing_passes_the_static_audit():
     for kernel, problems, summary in results:
         assert not problems, (kernel, problems)
         assert summary["agpr_count"] == 132 and summary["mfma"] in (16 + 3 * 40 + 2 * 24, 16 + 3 * 32 + 2 * 16)      # prologue, 3 full steps, 2 tails
+
+
+def test_no_kernel_overwrites_the_data_registers_of_a_wide_store_right_behind_it():
+    """tools/isa_audit.py --stores: every kernel source of libvcx compiled to gfx950 assembly (no GPU needed) and scanned for a VALU
+    write to the data registers of a >= 96-bit LDS / memory store within two issue slots.  hipcc emitted that once (the LNFOLD_T
+    epilogue's second strip vector into the registers its first ds_write_b128 was still reading) and the GPU suite caught it as a
+    run-dependent error in single output columns; this keeps it from coming back anywhere."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.audit_library_store_hazards() == []
+    # the scanner itself: the pattern that was emitted, and the same store with a slot of distance
+    bad = "_Zk:\n\tds_write_b128 v141, v[150:153]\n\tv_pk_mul_f32 v[150:151], v[150:151], v[162:163]\n"
+    ok = "_Zk:\n\tds_write_b128 v141, v[150:153]\n\ts_nop 1\n\tv_pk_mul_f32 v[150:151], v[150:151], v[162:163]\n"
+    assert len(mod.store_data_hazards(bad)) == 1 and mod.store_data_hazards(ok) == []

@@ -15,6 +15,7 @@ script compiles the file to gfx950 assembly (device side only, a few seconds, no
 Checks 4-7 walk the listing linearly (basic blocks in layout order), which is how the hot loop executes.
 
     python tools/isa_audit.py            # exit code 0 = clean; prints a per-check summary
+    python tools/isa_audit.py --stores   # library-wide: no VALU write to the data registers of a wide store right behind it
 """
 import os
 import re
@@ -168,7 +169,69 @@ def audit_all(listing):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Library-wide check (round 3, after a run-dependent failure of the LNFOLD_T epilogue): hipcc may place a VALU instruction that
+# overwrites the DATA registers of a wide (>= 96-bit) LDS or memory store one or two slots behind that store.  The store still reads
+# its data then (observed with ds_write_b128 followed by v_pk_mul_f32 into the same registers: single elements of the stored vector
+# went out stale, in some runs).  No kernel of libvcx may contain that pattern.
+# ---------------------------------------------------------------------------------------------------------------------------
+CSRC = os.path.join(ROOT, "viewcrafter_amd", "csrc")
+LIB_SOURCES = ("gemm.hip", "gemm_dma.hip", "attention.hip", "attention_v2.hip", "norm.hip", "elementwise.hip")
+WIDE_STORES = ("ds_write_b128", "ds_write_b96", "ds_write2_b64", "ds_write2st64_b64", "buffer_store_dwordx4", "buffer_store_dwordx3",
+               "global_store_dwordx4", "global_store_dwordx3", "flat_store_dwordx4", "flat_store_dwordx3")
+
+
+def store_data_hazards(listing):
+    """[(kernel, store, offending instruction, slots behind)] of one hipcc -S listing."""
+    lines = [l.strip() for l in listing.split("\n")]
+    found, kern = [], "?"
+    for i, l in enumerate(lines):
+        if l.startswith("_Z") and ":" in l:
+            kern = l.split(":")[0]
+        op, _, rest = l.partition(" ")
+        if op not in WIDE_STORES:
+            continue
+        data = set()
+        for o in [x.strip() for x in rest.split(",")][:3]:
+            r = vregs(o)
+            if len(r) >= 3 or (op.startswith("ds_write2") and len(r) == 2):
+                data |= r
+        slots, j = 0, i + 1
+        while j < len(lines) and slots < 2:
+            t = lines[j]
+            j += 1
+            if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+                continue
+            top, _, trest = t.partition(" ")
+            if top == "s_nop":
+                slots += int(trest.split()[0]) + 1
+                continue
+            slots += 1
+            if top.startswith("v_") and not top.startswith("v_cmp") and not top.startswith("v_mfma") and trest:
+                if vregs(trest.split(",")[0].strip()) & data:
+                    found.append((kern, l, t, slots))
+    return found
+
+
+def audit_library_store_hazards():
+    out = []
+    for name in LIB_SOURCES:
+        tmp = os.path.join(tempfile.mkdtemp(prefix="vcx_isa_"), name + ".s")
+        flags = FLAGS if name == "attention_v2.hip" else [f for f in FLAGS if f != "-fno-slp-vectorize"]
+        r = subprocess.run([HIPCC] + flags + ["-I", os.path.join(ROOT, "include"), "-o", tmp, os.path.join(CSRC, name)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on " + name + ":\n" + r.stderr[-2000:])
+        out += [(name,) + h for h in store_data_hazards(open(tmp).read())]
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--stores":
+        hz = audit_library_store_hazards()
+        for h in hz:
+            print("HAZARD", h)
+        print("clean" if not hz else f"{len(hz)} store-data hazard(s)")
+        return 1 if hz else 0
     bad = 0
     for k, problems, summary in audit_all(compile_listing(sys.argv[1] if len(sys.argv) > 1 else None)):
         print(k + ":", summary)

@@ -156,9 +156,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
             const int nc = min(nstrip + lane * 4, p.N - 4);
             if (LNF == 2) {         // per-column (alpha rstd_n, -alpha rstd_n mean_n)
                 const f4 s01 = *reinterpret_cast<const f4*>(p.ln_stats + 2 * nc), s23 = *reinterpret_cast<const f4*>(p.ln_stats + 2 * nc + 4);
-                const f4 cs = {p.alpha * s01[1], p.alpha * s01[3], p.alpha * s23[1], p.alpha * s23[3]};
+                // Both vectors are complete BEFORE the first store and stay live behind the second one: hipcc otherwise re-used the data
+                // registers of the first ds_write_b128 for the second product in the very next instructions (v_pk_mul_f32 into
+                // v[n:n+1] one and two slots behind the store) - a wide LDS store still reads its data then, and single strip
+                // elements went out stale, run-dependent (found by the full GPU suite; tools/isa_audit.py now scans every kernel of
+                // the library for a VALU write to the data registers of a >= 96-bit LDS / memory store within two slots).
+                f4 cs = {p.alpha * s01[1], p.alpha * s01[3], p.alpha * s23[1], p.alpha * s23[3]};
+                f4 cq = {-cs[0] * s01[0], -cs[1] * s01[2], -cs[2] * s23[0], -cs[3] * s23[2]};
+                asm volatile("" : "+v"(cs), "+v"(cq));
                 *reinterpret_cast<f4*>(sB + lane * 4) = cs;
-                *reinterpret_cast<f4*>(sS + lane * 4) = f4{-cs[0] * s01[0], -cs[1] * s01[2], -cs[2] * s23[0], -cs[3] * s23[2]};
+                *reinterpret_cast<f4*>(sS + lane * 4) = cq;
+                asm volatile("" : : "v"(cs), "v"(cq));
             } else {
                 f4 t = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nc) : f4{0.f, 0.f, 0.f, 0.f};
                 if (radd_tile) {
