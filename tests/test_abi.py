@@ -109,3 +109,6 @@ def test_no_kernel_overwrites_the_data_registers_of_a_wide_store_right_behind_it
     bad = "_Zk:\n\tds_write_b128 v141, v[150:153]\n\tv_pk_mul_f32 v[150:151], v[150:151], v[162:163]\n"
     ok = "_Zk:\n\tds_write_b128 v141, v[150:153]\n\ts_nop 1\n\tv_pk_mul_f32 v[150:151], v[150:151], v[162:163]\n"
     assert len(mod.store_data_hazards(bad)) == 1 and mod.store_data_hazards(ok) == []
+    # ... and the packed fma form that was not bit-reproducible (LNFOLD_T epilogue, 128x128 tile): low result from a high source half
+    assert len(mod.store_data_hazards("_Zk:\n\tv_pk_fma_f32 v[60:61], v[60:61], v[4:5], v[0:1] op_sel:[0,1,1]\n")) == 1
+    assert mod.store_data_hazards("_Zk:\n\tv_pk_fma_f32 v[60:61], v[60:61], v[4:5], v[0:1] op_sel_hi:[1,0,0]\n") == []

@@ -10,19 +10,19 @@ x = (rnd(tokens, D, seed=211) * 2 + 0.5).to(DEV).half()
 gamma = (1 + 0.3 * rnd(D, seed=212)).to(DEV); beta = (0.2 * rnd(D, seed=213)).to(DEV)
 wv = (rnd(D, D, seed=214) / math.sqrt(D)).to(DEV)
 wf, colsum, bias_f = fold_layernorm(wv, gamma, beta, None)
-xd = x.double(); mu = xd.mean(-1, keepdim=True); var = ((xd - mu) ** 2).mean(-1, keepdim=True)
-ref = (((xd - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()) @ wv.double().t()).t()
-outs = []
-for it in range(12):
-    junk = torch.full((64 << 20,), float("nan") if it % 2 else 1e4, device=DEV, dtype=torch.float16); del junk
-    st = ops.row_stats(x, 1e-5)
-    out = ops.gemm(wf, x, M=D, N=tokens, K=D, lda=D, bias=bias_f, bias_m=True, ln_stats=st, ln_colsum=colsum, ln_t=True)
-    torch.cuda.synchronize()
-    e = float((out.double() - ref).norm() / ref.norm())
-    bad = ((out.double() - ref).abs() > 0.05) | ~torch.isfinite(out.double())
-    idx = bad.nonzero()
-    print(it, f"{e:.3e}", "bad", int(bad.sum()), "rows", sorted(set(idx[:, 0].tolist()))[:8], "cols", sorted(set(idx[:, 1].tolist()))[:12], flush=True)
-    outs.append(out.clone())
-print("all equal:", all(torch.equal(outs[0], o) for o in outs[1:]))
-st2 = ops.row_stats(x, 1e-5)
-print("stats err", float((st2[:, 0].double() - mu[:, 0]).abs().max()), float(((st2[:, 1].double() - 1 / torch.sqrt(var[:, 0] + 1e-5)).abs() / st2[:, 1].double()).max()))
+st = ops.row_stats(x, 1e-5)
+torch.cuda.synchronize()
+def run_t():
+    return ops.gemm(wf, x, M=D, N=tokens, K=D, lda=D, bias=bias_f, bias_m=True, ln_stats=st, ln_colsum=colsum, ln_t=True)
+def run_n():
+    return ops.linear(x, wf, bias_f, ln_stats=st, ln_colsum=colsum)
+for name, fn in (("T", run_t), ("N", run_n)):
+    for cfg in (-1, 0, 1, 2, 3):
+        ops.tune_set("GEMM_CFG", cfg)
+        outs = [fn().clone() for _ in range(10)]
+        torch.cuda.synchronize()
+        nd = [int((o != outs[0]).sum()) for o in outs[1:]]
+        idx = [(o != outs[0]).nonzero() for o in outs[1:]]
+        rows = sorted({int(r) // 16 % 4 for t in idx for r in t[:, 0].tolist()}); cols = sorted({int(c) % 16 for t in idx for c in t[:, 1].tolist()})
+        print(name, "cfg", cfg, "differing elements vs run 0:", nd, "row-group b", rows, "col%16", cols, flush=True)
+ops.tune_set("GEMM_CFG", -1)

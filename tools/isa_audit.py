@@ -210,6 +210,18 @@ def store_data_hazards(listing):
             if top.startswith("v_") and not top.startswith("v_cmp") and not top.startswith("v_mfma") and trest:
                 if vregs(trest.split(",")[0].strip()) & data:
                     found.append((kern, l, t, slots))
+    # second pattern: a packed fp32 multiply-add whose LOW result selects the HIGH half of a source pair (op_sel:[...] with a 1).
+    # hipcc emitted `v_pk_fma_f32 v[60:61], v[60:61], v[4:5], v[0:1] op_sel:[0,1,1]` in ONE kernel (128x128 tile, LNFOLD_T epilogue,
+    # odd row group) and exactly those results - low halves, lanes 48-63 - were run-dependent on the MI355X, with every operand
+    # long since written.  (The horizontal `v_pk_add_f32 x, x, x op_sel:[0,1] op_sel_hi:[1,0]` of gn_stats_kernel has been
+    # bit-reproducible for three rounds and is not flagged.)
+    kern = "?"
+    for l in lines:
+        if l.startswith("_Z") and ":" in l:
+            kern = l.split(":")[0]
+        m = re.match(r"v_pk_fma_f32\s.*\bop_sel:\[([01,]+)\]", l)
+        if m and "1" in m.group(1):
+            found.append((kern, l, "low result of a packed fma takes a high source half", 0))
     return found
 
 

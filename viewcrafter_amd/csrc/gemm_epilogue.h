@@ -211,10 +211,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
             if (FOLD) {
                 const f4 t = *reinterpret_cast<const f4*>(sB + bopaque + a * 16 + lg * 4);
                 const f4 u = *reinterpret_cast<const f4*>(sS + bopaque + a * 16 + lg * 4);
+                // The row terms enter the packed multiply-adds as explicit (x, x) pairs behind an optimisation barrier.  Left alone,
+                // hipcc used the four row terms straight out of their registers - for odd b the HIGH half of an aligned pair as
+                // the LOW operand, `v_pk_fma_f32 ... op_sel:[0,1,1]` - in one instantiation (128x128 tile, LNFOLD_T), and exactly
+                // that kernel returned run-dependent low halves in lanes 48-63 of the b = 1 row group (every other form,
+                // op_sel_hi:[1,0,0] included, is bit-reproducible).  tools/isa_audit.py --stores rejects the form library-wide.
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                f2v la = {ln_a[b], ln_a[b]}, lb = {ln_b[b], ln_b[b]};
+                asm volatile("" : "+v"(la), "+v"(lb));
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    v[r] = LNF == 1 ? __builtin_fmaf(acc[a][b][r], ln_a[b], __builtin_fmaf(ln_b[b], u[r], t[r]))
-                                    : __builtin_fmaf(acc[a][b][r], t[r], __builtin_fmaf(u[r], ln_a[b], ln_b[b]));
+                    v[r] = LNF == 1 ? __builtin_fmaf(acc[a][b][r], la[r & 1], __builtin_fmaf(lb[r & 1], u[r], t[r]))
+                                    : __builtin_fmaf(acc[a][b][r], t[r], __builtin_fmaf(u[r], la[r & 1], lb[r & 1]));
             } else if (per_row) {      // rare: V^T projections (per-row bias) and tiles that straddle two addend rows
                 // same arithmetic as the tile-uniform case, (bias + addend) first and one fma: a row's result must
                 // not depend on how the batch happens to align tiles with frames (bit-exact batch invariance)
