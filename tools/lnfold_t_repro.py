@@ -1,3 +1,7 @@
+"""Bit-reproducibility probe of the folded-LayerNorm projections (profiles/r03zz_lnfold_t_determinism.txt): the LNFOLD_T projection
+out[1280, 6216] and the same operands as a plain LNFOLD projection, ten calls per forced tile configuration (knob GEMM_CFG), counting the
+elements that differ from call 0.  Found hipcc's `v_pk_fma_f32 ... op_sel:[0,1,1]` form in the 128x128 LNFOLD_T kernel to be run-dependent
+on the MI355X; tools/isa_audit.py --stores now rejects that form.   python tools/lnfold_t_repro.py"""
 import math, sys, torch
 sys.path.insert(0, ".")
 from viewcrafter_amd import ops
