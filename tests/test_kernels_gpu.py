@@ -228,6 +228,34 @@ def test_groupnorm(n, pix, C, silu, eps):
     check(out, ref.permute(0, 2, 1), name="groupnorm")
 
 
+def test_groupnorm_and_folded_projections_are_bit_reproducible():
+    """Ten calls, identical bits: the three-pass GroupNorm (its statistics kernel holds the library's only packed adds with an
+    op_sel half-swap), the row statistics and both folded-LayerNorm projections in every tile configuration.  (Round 3 found one
+    packed multiply-add form that the MI355X does not execute reproducibly - profiles/r03_experiments.md section 11; this is the
+    run-time counterpart of the static check in tools/isa_audit.py.)"""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import fold_layernorm
+    x = (rnd(6, 2304, 640, seed=401) * 2 + 0.7).to(DEV).half()
+    g, b = (1 + 0.2 * rnd(640, seed=402)).to(DEV), (0.1 * rnd(640, seed=403)).to(DEV)
+    first = ops.group_norm(x, g, b, 1e-5, True)
+    assert all(torch.equal(ops.group_norm(x, g, b, 1e-5, True), first) for _ in range(9))
+    D, tokens = 640, 3304                         # tokens % 160 != 0: the dispatcher picks the 128x128 tile
+    t = (rnd(tokens, D, seed=404) * 2 + 0.5).to(DEV).half()
+    wf, colsum, bias_f = fold_layernorm((rnd(D, D, seed=405) / math.sqrt(D)).to(DEV), g, b, None)
+    st = ops.row_stats(t, 1e-5)
+    assert all(torch.equal(ops.row_stats(t, 1e-5), st) for _ in range(3))
+    try:
+        for cfg in (-1, 0, 1, 2, 3):
+            ops.tune_set("GEMM_CFG", cfg)
+            vt = ops.gemm(wf, t, M=D, N=tokens, K=D, lda=D, bias=bias_f, bias_m=True, ln_stats=st, ln_colsum=colsum, ln_t=True)
+            q = ops.linear(t, wf, bias_f, ln_stats=st, ln_colsum=colsum)
+            for _ in range(9):
+                assert torch.equal(ops.gemm(wf, t, M=D, N=tokens, K=D, lda=D, bias=bias_f, bias_m=True, ln_stats=st, ln_colsum=colsum, ln_t=True), vt), cfg
+                assert torch.equal(ops.linear(t, wf, bias_f, ln_stats=st, ln_colsum=colsum), q), cfg
+    finally:
+        ops.tune_set("GEMM_CFG", -1)
+
+
 @pytest.mark.parametrize("n,pix,C,offset,std", [(2, 9216, 320, 100.0, 0.1), (1, 5000, 640, -300.0, 0.25), (1, 230400, 320, 60.0, 0.05)])
 def test_groupnorm_large_common_offset(n, pix, C, offset, std):
     """|mean| >> std (what real checkpoints produce in the VAE decoder and the deep UNet levels): a one-pass
