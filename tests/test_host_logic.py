@@ -392,6 +392,21 @@ def test_fold_layernorm_is_the_exact_algebra_of_layernorm_then_linear():
     assert torch.equal(cp, wp.double().sum(1).float())
 
 
+def test_colstats_eligibility_mirrors_the_kernels_conditions():
+    """ops.colstats_ok: GroupNorm statistics come from the producing convolution's epilogue only where the DMA conv kernel runs
+    (cin % 64 == 0, cout % 8 == 0, 32-bit byte offsets) and every statistics unit is whole 64-row strips - all levels of 576x1024 and
+    320x512 but the deepest (9x16 / 5x8 pixels per frame), per frame and per video; elsewhere the statistics pass stays."""
+    from viewcrafter_amd import ops
+    for h, w, ok in ((72, 128, True), (36, 64, True), (18, 32, True), (9, 16, False), (40, 64, True), (20, 32, True), (10, 16, False), (5, 8, False)):
+        n = 50
+        assert ops.colstats_ok(n * h * w, h * w, 320, 320) is ok, (h, w)                       # per frame
+        assert ops.colstats_ok(n * h * w, 25 * h * w, 640, 640) is (25 * h * w % 64 == 0), (h, w)   # per video
+    assert not ops.colstats_ok(50 * 72 * 128, 72 * 128, 8, 320)            # conv_in: 8 input channels -> register-staged kernel
+    assert not ops.colstats_ok(50 * 72 * 128, 72 * 128, 320, 4)            # the 4-channel output convolution
+    assert not ops.colstats_ok(8 * 1024 * 1024, 1024 * 1024, 320, 320)     # output beyond 32-bit byte offsets
+    assert ops.colstats_ok(460800, 9216, 960, 320, in_rows=460800) and not ops.colstats_ok(460800, 9216, 960, 320, in_rows=3_000_000)
+
+
 def test_pack_conv_slab_major_order_for_64_channel_multiples():
     """cin % 64 == 0 and more than one tap: K is ordered (c / 64, tap, c % 64) - VCX_GEMM_CONV_SLABK, the order both GEMM
     kernels walk when ops.conv2d / temporal_conv3 set the flag from the same predicate."""
