@@ -32,7 +32,10 @@ extern "C" {
 #define VCX_ELAUNCH (-2)  /* HIP launch or runtime error                 */
 #define VCX_ENODEV (-3)   /* no gfx950 device                            */
 
-#define VCX_ABI_VERSION 4   /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*.  3: vcx_gemm_desc grows ln_stats / ln_colsum (VCX_GEMM_LNFOLD*), vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32 */
+/* 2: groupnorm stats are (mean, biased variance); vcx_tune_*.  3: vcx_gemm_desc grows ln_stats / ln_colsum (VCX_GEMM_LNFOLD*),
+ * vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32.  5: vcx_gemm_desc starts with
+ * struct_size - a descriptor of another layout is rejected instead of read past its end. */
+#define VCX_ABI_VERSION 5
 
 int vcx_abi_version(void);
 const char* vcx_last_error(void);
@@ -91,6 +94,7 @@ int vcx_device_arch(char* name_host, int len);
 #define VCX_GEMM_COLSTATS 0x200
 
 typedef struct vcx_gemm_desc {
+    size_t struct_size;   /* = sizeof(vcx_gemm_desc) of the header the caller was compiled against; anything else is VCX_EINVAL */
     const void* A;        /* fp16 activations                                             */
     const void* W;        /* fp16 weights [N][ldw]                                        */
     void* C;              /* fp16 (or fp32) output [M][ldc]                               */

@@ -47,25 +47,59 @@ def test_tune_knobs_default_to_the_product_and_round_trip():
     assert L.vcx_tune_set(99, 1) == -1 and b"knob" in L.vcx_last_error()
 
 
-def test_gemm_desc_layout_matches_header():
-    """The ctypes mirror follows the C struct of include/vcx.h field by field (names and order parsed from the header; C types
-    mapped to ctypes) and in total size: 9 pointers, one int64, 21 int32, one float - 168 bytes, no padding."""
+def header_gemm_desc_fields():
+    """(name, ctypes type) of every field of struct vcx_gemm_desc, parsed from include/vcx.h."""
     src = open(os.path.join(ROOT, "include", "vcx.h")).read()
     body = re.search(r"typedef struct vcx_gemm_desc \{(.*?)\} vcx_gemm_desc;", src, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     want = []
+    ctypes_of = {"int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "float": ctypes.c_float, "size_t": ctypes.c_size_t}
     for decl in body.split(";"):
         decl = decl.strip()
         if not decl:
             continue
-        ctype, names = decl.rsplit(None, 1)[0], decl.split(",")
+        names = decl.split(",")
         first = names[0].rsplit(None, 1)
         ctype, names = first[0], [first[1]] + [n.strip() for n in names[1:]]
         for n in names:
             ptr = "*" in ctype or n.startswith("*")
-            want.append((n.lstrip("*"), ctypes.c_void_p if ptr else {"int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "float": ctypes.c_float}[ctype]))
+            want.append((n.lstrip("*"), ctypes.c_void_p if ptr else ctypes_of[ctype]))
+    return want
+
+
+def test_gemm_desc_layout_matches_header():
+    """The ctypes mirror follows the C struct of include/vcx.h field by field (names and order parsed from the header; C types
+    mapped to ctypes) and in total size: size_t, 9 pointers, one int64, 21 int32, one float - 176 bytes, no padding."""
+    want = header_gemm_desc_fields()
     assert [(f[0], f[1]) for f in _lib.GemmDesc._fields_] == want
-    assert ctypes.sizeof(_lib.GemmDesc) == 9 * 8 + 8 + 21 * 4 + 4 == 168
+    assert ctypes.sizeof(_lib.GemmDesc) == 8 + 9 * 8 + 8 + 21 * 4 + 4 == 176
+    assert _lib.GemmDesc().struct_size == 176 and _lib.GemmDesc(M=3).struct_size == 176
+
+
+def test_integration_md_stub_matches_header():
+    """The binding stub a maintainer copies out of INTEGRATION.md is executed as written and compared with the header - the doc
+    cannot go stale again (round 3 shipped a 144-byte ABI-1 stub next to a 168-byte struct)."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\nimport ctypes, torch\n(.*?)```", md, re.S).group(1)
+    cls = re.search(r"(class GemmDesc\(ctypes\.Structure\):.*?)\nvcx\.vcx_gemm_f16\.argtypes", block, re.S).group(1)
+    ns = {"ctypes": ctypes}
+    exec(cls, ns)
+    stub = ns["GemmDesc"]
+    assert [(f[0], f[1]) for f in stub._fields_] == header_gemm_desc_fields()
+    assert ctypes.sizeof(stub) == ctypes.sizeof(_lib.GemmDesc)
+    assert "struct_size=ctypes.sizeof(GemmDesc)" in block, "the stub's call must fill in struct_size"
+    assert f"ABI {_lib.ABI_VERSION}" in cls
+
+
+def test_gemm_rejects_a_descriptor_of_another_size():
+    """ABI 5: a descriptor whose struct_size is not sizeof(vcx_gemm_desc) - an old binding's 168-byte struct starts with the A
+    pointer there - is refused before any field is trusted."""
+    L = _lib.lib()
+    d = _lib.GemmDesc()
+    d.struct_size = 168
+    assert L.vcx_gemm_f16(ctypes.byref(d), None) == -1 and b"struct_size" in L.vcx_last_error()
+    d.struct_size = 0
+    assert L.vcx_gemm_f16(ctypes.byref(d), None) == -1 and b"struct_size" in L.vcx_last_error()
 
 
 def test_argument_validation_without_gpu():

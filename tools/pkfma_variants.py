@@ -1,0 +1,170 @@
+"""Root-cause hunt for the run-dependent `v_pk_fma_f32 ... op_sel:[0,1,1]` result (profiles/r03_experiments.md section 11,
+profiles/r04_pkfma_rootcause.md): rebuild the PRE-FIX library (commit 5b23812, the kernel that failed) with the device
+assembly of gemm_dma.hip patched in four ways, everything else byte-identical, so that one run on an MI355X says whether
+the failure follows the instruction FORM or its TIMING:
+
+    v0   unpatched (must reproduce the failure, otherwise the experiment says nothing)
+    v1   `s_nop 7` AFTER every op_sel pk_fma   (result -> consumer distance; LLVM's dst-sel forwarding rule pads 1 slot)
+    v2   `s_nop 7` BEFORE every op_sel pk_fma  (ds_read return / s_waitcnt -> packed read distance)
+    v3   every op_sel pk_fma replaced by two scalar v_fma_f32 reading the same registers (same operands, no op_sel)
+    v4   the 128-bit store / ds_read pairs left alone, but the op_sel form rewritten to op_sel_hi-only by swapping to
+         explicit copies is NOT possible without free registers - instead: `s_nop 0` after (exactly one slot)
+
+Build (CPU, no GPU needed):   python tools/pkfma_variants.py build        -> tools/_abl/libvcx_pkfma_v{0..4}.so
+Run on the GPU box:           python tools/pkfma_variants.py run [calls]  -> table on stdout
+The run leg uses its own ctypes binding of the ABI-4 struct the old library expects (168 bytes, no struct_size)."""
+import ctypes
+import math
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ABL = os.path.join(ROOT, "tools", "_abl")
+COMMIT = "5b23812"
+LLVM = "/opt/rocm/lib/llvm/bin"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
+PK = re.compile(r"^\tv_pk_fma_f32 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\] op_sel:\[0,1,1\]\s*$")
+
+
+def sh(*cmd, cwd=None):
+    subprocess.check_call(list(cmd), cwd=cwd)
+
+
+def patch(asm, variant):
+    out, n = [], 0
+    for line in asm.split("\n"):
+        m = PK.match(line)
+        if not m:
+            out.append(line)
+            continue
+        n += 1
+        d0, d1, s0, s1, a0, a1, c0, c1 = map(int, m.groups())
+        if variant == 0:
+            out.append(line)
+        elif variant == 1:
+            out += [line, "\ts_nop 7"]
+        elif variant == 2:
+            out += ["\ts_nop 7", line]
+        elif variant == 3:      # low = s0.lo * a.hi + c.hi ; high = s0.hi * a.hi + c.hi   (d may alias s0: lo first is safe, d0 is only s0's own lo)
+            out += [f"\tv_fma_f32 v{d0}, v{s0}, v{a1}, v{c1}", f"\tv_fma_f32 v{d1}, v{s1}, v{a1}, v{c1}"]
+        elif variant == 4:
+            out += [line, "\ts_nop 0"]
+    return "\n".join(out), n
+
+
+def build():
+    work = "/tmp/pkfma_build"
+    sh("rm", "-rf", work)
+    os.makedirs(work)
+    os.makedirs(ABL, exist_ok=True)
+    sh("bash", "-c", f"git -C {ROOT} archive {COMMIT} viewcrafter_amd/csrc include | tar x -C {work}")
+    src = os.path.join(work, "viewcrafter_amd", "csrc")
+    sh("make", "-j8", cwd=src)
+    sh(f"{LLVM}/../../../bin/hipcc", *FLAGS, "-S", "--cuda-device-only", "gemm_dma.hip", "-o", "dev.s", cwd=src)
+    asm = open(os.path.join(src, "dev.s")).read()
+    others = [os.path.join(src, "build", f"{n}.o") for n in ("api", "gemm", "attention", "attention_v2", "norm", "elementwise")]
+    for v in range(5):
+        text, n = patch(asm, v)
+        assert n == 4, f"expected the four op_sel:[0,1,1] instructions of the 128x128 LNFOLD_T kernel, found {n}"
+        open(os.path.join(src, f"dev{v}.s"), "w").write(text)
+        sh(f"{LLVM}/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", f"dev{v}.s", "-o", f"dev{v}.o", cwd=src)
+        sh(f"{LLVM}/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", f"dev{v}.out", f"dev{v}.o", cwd=src)
+        sh(f"{LLVM}/clang-offload-bundler", "-type=o", "-bundle-align=4096",
+           "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input=dev{v}.out",
+           f"-output=dev{v}.hipfb", cwd=src)
+        sh(f"{LLVM}/../../../bin/hipcc", *FLAGS, "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", f"dev{v}.hipfb",
+           "-c", "gemm_dma.hip", "-o", f"gemm_dma{v}.o", cwd=src)
+        dst = os.path.join(ABL, f"libvcx_pkfma_v{v}.so")
+        sh(f"{LLVM}/../../../bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", dst, f"gemm_dma{v}.o", *others, cwd=src)
+        print("built", dst)
+    # the context of the four instructions, for the record
+    lines = asm.split("\n")
+    first = next(i for i, l in enumerate(lines) if PK.match(l))
+    open(os.path.join(ABL, "pkfma_context.s"), "w").write("\n".join(lines[first - 40:first + 30]) + "\n")
+
+
+class GemmDesc4(ctypes.Structure):       # ABI 4 (the old library)
+    _fields_ = [(n, ctypes.c_void_p) for n in ("A", "W", "C", "bias", "rowadd", "residual")] + [("lda", ctypes.c_int64)] + \
+               [(n, ctypes.c_int32) for n in ("M", "N", "K", "ldw", "ldc", "ldr", "mode", "in_h", "in_w", "out_h", "out_w", "cin", "kh", "kw",
+                                              "stride", "pad_h", "pad_w", "ups", "rowadd_div", "flags")] + [("alpha", ctypes.c_float)] + \
+               [(n, ctypes.c_void_p) for n in ("ln_stats", "ln_colsum", "colstats")]
+
+
+def run(calls):
+    import torch
+    sys.path.insert(0, ROOT)
+    from viewcrafter_amd.packing import fold_layernorm
+    dev = "cuda"
+
+    def rnd(*shape, seed=0):
+        g = torch.Generator().manual_seed(seed + sum(shape))
+        return torch.randn(*shape, generator=g)
+    D, tokens = 1280, 6216
+    x = (rnd(tokens, D, seed=211) * 2 + 0.5).to(dev).half()
+    gamma = (1 + 0.3 * rnd(D, seed=212)).to(dev)
+    beta = (0.2 * rnd(D, seed=213)).to(dev)
+    wv = (rnd(D, D, seed=214) / math.sqrt(D)).to(dev)
+    wf, colsum, bias_f = fold_layernorm(wv, gamma, beta, None)
+    wf, colsum, bias_f = wf.contiguous(), colsum.float().contiguous(), bias_f.float().contiguous()
+    stream = torch.cuda.current_stream().cuda_stream
+    # fp64 pieces for the diagnosis of a wrong element: out[m, n] = rstd_n (acc[m, n] - mean_n colsum_m) + bias_m
+    xd = x.double()
+    mean, var = xd.mean(1), xd.var(1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    acc = wf.double() @ xd.t()                  # [D, tokens]
+    for v in range(5):
+        path = os.path.join(ABL, f"libvcx_pkfma_v{v}.so")
+        L = ctypes.CDLL(path)
+        L.vcx_last_error.restype = ctypes.c_char_p
+        L.vcx_gemm_f16.argtypes = [ctypes.POINTER(GemmDesc4), ctypes.c_void_p]
+        L.vcx_rowstats_f16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+        L.vcx_tune_set.argtypes = [ctypes.c_int, ctypes.c_int]
+        assert L.vcx_abi_version() == 4
+        st = torch.empty(tokens, 2, device=dev, dtype=torch.float32)
+        assert L.vcx_rowstats_f16(x.data_ptr(), st.data_ptr(), tokens, D, 1e-5, stream) == 0
+        L.vcx_tune_set(0, 0)                     # GEMM_CFG = 0: the 128x128 tile
+        outs = []
+        for _ in range(calls):
+            o = torch.empty(D, tokens, device=dev, dtype=torch.float16)
+            # LNFOLD_T: the folded WEIGHT rows are the GEMM's M axis (out[d, token]), the token rows its N axis - as
+            # ops.gemm(wf, x, ..., bias_m=True, ln_t=True) sets the descriptor up
+            d = GemmDesc4(A=wf.data_ptr(), W=x.data_ptr(), C=o.data_ptr(), bias=bias_f.data_ptr(), lda=D, M=D, N=tokens, K=D, ldw=D,
+                          ldc=tokens, mode=0, rowadd_div=0, flags=0x2 | 0x100, alpha=1.0, ln_stats=st.data_ptr(), ln_colsum=colsum.data_ptr())
+            rc = L.vcx_gemm_f16(ctypes.byref(d), stream)
+            assert rc == 0, L.vcx_last_error()
+            outs.append(o)
+        torch.cuda.synchronize()
+        # majority value per element = the reproducible result; count the deviants of every call
+        stack = torch.stack(outs)
+        ref = stack.mode(0).values
+        bad = (stack != ref)
+        per_call = bad.flatten(1).sum(1).tolist()
+        idx = bad.nonzero()
+        rows = sorted({int(r) // 16 % 4 for r in idx[:, 1].tolist()})
+        cols = sorted({int(c) % 16 for c in idx[:, 2].tolist()})
+        # which WRONG formula explains a deviant?  candidates for the (colsum, bias') pair of row m: the pair of row m - 16 (the
+        # low halves of the same register pairs = op_sel ignored on both sources), and each source alone
+        expl = {"own": 0, "both_lo": 0, "src1_lo": 0, "src2_lo": 0, "none": 0}
+        for c, m, n in idx[:2000].tolist():
+            got = float(stack[c, m, n])
+            a, r, mu = float(acc[m, n]), float(rstd[n]), float(mean[n])
+            cands = {"own": (colsum[m], bias_f[m]), "both_lo": (colsum[m - 16], bias_f[m - 16]), "src1_lo": (colsum[m - 16], bias_f[m]),
+                     "src2_lo": (colsum[m], bias_f[m - 16])}
+            hit = "none"
+            for name, (cs_, b_) in cands.items():
+                val = torch.tensor(r * (a - mu * float(cs_)) + float(b_)).half()
+                if abs(float(val) - got) <= 2 * abs(float(torch.finfo(torch.float16).eps * val)) + 1e-6:
+                    hit = name
+                    break
+            expl[hit] += 1
+        print(f"v{v}: calls {calls}  deviating elements per call min/median/max {min(per_call)}/{sorted(per_call)[len(per_call) // 2]}/{max(per_call)}"
+              f"  total {int(bad.sum())}  row-group b {rows}  col%16 {cols}  explained-by {expl}", flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 30)

@@ -21,7 +21,7 @@ SYMBOLS = [
     "vcx_profile_begin", "vcx_profile_end", "vcx_tune_set", "vcx_tune_get",
 ]
 
-ABI_VERSION = 4          # include/vcx.h VCX_ABI_VERSION
+ABI_VERSION = 5          # include/vcx.h VCX_ABI_VERSION
 # experiment knobs (include/vcx.h VCX_TUNE_*): name -> (index, default)
 TUNE = {"GEMM_CFG": (0, -1), "GEMM_DMA": (1, 1), "FLASH_QB": (2, 0), "XATTN_RESIDENT": (3, 1), "FLASH_IMPL": (4, 0), "EXP0": (5, 0),
         "EXP1": (6, 0)}
@@ -32,6 +32,7 @@ PROF_FAMILIES = ("gemm", "flash_attn", "temporal_attn", "groupnorm", "layernorm"
 
 class GemmDesc(ctypes.Structure):
     _fields_ = [
+        ("struct_size", ctypes.c_size_t),
         ("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("rowadd", c_void_p),
         ("residual", c_void_p), ("lda", c_int64), ("M", c_int32), ("N", c_int32), ("K", c_int32),
         ("ldw", c_int32), ("ldc", c_int32), ("ldr", c_int32), ("mode", c_int32),
@@ -40,6 +41,10 @@ class GemmDesc(ctypes.Structure):
         ("ups", c_int32), ("rowadd_div", c_int32), ("flags", c_int32), ("alpha", c_float),
         ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("colstats", c_void_p),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(GemmDesc)      # vcx_gemm_f16 rejects any other value (include/vcx.h, ABI 5)
 
 
 _lib = None

@@ -396,6 +396,10 @@ int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) 
 
 extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     VCX_REQUIRE(d != nullptr, "vcx_gemm_f16: null descriptor");
+    // ABI 5: the caller states the size of the struct it filled in.  A binding written against another header version (the
+    // 144-byte ABI-1 or 168-byte ABI-4 layouts started with the A pointer) is refused here instead of being read past its end.
+    VCX_REQUIRE(d->struct_size == sizeof(vcx_gemm_desc), "vcx_gemm_f16: descriptor struct_size %zu != %zu (sizeof(vcx_gemm_desc), ABI %d)",
+                (size_t)d->struct_size, sizeof(vcx_gemm_desc), VCX_ABI_VERSION);
     VCX_REQUIRE(d->A && d->W && d->C, "vcx_gemm_f16: null A/W/C");
     VCX_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "vcx_gemm_f16: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
     VCX_REQUIRE(d->K % 8 == 0 && d->ldw % 8 == 0 && d->lda % 8 == 0,
