@@ -36,6 +36,7 @@ def build(ref=REF, out=OUT, quiet=False):
             print(f"[build_ref] {ref} not present: oracle/_ref is only (re)built in the build container; keeping what is there")
         return False
     tag = f"cpython-{sys.version_info.major}{sys.version_info.minor}"
+    final, out = out, out + ".tmp"           # compiled aside and swapped in at the end: a compile error leaves the previous tree alone
     if os.path.isdir(out):
         shutil.rmtree(out)
     packages = set()
@@ -60,8 +61,11 @@ def build(ref=REF, out=OUT, quiet=False):
             os.remove(empty)
     with open(os.path.join(out, "BUILD_INFO"), "w") as f:
         f.write(f"bytecode ({tag}) of {len(MODULES)} reference modules compiled from {ref} by oracle/build_ref.py; no sources here\n")
+    if os.path.isdir(final):
+        shutil.rmtree(final)
+    os.rename(out, final)
     if not quiet:
-        print(f"[build_ref] wrote {len(MODULES)} modules + {len(packages)} packages under {out}")
+        print(f"[build_ref] wrote {len(MODULES)} modules + {len(packages)} packages under {final}")
     return True
 
 

@@ -15,8 +15,28 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_DIR = os.path.join(HERE, "_ref")
 
 
+_available = None
+
+
 def available():
-    return os.path.exists(os.path.join(REF_DIR, "lvdm", "modules", "networks", "openaimodel3d.pyc"))
+    """True when oracle/_ref is present AND importable by THIS interpreter.  The tree is bytecode: built by another CPython minor
+    version it fails with ImportError (bad magic number) - callers then fall back to the oracle port (bench.py `cpu_baseline.kind`
+    = "port") or skip, instead of dying inside the import."""
+    global _available
+    if _available is None:
+        _available = False
+        if os.path.exists(os.path.join(REF_DIR, "lvdm", "modules", "networks", "openaimodel3d.pyc")):
+            try:
+                import_reference()
+                _available = True
+            except Exception as e:      # ImportError / bad magic / a stale tree
+                print(f"[ref_runner] oracle/_ref is present but not importable here ({type(e).__name__}: {e}); using the oracle port",
+                      file=sys.stderr)
+                for name in [n for n in sys.modules if n == "lvdm" or n.startswith("lvdm.") or n == "utils.diffusion_utils"]:
+                    sys.modules.pop(name, None)
+                if REF_DIR in sys.path:
+                    sys.path.remove(REF_DIR)
+    return _available
 
 
 _REF_MODULES = ("lvdm.models.ddpm3d", "lvdm.models.autoencoder", "lvdm.models.samplers.ddim", "lvdm.models.samplers.ddim_multiplecond",

@@ -549,10 +549,14 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
 int vcx_flash2_launch(const Flash2Args& a, hipStream_t s) {
     const int prob_pad = (a.nprob + 7) / 8 * 8;
     const dim3 grid((unsigned)(a.nqb * prob_pad));
-    const int abl = vcx_tune(VCX_TUNE_EXP0), sumv = vcx_tune(VCX_TUNE_EXP1);      // timing-only ablations / A-B (tools/flash_ab.py); 0, 0 = the product
 #define F2_LAUNCH(A, SV) hipLaunchKernelGGL((flash2_d64_kernel<A, SV>), grid, dim3(256), 0, s, a)
+#ifndef VCX_FLASH2_ABLATIONS
+    // the product: one kernel, no knob read - the scratch knobs EXP0 / EXP1 ("free for one-off experiments", vcx.h) must not be
+    // able to turn every 9216-key self-attention into VCX_EINVAL because some unrelated experiment set them
+    F2_LAUNCH(0, F2_SUMV_DEFAULT);
+#else
+    const int abl = vcx_tune(VCX_TUNE_EXP0), sumv = vcx_tune(VCX_TUNE_EXP1);      // timing-only ablations / A-B (tools/flash_ab.py); 0, 0 = the product
     if (abl == 0 && sumv == 0) F2_LAUNCH(0, F2_SUMV_DEFAULT);
-#ifdef VCX_FLASH2_ABLATIONS
     else if (abl == 0 && sumv == 1) F2_LAUNCH(0, 1);
     else if (abl == 0 && sumv == 2) F2_LAUNCH(0, 0);
     else if (abl == 1) F2_LAUNCH(1, F2_SUMV_DEFAULT);
@@ -565,11 +569,11 @@ int vcx_flash2_launch(const Flash2Args& a, hipStream_t s) {
     else if (abl == 64) F2_LAUNCH(64, F2_SUMV_DEFAULT);
     else if (abl == 72) F2_LAUNCH(72, F2_SUMV_DEFAULT);
     else if (abl == 59) F2_LAUNCH(59, F2_SUMV_DEFAULT);
-#endif
     else {
-        vcx_set_error("vcx_attn_flash_d64_f16(v2): variant EXP0=%d EXP1=%d is not compiled in (build with -DVCX_FLASH2_ABLATIONS)", abl, sumv);
+        vcx_set_error("vcx_attn_flash_d64_f16(v2): ablation variant EXP0=%d EXP1=%d does not exist", abl, sumv);
         return VCX_EINVAL;
     }
+#endif
 #undef F2_LAUNCH
     return vcx_check_launch("vcx_attn_flash_d64_f16(v2)");
 }

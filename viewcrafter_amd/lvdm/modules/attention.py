@@ -40,23 +40,65 @@ FOLD_LAYERNORM_FF = os.environ.get("VCX_LN_FOLD_FF", "0") == "1"
 
 def _ln_projection(w, ln, alpha=1.0, bias=None):
     """Packed form of `Linear(w, bias)(LayerNorm(.)) * alpha` (alpha scales the product, not the layer's own bias): folded
-    (w', colsum, bias') when `ln` is given, plain fp16 weights otherwise (colsum None: the caller normalises first)."""
+    (w', colsum, bias') when `ln` is given, plain fp16 weights otherwise (colsum None: the caller normalises first).  A folded
+    pack keeps what it needs to build the plain form on demand (`_plain`: shapes the folded kernel cannot take, ops.lnfold_ok)."""
     if ln is not None:
         wf, colsum, bias_f = fold_layernorm(w, ln.weight, ln.bias, None)
         bias_f = bias_f * alpha
         if bias is not None:
             bias_f = bias_f + bias.detach().float()
-        return dict(w=wf, colsum=colsum, bias=bias_f.contiguous(), eps=ln.eps)
+        return dict(w=wf, colsum=colsum, bias=bias_f.contiguous(), eps=ln.eps, _src=(w, bias), _plain=None)
     return dict(w=_f16(w), colsum=None, bias=None if bias is None else _f32(bias), eps=None)
+
+
+def _plain_of(pj):
+    """The un-folded fp16 weights (+ fp32 bias) of a folded pack, built once when a call cannot use the fold."""
+    if pj["_plain"] is None:
+        w, bias = pj["_src"]
+        with torch.no_grad():
+            pj["_plain"] = (_f16(w), None if bias is None else _f32(bias))
+    return pj["_plain"]
+
+
+def ln_linear(t, pj, lnp, alpha=1.0, stats=None, **kw):
+    """Linear(LayerNorm(t)) * alpha for a pack of _ln_projection: the folded projection of the un-normalised rows where the pack
+    is folded AND the kernel takes the shape, layer_norm + plain projection otherwise.  lnp = (gamma, beta, eps); `stats` =
+    row statistics of t when the caller already has them."""
+    rows, K = t.shape
+    if pj["colsum"] is not None and ops.lnfold_ok(rows, pj["w"].shape[0], K, lda=t.stride(0)):
+        st = stats if stats is not None else ops.row_stats(t, lnp[2])
+        return ops.linear(t, pj["w"], pj["bias"], alpha=alpha, ln_stats=st, ln_colsum=pj["colsum"], **kw)
+    w, bias = (pj["w"], pj["bias"]) if pj["colsum"] is None else _plain_of(pj)
+    return ops.linear(ops.layer_norm(t, *lnp), w, bias, alpha=alpha, **kw)
+
+
+def ln_linear_t(t, pj, lnp, stats=None):
+    """The transposed projection out[D, tokens] = W LayerNorm(t)^T (V^T of the spatial self-attention), same rule as ln_linear."""
+    tokens, K = t.shape
+    D = pj["w"].shape[0]
+    if pj["colsum"] is not None and ops.lnfold_ok(tokens, D, K, lda=t.stride(0), transposed=True):
+        st = stats if stats is not None else ops.row_stats(t, lnp[2])
+        return ops.gemm(pj["w"], t, M=D, N=tokens, K=K, lda=K, ldw=t.stride(0), bias=pj["bias"], bias_m=True, ln_stats=st,
+                        ln_colsum=pj["colsum"], ln_t=True)
+    w, bias = (pj["w"], pj["bias"]) if pj["colsum"] is None else _plain_of(pj)
+    return ops.gemm(w, ops.layer_norm(t, *lnp), M=D, N=tokens, K=K, lda=K, bias=bias, bias_m=bias is not None)
+
+
+def _sig(tensors):
+    return tuple((p.data_ptr(), p._version) for p in tensors)
 
 
 class PackedModule(nn.Module):
     """Base for modules that keep kernel-layout copies of their parameters in `self._pk` (built lazily on the first
-    forward, dropped whenever parameters are moved/cast or a state dict is loaded)."""
+    forward, dropped whenever parameters are moved/cast or a state dict is loaded).  A pack that embeds parameters of ANOTHER
+    module (the folded LayerNorm of the owning BasicTransformerBlock, `_pre_norm`) also remembers their identity and version
+    counter and is rebuilt when either changes - `blk.norm1.load_state_dict(...)`, `.data` assignment or in-place edits of the
+    norm no longer leave stale folded weights behind."""
 
     def __init__(self):
         super().__init__()
         self._pk = None
+        self._pk_sig = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_packed())
 
     def _drop_packed(self):
@@ -66,10 +108,18 @@ class PackedModule(nn.Module):
         self._pk = None
         return super()._apply(fn, recurse)
 
+    def _foreign_params(self):
+        pre = getattr(self, "_pre_norm", None)
+        return [pre[0].weight, pre[0].bias] if pre else []
+
     def packed(self):
+        foreign = self._foreign_params()
+        if self._pk is not None and foreign and _sig(foreign) != self._pk_sig:
+            self._pk = None
         if self._pk is None:
             with torch.no_grad():
                 self._pk = self._pack()
+            self._pk_sig = _sig(foreign)
         return self._pk
 
     def _pack(self):
@@ -168,10 +218,14 @@ class FeedForward(PackedModule):
     def run(self, t, ln_params):
         """t + FF(LayerNorm(t)); ln_params = (gamma, beta, eps) of the LayerNorm in front (used when it is not folded into w1)."""
         pk = self.packed()
-        if pk["colsum"] is not None:
+        if pk["colsum"] is not None and ops.lnfold_ok(t.shape[0], pk["w1"].shape[0], t.shape[1], lda=t.stride(0)):
             g = ops.linear(t, pk["w1"], pk["b1"], geglu=True, ln_stats=ops.row_stats(t, ln_params[2]), ln_colsum=pk["colsum"])
         else:
-            g = ops.linear(ops.layer_norm(t, *ln_params), pk["w1"], pk["b1"], geglu=True)
+            if pk["colsum"] is not None and "w1_plain" not in pk:      # folded pack, shape the folded kernel cannot take
+                proj = self.net[0].proj
+                pk["w1_plain"], pk["b1_plain"] = pack_geglu(_f16(proj.weight), _f32(proj.bias))
+            w1, b1 = (pk["w1"], pk["b1"]) if pk["colsum"] is None else (pk["w1_plain"], pk["b1_plain"])
+            g = ops.linear(ops.layer_norm(t, *ln_params), w1, b1, geglu=True)
         return ops.linear(g, pk["w2"], pk["b2"], residual=t)
 
 
@@ -310,26 +364,17 @@ class SpatialTransformer(PackedModule):
             # scale * log2(e) rides in the projections (sqrt of it on Q and on K: one fp16 rounding each, as without it), so the
             # attention kernel gets base-2 logits and its running max can live in the MFMA accumulator (VCX_ATTN_LOG2_LOGITS)
             pqk, pv, qk_alpha = a1["qk"], a1["v"], math.sqrt(blk.attn1.scale * ops.LOG2E)
-            if pqk["colsum"] is not None:      # norm1 folded into both projections: they read the token stream itself
-                st = ops.row_stats(t, ln[0][2])
-                qk = ops.linear(t, pqk["w"], pqk["bias"], alpha=qk_alpha, ln_stats=st, ln_colsum=pqk["colsum"])   # [tokens, 2D]
-                vt = ops.gemm(pv["w"], t, M=D, N=tokens, K=D, lda=D, bias=pv["bias"], bias_m=True, ln_stats=st,
-                              ln_colsum=pv["colsum"], ln_t=True)                                                    # [D, tokens]
-            else:
-                h1 = ops.layer_norm(t, *ln[0])
-                qk = ops.linear(h1, pqk["w"], alpha=qk_alpha)
-                vt = ops.gemm(pv["w"], h1, M=D, N=tokens, K=D, lda=D)
+            # norm1 folded into both projections (they read the token stream itself) wherever the pack is folded and the kernel
+            # takes the shape; layer_norm + plain projections otherwise (ln_linear / ln_linear_t)
+            st = ops.row_stats(t, ln[0][2]) if pqk["colsum"] is not None else None
+            qk = ln_linear(t, pqk, ln[0], alpha=qk_alpha, stats=st)                 # [tokens, 2D]
+            vt = ln_linear_t(t, pv, ln[0], stats=st)                                # [D, tokens]
             o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
             ops.flash_attn(qk, qk[:, D:], vt, o, n_groups=n, heads=heads, nq=N, nk=N_img, kv_rows=N, kv_div=1, ldq=2 * D,
                            ldk=2 * D, ldvt=tokens, ldo=D, scale=blk.attn1.scale, log2_logits=True)
             t = ops.linear(o, a1["wo"], a1["bo"], residual=t)
             # ---- cross-attention: softmax(Q K_txt) V_txt + softmax(Q K_img) V_img
-            pq = a2["q"]
-            if pq["colsum"] is not None:
-                q2 = ops.linear(t, pq["w"], pq["bias"], alpha=blk.attn2.scale * ops.LOG2E, ln_stats=ops.row_stats(t, ln[1][2]),
-                                ln_colsum=pq["colsum"])
-            else:
-                q2 = ops.linear(ops.layer_norm(t, *ln[1]), pq["w"], alpha=blk.attn2.scale * ops.LOG2E)
+            q2 = ln_linear(t, a2["q"], ln[1], alpha=blk.attn2.scale * ops.LOG2E)
             if bi == 0 and cfg_repeat > 1:      # from here on the r conditionings differ
                 t, q2, xin = ops.repeat_rows(t, cfg_repeat), ops.repeat_rows(q2, cfg_repeat), ops.repeat_rows(xin, cfg_repeat)
                 n, tokens = n * cfg_repeat, tokens * cfg_repeat
@@ -407,11 +452,7 @@ class TemporalTransformer(PackedModule):
             ln = blk.ln_params()
             for attn, lnp in ((blk.attn1, ln[0]), (blk.attn2, ln[1])):
                 ap = attn.packed()
-                pj = ap["qkv"]
-                if pj["colsum"] is not None:
-                    qkv = ops.linear(t, pj["w"], pj["bias"], ln_stats=ops.row_stats(t, lnp[2]), ln_colsum=pj["colsum"])   # [tokens, 3D]
-                else:
-                    qkv = ops.linear(ops.layer_norm(t, *lnp), pj["w"])
+                qkv = ln_linear(t, ap["qkv"], lnp)                                   # [tokens, 3D]
                 o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
                 ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D, ldo=D,
                                   scale=attn.scale)

@@ -110,6 +110,21 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
     return out
 
 
+def lnfold_ok(rows, n_out, K, *, lda=None, ldc=None, transposed=False):
+    """Will vcx_gemm_f16 take a folded-LayerNorm projection (VCX_GEMM_LNFOLD / _T) of `rows` token rows x K channels onto n_out
+    outputs?  The epilogue exists in the DMA kernel only; this mirrors its preconditions in csrc/gemm.hip (`dma_ok`: knob
+    GEMM_DMA, K % 64 == 0, GEMM N % 8 == 0, every extent and the output offsets up to 256 rows past the end below 4 GiB).  Where it
+    says no - a longer clip or a larger frame than any shipped config - the caller runs layer_norm + the plain projection, as
+    before the fold existed, instead of getting VCX_EINVAL from every transformer block."""
+    lim = 0xFFFF0000
+    lda = K if lda is None else lda
+    M, N = (n_out, rows) if transposed else (rows, n_out)          # GEMM axes: LNFOLD_T puts the weight rows on M
+    ldc = N if ldc is None else ldc
+    a_rows, a_ld, w_rows, w_ld = (n_out, K, rows, lda) if transposed else (rows, lda, n_out, K)
+    return (tune_get("GEMM_DMA") != 0 and K % 64 == 0 and N % 8 == 0 and (n_out % 4 == 0 and n_out >= 4)
+            and 2 * ((a_rows - 1) * a_ld + K) < lim and 2 * ((w_rows - 1) * w_ld + K) < lim and 2 * (M + 256) * ldc < lim)
+
+
 def linear(x, w, bias=None, **kw):
     """x [rows, K] (row stride may exceed K) times w [N, K]^T."""
     rows, K = x.shape
