@@ -1,0 +1,173 @@
+"""Bit-reproducibility soak (round 4).  Round 3 found two run-dependent results in ONE template instantiation (the 128x128 LNFOLD_T
+epilogue, profiles/r03_experiments.md section 11 / profiles/r04_pkfma_rootcause.md) and a ten-call loop over small shapes was the only
+run-time guard.  Here:
+
+  * every `gemm_dma_kernel` instantiation the dispatcher can reach - 4 tile configurations x {linear, conv} x {plain (+ bias, residual,
+    per-image addend), fp32 output, GEGLU, LNFOLD, LNFOLD + GEGLU, LNFOLD_T, COLSTATS} = 34 kernels - 200 calls each on a problem
+    that fills the persistent grid several times over, every call compared bit for bit with the first (also the column moments);
+  * the attention / normalisation kernels at the benchmark's own shapes, 50 calls each;
+  * the whole B = 2 (cond + uncond) UNet forward at the headline latent 25x72x128, 20 runs, identical bits - with and without the
+    shared CFG prefix.
+
+All reductions in libvcx have a fixed order and there are no floating-point atomics, so ANY differing bit is a defect."""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CALLS = int(os.environ.get("VCX_SOAK_CALLS", "200"))
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _soak(fn, calls, what):
+    first = fn()
+    first = tuple(t.clone() for t in (first if isinstance(first, tuple) else (first,)))
+    torch.cuda.synchronize()
+    for i in range(1, calls):
+        out = fn()
+        out = out if isinstance(out, tuple) else (out,)
+        for a, b in zip(out, first):
+            if not torch.equal(a, b):
+                nd = int((a != b).sum())
+                idx = (a != b).nonzero()[:8].tolist()
+                pytest.fail(f"{what}: call {i} differs from call 0 in {nd} elements, first at {idx}")
+    assert all(torch.isfinite(t.float()).all() for t in first), what
+
+
+# variant -> (conv?, needs NF % 4 == 0 i.e. tile configs 0 / 2 only)
+VARIANTS = {"plain": (False, False), "f32": (False, False), "geglu": (False, True), "lnfold": (False, False), "lnfold_geglu": (False, True),
+            "lnfold_t": (False, False), "conv": (True, False), "conv_f32": (True, False), "conv_geglu": (True, True),
+            "conv_colstats": (True, False)}
+
+
+_DATA = {}
+
+
+def _gemm_data():
+    """Operands shared by the 34 cases (built once: 33 k x 640 activations, a 3x3 convolution input with 65-pixel rows)."""
+    if not _DATA:
+        from viewcrafter_amd.packing import pack_conv
+        # the persistent grid is filled at least twice in every configuration (128-row tiles: 2 blocks / CU, 256-row tiles: 1 block / CU)
+        M, K, N = 32768 + 128, 640, 1280           # 2 (256x320) ... 5 (128x128) rounds; ragged last tile rows in the 256-row configurations
+        n_img, Hh, Ww, cin = 16, 32, 64 + 1, 128   # M = 33280 image rows, 65 columns: border taps in every tile
+        w32 = (rnd(N, K, seed=2) / math.sqrt(K)).to(DEV)
+        _DATA.update(M=M, K=K, N=N, n_img=n_img, Hh=Hh, Ww=Ww, x=(rnd(M, K, seed=1) * 2 + 0.5).to(DEV).half(), bias=rnd(N, seed=3).to(DEV),
+                     res=rnd(M, N, seed=4).to(DEV).half(), gamma=(1 + 0.3 * rnd(K, seed=5)).to(DEV), beta=(0.2 * rnd(K, seed=6)).to(DEV),
+                     w32=w32, w=w32.half(), xi=rnd(n_img, Hh, Ww, cin, seed=7).to(DEV).half(),
+                     wc=pack_conv(rnd(N, cin, 3, 3, seed=8) / math.sqrt(9 * cin)).to(DEV).half(), rowadd=rnd(n_img, N, seed=9).to(DEV),
+                     resc=rnd(n_img * Hh * Ww, N, seed=10).to(DEV).half())
+    return _DATA
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_every_dma_gemm_instantiation_is_bit_reproducible(cfg, variant):
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import fold_layernorm, pack_geglu
+    conv, needs_nf4 = VARIANTS[variant]
+    if needs_nf4 and cfg in (1, 3):
+        pytest.skip("GEGLU needs whole 64-column blocks per wave: tile configurations 128x128 and 256x256 only")
+    d = _gemm_data()
+    M, N, K, n_img, Hh, Ww = d["M"], d["N"], d["K"], d["n_img"], d["Hh"], d["Ww"]
+    x, bias, res, gamma, beta, w32, w = d["x"], d["bias"], d["res"], d["gamma"], d["beta"], d["w32"], d["w"]
+    xi, wc, rowadd, resc = d["xi"], d["wc"], d["rowadd"], d["resc"]
+    prev = ops.tune_set("GEMM_CFG", cfg)
+    try:
+        if variant == "plain":
+            fn = lambda: ops.linear(x, w, bias, residual=res)
+        elif variant == "f32":
+            fn = lambda: ops.linear(x, w, bias, out_f32=True)
+        elif variant == "geglu":
+            wg, bg = pack_geglu(w, bias)
+            fn = lambda: ops.linear(x, wg, bg, geglu=True)
+        elif variant in ("lnfold", "lnfold_geglu", "lnfold_t"):
+            wf, colsum, bias_f = fold_layernorm(w32, gamma, beta, bias if variant != "lnfold_t" else None)
+            st = ops.row_stats(x, 1e-5)
+            if variant == "lnfold":
+                fn = lambda: ops.linear(x, wf, bias_f, residual=res, ln_stats=st, ln_colsum=colsum)
+            elif variant == "lnfold_geglu":
+                wg, bg = pack_geglu(wf, bias_f)
+                cg = pack_geglu(wf, colsum)[1]
+                fn = lambda: ops.linear(x, wg, bg, geglu=True, ln_stats=st, ln_colsum=cg)
+            else:
+                fn = lambda: ops.gemm(wf, x, M=N, N=M, K=K, lda=K, bias=bias_f, bias_m=True, ln_stats=st, ln_colsum=colsum, ln_t=True)
+        elif variant == "conv":
+            fn = lambda: ops.conv2d(xi, wc, bias, kh=3, kw=3, residual=resc, rowadd=rowadd, rowadd_div=Hh * Ww)
+        elif variant == "conv_f32":
+            fn = lambda: ops.conv2d(xi, wc, bias, kh=3, kw=3, out_f32=True)
+        elif variant == "conv_geglu":
+            wg, bg = pack_geglu(wc, bias)
+            fn = lambda: ops.conv2d(xi, wg, bg, kh=3, kw=3, geglu=True)
+        else:
+            xs = xi[:, :, :64].contiguous()            # COLSTATS: whole 64-row strips per frame (32 x 64 pixels)
+            Ms = n_img * Hh * 64
+            def fn():
+                cs = ops.colstats_buffer(Ms, N, DEV)
+                y = ops.conv2d(xs, wc, bias, kh=3, kw=3, rowadd=rowadd, rowadd_div=Hh * 64, colstats=cs)
+                return y, cs
+        _soak(fn, CALLS, f"gemm_dma cfg {cfg} {variant}")
+    finally:
+        ops.tune_set("GEMM_CFG", prev)
+
+
+def test_attention_and_norm_kernels_are_bit_reproducible_at_the_benchmark_shapes():
+    from viewcrafter_amd import ops
+    calls = max(CALLS // 4, 10)
+    # spatial self-attention of level 0 (flash2, 9216 keys) and level 1 (phased kernel, 2304 keys), 4 frames x 5 / 10 heads
+    for N_img, D in ((9216, 320), (2304, 640)):
+        n, heads = 4, D // 64
+        tokens = n * N_img
+        qk = rnd(tokens, 2 * D, seed=21).to(DEV).half()
+        vt = rnd(D, tokens, seed=22).to(DEV).half()
+
+        def attn():
+            o = torch.empty((tokens, D), dtype=torch.float16, device=DEV)
+            return ops.flash_attn(qk, qk[:, D:], vt, o, n_groups=n, heads=heads, nq=N_img, nk=N_img, kv_rows=N_img, kv_div=1, ldq=2 * D,
+                                  ldk=2 * D, ldvt=tokens, ldo=D, scale=0.125, log2_logits=True)
+        _soak(attn, calls, f"flash attention {N_img} keys")
+    # temporal attention, level 0: 25 frames, 2304 pixels
+    B, T, P, D = 1, 25, 2304, 320
+    qkv = rnd(B * T * P, 3 * D, seed=23).to(DEV).half()
+
+    def tattn():
+        o = torch.empty((B * T * P, D), dtype=torch.float16, device=DEV)
+        return ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=D // 64, ld=3 * D, k_off=D, v_off=2 * D, ldo=D, scale=0.125)
+    _soak(tattn, calls, "temporal attention")
+    x = (rnd(2, 25 * 2304, 320, seed=24) * 2 + 0.7).to(DEV).half()
+    g, b = (1 + 0.2 * rnd(320, seed=25)).to(DEV), (0.1 * rnd(320, seed=26)).to(DEV)
+    _soak(lambda: ops.group_norm(x, g, b, 1e-5, True), calls, "groupnorm per video")
+    xr = x.view(-1, 320)
+    _soak(lambda: ops.layer_norm(xr, g, b, 1e-5), calls, "layernorm")
+    _soak(lambda: ops.row_stats(xr, 1e-5), calls, "row statistics")
+
+
+@pytest.mark.parametrize("share_prefix", [True, False])
+def test_b2_unet_forward_at_25x72x128_is_bit_reproducible_over_20_runs(share_prefix):
+    """The cond + uncond evaluation of one DDIM step at the headline latent, as the sampler launches it (B = 2, with the shared
+    CFG prefix and as a plain batched forward): 20 runs, identical bits."""
+    from tests.test_fullconfig_gpu import _inputs, _model
+    model, _ = _model("inference_pvd_1024.yaml")
+    unet = model.model.diffusion_model
+    T, h, w = 25, 72, 128
+    x, ctx = _inputs(T, h, w, seed=99, B=2)
+    ts, fs = torch.tensor([599, 599], device=DEV), torch.tensor([10, 10], device=DEV)
+    if share_prefix:
+        x = x[:1].contiguous()
+        ts, fs = ts[:1], fs[:1]
+
+    def fwd():
+        with torch.no_grad():
+            if share_prefix:
+                return unet._forward(x, ts, context=ctx, fs=fs, cfg_repeat=2)
+            return unet(x, ts, context=ctx, fs=fs)
+    runs = int(os.environ.get("VCX_SOAK_FORWARDS", "20"))
+    _soak(fwd, runs, f"B=2 UNet forward 25x72x128 (shared prefix: {share_prefix})")
+    torch.cuda.empty_cache()
