@@ -34,7 +34,7 @@ extern "C" {
 
 /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*.  3: vcx_gemm_desc grows ln_stats / ln_colsum (VCX_GEMM_LNFOLD*),
  * vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32.  5: vcx_gemm_desc starts with
- * struct_size - a descriptor of another layout is rejected instead of read past its end. */
+ * struct_size - a descriptor of another layout is rejected instead of read past its end; vcx_clip_preprocess_f32. */
 #define VCX_ABI_VERSION 5
 
 int vcx_abi_version(void);
@@ -206,6 +206,13 @@ int vcx_silu_f32(const float* x, float* y, int64_t n, void* stream);
 /* exact (erf) GELU on fp16 -> fp16, y may alias x (nn.GELU of the Resampler feed-forward,
  * lvdm/modules/encoders/resampler.py:27-34). */
 int vcx_gelu_f16(const void* x, void* y, int64_t n, void* stream);
+/* Image pre-processing of the OpenCLIP vision tower, lvdm/modules/encoders/condition.py:322-329:
+ * kornia.geometry.resize(x, (size, size), 'bicubic', align_corners=True, antialias) -> (x + 1) / 2 -> (x - mean) / std.
+ * x fp32 [B, C, H, W] in [-1, 1] (C <= 4), y fp32 [B, C, size, size]; mean_host / std_host: C host floats.  kornia's anti-aliasing
+ * (Gaussian, sigma = (factor - 1) / 2 per axis, kernel int(max(4 sigma, 3)) made odd, mirror border; only when an axis shrinks)
+ * and torch's bicubic (A = -0.75, clamped neighbours) are evaluated in one pass, the blurred image is never written. */
+int vcx_clip_preprocess_f32(const float* x, float* y, int B, int C, int H, int W, int size, int antialias,
+                            const float* mean_host, const float* std_host, void* stream);
 /* sinusoidal embedding, lvdm/models/utils_diffusion.py:8-28: out[b] = [cos(t f) | sin(t f)] */
 int vcx_timestep_embedding_f32(const int64_t* t, float* out, int B, int dim, float max_period,
                                void* stream);

@@ -165,6 +165,101 @@ __global__ void gelu_f16_kernel(const half_t* x, half_t* y, int64_t n8) {
     }
 }
 
+// Image pre-processing in front of the OpenCLIP vision tower (reference condition.py:322-329: kornia.geometry.resize(bicubic,
+// align_corners=True, antialias) -> (x + 1) / 2 -> normalize(mean, std)), one thread per output pixel.  kornia's anti-aliasing is a
+// separable Gaussian over the whole image (mirror border without the edge sample) followed by torch's bicubic interpolation (Keys
+// cubic convolution, A = -0.75, neighbour indices clamped): out = sum_i cy_i sum_k gy_k sum_j cx_j sum_l gx_l
+// x[mirror(clamp(y0 - 1 + i) + k - ksy / 2)][mirror(clamp(x0 - 1 + j) + l - ksx / 2)] - the blurred image is never materialised
+// (4 ksy x 4 ksx taps per output, 336 at 576x1024 -> 224; once per video).  ksy = ksx = 1 (no blur) when nothing shrinks.
+__device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    c[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    c[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+__device__ __forceinline__ int mirror_index(int j, int n) {
+    j = j < 0 ? -j : j;
+    return j > n - 1 ? 2 * (n - 1) - j : j;
+}
+struct ClipPreArgs {
+    int B, C, H, W, S, ksy, ksx;
+    float sy, sx;          // Gaussian sigmas
+    float ry, rx;          // source step per output pixel: (in - 1) / (out - 1)
+    float mean[4], istd[4];
+};
+__global__ void clip_preprocess_kernel(const float* __restrict__ x, float* __restrict__ y, ClipPreArgs a) {
+    const int64_t total = (int64_t)a.B * a.C * a.S * a.S;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % a.S), oy = (int)((i / a.S) % a.S);
+    const int64_t bc = i / ((int64_t)a.S * a.S);
+    const int c = (int)(bc % a.C);
+    const float* src = x + bc * (int64_t)a.H * a.W;
+    const float fy = (float)oy * a.ry, fx = (float)ox * a.rx;
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    float cy[4], cx[4];
+    cubic_coeffs(fy - (float)y0, cy);
+    cubic_coeffs(fx - (float)x0, cx);
+    const int hy = a.ksy >> 1, hx = a.ksx >> 1;
+    float ny = 0.f, nx = 0.f;          // Gaussian normalisers
+    for (int k = 0; k < a.ksy; ++k) { const float d = (float)(k - hy); ny += expf(-d * d / (2.f * a.sy * a.sy)); }
+    for (int k = 0; k < a.ksx; ++k) { const float d = (float)(k - hx); nx += expf(-d * d / (2.f * a.sx * a.sx)); }
+    float acc = 0.f;
+    for (int iy = 0; iy < 4; ++iy) {
+        const int yc = min(max(y0 - 1 + iy, 0), a.H - 1);
+        for (int k = 0; k < a.ksy; ++k) {
+            const float dy = (float)(k - hy);
+            const float wy = cy[iy] * (a.ksy > 1 ? expf(-dy * dy / (2.f * a.sy * a.sy)) / ny : 1.f);
+            const float* row = src + (int64_t)mirror_index(yc + k - hy, a.H) * a.W;
+            float racc = 0.f;
+            for (int ix = 0; ix < 4; ++ix) {
+                const int xc = min(max(x0 - 1 + ix, 0), a.W - 1);
+                float g = 0.f;
+                for (int l = 0; l < a.ksx; ++l) {
+                    const float dx = (float)(l - hx);
+                    const float wx = a.ksx > 1 ? expf(-dx * dx / (2.f * a.sx * a.sx)) / nx : 1.f;
+                    g = fmaf(wx, row[mirror_index(xc + l - hx, a.W)], g);
+                }
+                racc = fmaf(cx[ix], g, racc);
+            }
+            acc = fmaf(wy, racc, acc);
+        }
+    }
+    y[i] = ((acc + 1.f) * 0.5f - a.mean[c]) * a.istd[c];
+}
+
+extern "C" int vcx_clip_preprocess_f32(const float* x, float* y, int B, int C, int H, int W, int size, int antialias,
+                                       const float* mean_host, const float* std_host, void* stream) {
+    VCX_REQUIRE(x && y && mean_host && std_host, "vcx_clip_preprocess_f32: null pointer");
+    VCX_REQUIRE(B > 0 && C > 0 && C <= 4 && H > 1 && W > 1 && size > 1, "vcx_clip_preprocess_f32: bad shape B=%d C=%d H=%d W=%d size=%d", B, C, H, W, size);
+    ClipPreArgs a;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.S = size;
+    const double fy = (double)H / size, fx = (double)W / size;
+    a.ksy = a.ksx = 1;
+    a.sy = a.sx = 1.f;
+    if (antialias && (fy > 1.0 || fx > 1.0) && !(H == size && W == size)) {       // kornia: blur only when an axis shrinks, sigma = (factor - 1) / 2
+        const double sy = fmax((fy - 1.0) / 2.0, 0.001), sx = fmax((fx - 1.0) / 2.0, 0.001);
+        int ky = (int)fmax(4.0 * sy, 3.0), kx = (int)fmax(4.0 * sx, 3.0);
+        ky += 1 - (ky & 1);
+        kx += 1 - (kx & 1);
+        VCX_REQUIRE(ky / 2 < H && kx / 2 < W, "vcx_clip_preprocess_f32: blur kernel %dx%d exceeds the image %dx%d", ky, kx, H, W);
+        a.ksy = ky; a.ksx = kx; a.sy = (float)sy; a.sx = (float)sx;
+    }
+    a.ry = (float)((double)(H - 1) / (size - 1));
+    a.rx = (float)((double)(W - 1) / (size - 1));
+    for (int c = 0; c < 4; ++c) {
+        a.mean[c] = c < C ? mean_host[c] : 0.f;
+        a.istd[c] = c < C ? 1.f / std_host[c] : 1.f;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * C * size * size;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 4.0 * ((double)B * C * H * W + (double)total));
+    hipLaunchKernelGGL(clip_preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, a);
+    return vcx_check_launch("vcx_clip_preprocess_f32");
+}
+
 extern "C" int vcx_gelu_f16(const void* x, void* y, int64_t n, void* stream) {
     VCX_REQUIRE(x && y && n > 0 && n % 8 == 0, "vcx_gelu_f16: bad arguments (n must be a multiple of 8)");
     VCX_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "vcx_gelu_f16: pointers must be 16-byte aligned");

@@ -317,35 +317,13 @@ class FrozenOpenCLIPEmbedder(AbstractEncoder):
         return self(text)
 
 
-def _gauss1d(ks, sigma, dtype, device):
-    x = torch.arange(ks, dtype=dtype, device=device) - ks // 2
-    if ks % 2 == 0:
-        x = x + 0.5
-    g = torch.exp(-x.pow(2) / (2.0 * sigma * sigma))
-    return g / g.sum()
-
-
 def clip_preprocess(x, size=224, antialias=True, mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)):
-    """condition.py:325-332: kornia.geometry.resize(bicubic, align_corners=True, antialias) -> [0, 1] -> CLIP mean / std.
-    kornia's anti-aliasing is a separable Gaussian (sigma = (factor - 1) / 2 per axis, kernel 4 sigma made odd, >= 3, reflect
-    border) applied only when shrinking.  Host-side image plumbing (one 224x224 image per clip), plain torch on the device."""
-    x = x.float()
-    h, w = x.shape[-2:]
-    fy, fx = h / size, w / size
-    if antialias and max(fy, fx) > 1:
-        sy, sx = max((fy - 1.0) / 2.0, 0.001), max((fx - 1.0) / 2.0, 0.001)
-        ky, kx = int(max(4.0 * sy, 3)), int(max(4.0 * sx, 3))
-        ky, kx = ky + 1 - ky % 2, kx + 1 - kx % 2
-        c = x.shape[1]
-        gy = _gauss1d(ky, sy, x.dtype, x.device).view(1, 1, -1, 1).expand(c, 1, -1, 1)
-        gx = _gauss1d(kx, sx, x.dtype, x.device).view(1, 1, 1, -1).expand(c, 1, 1, -1)
-        x = F.pad(x, (kx // 2, kx // 2, ky // 2, ky // 2), mode="reflect")
-        x = F.conv2d(F.conv2d(x, gx, groups=c), gy, groups=c)
-    x = F.interpolate(x, size=(size, size), mode="bicubic", align_corners=True)
-    x = (x + 1.0) / 2.0
-    mean = torch.tensor(mean, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
-    std = torch.tensor(std, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
-    return (x - mean) / std
+    """condition.py:322-329: kornia.geometry.resize(bicubic, align_corners=True, antialias) -> [0, 1] -> CLIP mean / std, as ONE
+    libvcx kernel (vcx_clip_preprocess_f32; round 4 - it was plain torch conv2d / interpolate before).  kornia's anti-aliasing is
+    a separable Gaussian (sigma = (factor - 1) / 2 per axis, kernel 4 sigma made odd, >= 3, mirror border) applied only when
+    shrinking.  Pinned by two independent restatements of kornia's published algorithm (oracle/clip_oracle.py on torch ops,
+    oracle/kornia_numpy.py as fp64 matrices) - kornia itself is not in the image."""
+    return ops.clip_preprocess(x.float(), size, antialias, mean, std)
 
 
 class FrozenOpenCLIPImageEmbedderV2(AbstractEncoder):

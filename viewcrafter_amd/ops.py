@@ -283,6 +283,20 @@ def gelu_(x):
     return x
 
 
+def clip_preprocess(x, size, antialias, mean, std):
+    """x fp32 [B, C, H, W] in [-1, 1] -> fp32 [B, C, size, size]: kornia-style anti-aliased bicubic resize, (x + 1) / 2, CLIP
+    mean / std (reference condition.py:322-329) in one kernel."""
+    x = x.contiguous()
+    _dev32(x)
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, size, size), dtype=_f32, device=x.device)
+    m = (ctypes.c_float * C)(*[float(v) for v in mean])
+    s = (ctypes.c_float * C)(*[float(v) for v in std])
+    check(lib().vcx_clip_preprocess_f32(x.data_ptr(), out.data_ptr(), B, C, H, W, int(size), 1 if antialias else 0, m, s, _stream()),
+          "clip_preprocess")
+    return out
+
+
 def timestep_embedding(t, dim, max_period=10000.0):
     t = t.to(torch.int64).contiguous()
     out = torch.empty((t.shape[0], dim), dtype=_f32, device=t.device)
