@@ -362,6 +362,47 @@ def test_clip_tokenizer_contract(tmp_path, monkeypatch):
     cond._bpe_from_env.cache_clear()
 
 
+def test_bpe_tokenizer_matches_transformers_clip_tokenizer(tmp_path, monkeypatch):
+    """Non-empty prompts with $VCX_CLIP_BPE (reference condition.py:209-214 -> open_clip.tokenize): the byte-pair tokenizer against
+    an independent third-party implementation of CLIP's tokenisation that IS in the image - transformers' CLIPTokenizer (Rust
+    `tokenizers` backend) - given the same vocabulary and merges (learned from a small corpus, tests/util.py::write_synthetic_bpe;
+    the real vocabulary file is data that is not available offline).  Lower-casing, whitespace collapsing, apostrophe / digit /
+    punctuation splitting, rank-ordered merges, </w> word ends, <start_of_text> / <end_of_text> ids, truncation at 77."""
+    import pytest
+    pytest.importorskip("transformers")
+    try:
+        import open_clip  # noqa: F401
+        pytest.skip("open_clip is installed: tokenize() delegates to it")
+    except ImportError:
+        pass
+    from transformers import CLIPTokenizer
+    from tests.util import write_synthetic_bpe
+    from viewcrafter_amd.lvdm.modules.encoders import condition as cond
+    path = str(tmp_path / "bpe_syn.txt.gz")
+    merges = write_synthetic_bpe(path)
+    monkeypatch.setenv("VCX_CLIP_BPE", path)
+    cond._bpe_from_env.cache_clear()
+    try:
+        bpe = cond._bpe_from_env()
+        vocab = dict(bpe.encoder)
+        vocab["<|startoftext|>"], vocab["<|endoftext|>"] = vocab.pop("<start_of_text>"), vocab.pop("<end_of_text>")
+        assert vocab["<|startoftext|>"] == 49406 and vocab["<|endoftext|>"] == 49407 and len(vocab) == 49408
+        hf = CLIPTokenizer(vocab=vocab, merges=[tuple(m) for m in merges])
+        prompts = ["A photo of a large room", "the artist's view , camera moving forward .", "naive cafe 22 chairs !!", "  wooden   Furniture ",
+                   "a sweeping view of the old town at night, 4k, highly detailed", "it's", "a " * 100, "view" * 40]
+        merged_tokens = 0
+        for p in prompts:
+            ours = cond.tokenize([p])[0].tolist()
+            theirs = hf(p, padding="max_length", max_length=77, truncation=True)["input_ids"]
+            end = theirs.index(49407)
+            theirs = [t if i <= end else 0 for i, t in enumerate(theirs)]          # HF pads with <end_of_text>, open_clip with 0
+            assert ours == theirs, (p, ours[:16], theirs[:16])
+            merged_tokens += sum(1 for t in ours if 512 <= t < 49406)
+        assert merged_tokens > 20                                                   # the merges were exercised, not only single bytes
+    finally:
+        cond._bpe_from_env.cache_clear()
+
+
 def test_fold_layernorm_is_the_exact_algebra_of_layernorm_then_linear():
     """packing.fold_layernorm (VCX_GEMM_LNFOLD, include/vcx.h): with the ROUNDED fp16 weights w', colsum = their fp32 row sums and
     bias' = bias + w beta,  rstd (x w'^T - mean colsum) + bias'  IS  LayerNorm(x) w^T + bias  up to the fp16 rounding of gamma o w -

@@ -897,3 +897,24 @@ def test_front_end_rejects_wrong_dtype_or_host_tensors():
         ops.layer_norm(x, torch.ones(64, device=DEV).half(), torch.zeros(64, device=DEV))
     with pytest.raises(VcxError, match="fp16"):
         ops.group_norm(x.float().view(1, 64, 64), torch.ones(64, device=DEV), torch.zeros(64, device=DEV), 1e-5, False)
+
+
+# ---------------------------------------------------------------- CLIP image pre-processing
+@pytest.mark.parametrize("shape", [(1, 3, 576, 1024), (2, 3, 320, 512), (1, 3, 96, 64), (1, 3, 224, 224), (1, 3, 301, 500), (1, 3, 224, 600),
+                                   (3, 3, 288, 512), (1, 1, 2160, 3840)])
+def test_clip_preprocess_kernel_vs_fp64_numpy(shape):
+    """vcx_clip_preprocess_f32 (reference condition.py:322-329: kornia anti-aliased bicubic resize -> [0, 1] -> CLIP mean / std)
+    against oracle/kornia_numpy.py, the fp64 matrix form of kornia's published algorithm: both axes shrinking (576x1024: 3x7 blur),
+    one axis only (224x600), up-scaling (no blur), same size (identity), odd sizes, a 4K frame (9x17 blur), antialias off."""
+    import numpy as np
+    from oracle import kornia_numpy as K
+    from viewcrafter_amd import ops
+    B, C, H, W = shape
+    x = torch.tanh(rnd(*shape, seed=611))
+    mean, std = K.CLIP_MEAN[:C], K.CLIP_STD[:C]
+    for aa in (True, False):
+        out = ops.clip_preprocess(x.to(DEV), 224, aa, mean, std)
+        ref = K.clip_preprocess(x.numpy(), 224, aa, mean, std)
+        assert out.dtype == torch.float32 and tuple(out.shape) == (B, C, 224, 224)
+        err = float(np.abs(out.cpu().double().numpy() - ref).max())
+        assert err <= 2e-5, f"{shape} antialias={aa}: max |diff| {err:.2e} (values up to {np.abs(ref).max():.2f})"

@@ -222,6 +222,26 @@ def test_vae_vs_reference_golden(vae):
     assert rel_l2(post.mode(), g["vae_encode_mode"]) <= VAE_TOL
 
 
+@pytest.mark.parametrize("h,w", [(9, 15), (5, 7), (24, 40)])
+def test_vae_at_latent_sizes_whose_token_counts_are_not_multiples_of_8(vae, h, w):
+    """AttnBlock (reference ae_modules.py:26-78) at h*w = 135 / 35 tokens (and 960, the aligned control): the frames' token rows
+    are padded inside the block (round 3 raised here, so a free --height / --width that passed the UNet died in the decoder).
+    decode of two frames and encode of one, against the fp32 oracle on the same weights."""
+    from tests.tiny_config import TINY_DDCONFIG
+    m, sd = vae
+    z = synth_input(f"vae_z_{h}x{w}", (2, 4, h, w)).to(DEV)
+    img = synth_input(f"vae_img_{h}x{w}", (1, 3, 8 * h, 8 * w), scale=0.5).to(DEV)
+    with torch.no_grad():
+        dec = m.decode(z)
+        post = m.encode(img)
+        ref_dec = O.vae_decode(sd, TINY_DDCONFIG, z.cpu())
+        ref_mom = O.vae_encode_moments(sd, TINY_DDCONFIG, img.cpu())
+    assert tuple(dec.shape) == (2, 3, 8 * h, 8 * w) and torch.isfinite(dec).all()
+    e_dec, e_enc = rel_l2(dec, ref_dec), rel_l2(post.parameters, ref_mom)
+    print(f"VAE at latent {h}x{w} ({h * w} tokens): decode rel-L2 {e_dec:.3e}, encode moments {e_enc:.3e}")
+    assert e_dec <= VAE_TOL and e_enc <= VAE_TOL
+
+
 @pytest.mark.parametrize("eta", [0.0, 1.0])
 def test_ddim_trajectory_vs_reference_golden(model, eta):
     """VIPLatentDiffusion.apply_model + DDIMSampler.sample (5 steps, CFG 7.5, rescale 0.7, uniform_trailing, dynamic
@@ -399,3 +419,51 @@ def test_clip_towers_vs_transformers_third_party_pin():
     ei = rel_l2(img(x.to(DEV)), H.hf_vision_tokens(vm, x))
     print(f"CLIP towers vs transformers (third-party pin): text penultimate rel-L2 {e:.3e}, vision tokens {ei:.3e}")
     assert e <= 8e-3 and ei <= 8e-3
+
+
+def test_text_tower_on_non_empty_prompts_vs_transformers(tmp_path, monkeypatch):
+    """`--prompt "..."` end to end through the text conditioner (reference condition.py:209-237: open_clip.tokenize ->
+    encode_with_transformer, layer "penultimate"): with $VCX_CLIP_BPE pointing at a vocabulary file, FrozenOpenCLIPEmbedder(text)
+    tokenises and runs the HIP tower; the pin is transformers' CLIPTokenizer + CLIPTextModel given the same vocabulary / merges and
+    the same (renamed) weights - an independent implementation of both halves.  (Every other test reaches the text tower with the
+    empty prompt or ready-made token tensors only.)"""
+    pytest.importorskip("transformers")
+    try:
+        import open_clip  # noqa: F401
+        pytest.skip("open_clip is installed: tokenize() delegates to it")
+    except ImportError:
+        pass
+    from transformers import CLIPTokenizer
+    from oracle import clip_hf as H
+    from tests.util import write_synthetic_bpe
+    from viewcrafter_amd.lvdm.modules.encoders import condition as cond
+    path = str(tmp_path / "bpe_syn.txt.gz")
+    merges = write_synthetic_bpe(path)
+    monkeypatch.setenv("VCX_CLIP_BPE", path)
+    cond._bpe_from_env.cache_clear()
+    try:
+        cfg = dict(H.HF_TINY_CFG, text=dict(H.HF_TINY_CFG["text"], vocab_size=49408))
+        cond.CLIP_CONFIGS["vcx-hf-pin-bpe"] = cfg
+        tm, tsd = H.build_text(cfg)
+        txt = cond.FrozenOpenCLIPEmbedder(arch="vcx-hf-pin-bpe", layer="penultimate").eval()
+        missing, unexpected = txt.load_state_dict(tsd, strict=False)
+        assert not unexpected and set(missing) <= {"model.text_projection", "model.logit_scale"}, missing
+        txt = txt.to(DEV)
+        prompts = ["A photo of a large room with wooden furniture", "a sweeping view of the old town at night, 4k, highly detailed", ""]
+        y = txt.encode(prompts)                                                      # str -> tokens -> HIP tower
+        bpe = cond._bpe_from_env()
+        vocab = dict(bpe.encoder)
+        vocab["<|startoftext|>"], vocab["<|endoftext|>"] = vocab.pop("<start_of_text>"), vocab.pop("<end_of_text>")
+        hf_tok = CLIPTokenizer(vocab=vocab, merges=[tuple(m) for m in merges])
+        ids = torch.tensor(hf_tok(prompts, padding="max_length", max_length=77, truncation=True)["input_ids"])
+        for row in ids:                                                              # HF pads with <end_of_text>, open_clip with 0
+            end = int((row == 49407).nonzero()[0])
+            row[end + 1:] = 0
+        assert torch.equal(ids, cond.tokenize(prompts))
+        ref = H.hf_text_penultimate(tm, ids)
+        e = rel_l2(y, ref)
+        print(f"text tower on non-empty prompts (BPE from $VCX_CLIP_BPE) vs transformers tokenizer + CLIPTextModel: rel-L2 {e:.3e}")
+        assert y.dtype == torch.float32 and tuple(y.shape) == (3, 77, cfg["text"]["width"]) and e <= 8e-3
+        assert not torch.allclose(y[0], y[2])                                        # the prompt matters
+    finally:
+        cond._bpe_from_env.cache_clear()

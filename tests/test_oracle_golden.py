@@ -242,3 +242,40 @@ def test_oracle_matches_the_reference_code_itself_when_oracle_ref_is_built():
     with torch.no_grad():
         assert max_rel(O.vae_decode(vsd, TINY_DDCONFIG, z).numpy(), vae.decode(z).numpy()) <= 2e-5
         assert max_rel(O.vae_encode_moments(vsd, TINY_DDCONFIG, img).numpy(), vae.encode(img).parameters.numpy()) <= 2e-5
+
+
+def test_kornia_resize_two_independent_restatements_agree():
+    """kornia is absent from /root/reference and from the image, so the pre-processing of the vision tower (reference
+    condition.py:322-329) cannot be pinned to kornia's code.  It is pinned to kornia's published ALGORITHM twice, independently:
+    oracle/clip_oracle.py (torch conv2d + F.interpolate - what wrote tests/golden/clip_tiny.npz under the reference's embedder
+    code) and oracle/kornia_numpy.py (dense fp64 matrices built element by element from the formulas; shares no code with torch).
+    Down-scaling with both axes / one axis shrinking, up-scaling (no blur), same size (identity), odd sizes."""
+    from oracle import clip_oracle as C
+    from oracle import kornia_numpy as K
+    g = torch.Generator().manual_seed(0)
+    for shp in [(1, 3, 576, 1024), (2, 3, 320, 512), (1, 3, 96, 64), (1, 3, 224, 224), (1, 3, 301, 500), (1, 3, 224, 600), (1, 2, 200, 250)]:
+        x = torch.tanh(torch.randn(*shp, generator=g, dtype=torch.float64))
+        mean, std = C.CLIP_MEAN[:shp[1]], C.CLIP_STD[:shp[1]]
+        a = C.kornia_normalize((C.kornia_resize(x, (224, 224), True) + 1) / 2, mean, std).numpy()
+        b = K.clip_preprocess(x.numpy(), mean=mean, std=std)
+        assert np.abs(a - b).max() <= 1e-11, shp
+        a = C.kornia_resize(x, (224, 224), False).numpy()                        # antialias off
+        My, Mx = K.resize_matrices(shp[2], shp[3], 224, antialias=False)
+        assert np.abs(a - np.einsum("oh,bchw,pw->bcop", My, x.numpy(), Mx, optimize=True)).max() <= 1e-11, shp
+
+
+def test_clip_preprocess_against_pillow_documents_the_delta():
+    """A third implementation that IS in the image, with DIFFERENT published rules: Pillow's BICUBIC (Keys a = -0.5, support scaled
+    by the shrink factor as its anti-aliasing, pixel-centre alignment) against kornia's rule (Gaussian pre-blur + a = -0.75,
+    corner alignment).  They are not expected to agree bit for bit; on a smooth 576x1024 image they agree to 41.6 dB - which
+    catches gross mistakes (transposed axes, wrong scale, missing blur) and is the measured delta DESIGN.md quotes."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    from oracle import kornia_numpy as K
+    yy, xx = np.mgrid[0:576, 0:1024]
+    img = (0.5 + 0.5 * np.sin(xx / 37.0) * np.cos(yy / 23.0)).astype(np.float32)
+    pil = np.asarray(Image.fromarray(img, mode="F").resize((224, 224), Image.BICUBIC))
+    ours = K.clip_preprocess(img[None, None] * 2 - 1, mean=(0.0,), std=(1.0,))[0, 0]
+    psnr_db = 10 * np.log10(1.0 / float(((pil - ours) ** 2).mean()))
+    assert 38.0 <= psnr_db <= 46.0, psnr_db
+    assert 10 * np.log10(1.0 / float(((pil - ours.T[:224, :224]) ** 2).mean())) < 25.0      # ... and a transposed result would not pass

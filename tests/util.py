@@ -60,3 +60,45 @@ def write_tiny_entry_files(tmp_path, device_for_build="cpu"):
     g = torch.Generator().manual_seed(5)
     torch.save(torch.rand(IGS_T, IGS_H, IGS_W, 3, generator=g), rpath)
     return ypath, cpath, rpath, (IGS_T, IGS_H, IGS_W)
+
+
+def write_synthetic_bpe(path):
+    """A CLIP byte-pair vocabulary file in open_clip's format (bpe_simple_vocab_16e6.txt.gz: header line, one merge per line) with
+    merges LEARNED from a small corpus by the textbook BPE procedure, padded with never-matching filler merges to CLIP's 48894 so
+    that the special tokens land on 49406 / 49407.  The real file is data that is not available offline; the algorithm under test
+    (rank-ordered merging, </w> word ends, byte-to-unicode alphabet, CLIP's regex) does not care which merges it is given.
+    Returns the list of learned merges (pairs of symbols)."""
+    import gzip
+    from collections import Counter
+    from viewcrafter_amd.lvdm.modules.encoders import condition as cond
+    corpus = ("a photo of a large room with wooden furniture and a view of the garden , camera moving forward . it's the artist's 2 "
+              "chairs ! naive cafe a sweeping view of the old town at night , 4k , highly detailed").split()
+    byte = cond._bytes_to_unicode()
+    words = [tuple(byte[b] for b in w.encode()) for w in corpus]
+    words = [w[:-1] + (w[-1] + "</w>",) for w in words]
+    merges = []
+    for _ in range(90):
+        c = Counter()
+        for w in words:
+            for i in range(len(w) - 1):
+                c[(w[i], w[i + 1])] += 1
+        if not c:
+            break
+        best = max(sorted(c), key=lambda p: c[p])
+        merges.append(best)
+        nw = []
+        for w in words:
+            out, i = [], 0
+            while i < len(w):
+                if i < len(w) - 1 and (w[i], w[i + 1]) == best:
+                    out.append(w[i] + w[i + 1])
+                    i += 2
+                else:
+                    out.append(w[i])
+                    i += 1
+            nw.append(tuple(out))
+        words = nw
+    lines = ["#version: synthetic"] + [" ".join(m) for m in merges] + [f"zq{i}x zq{i}y" for i in range(49152 - 256 - 2 - len(merges))]
+    with gzip.open(path, "wb") as f:
+        f.write("\n".join(lines).encode())
+    return merges

@@ -161,6 +161,27 @@ def run(calls):
             expl[hit] += 1
         print(f"v{v}: calls {calls}  deviating elements per call min/median/max {min(per_call)}/{sorted(per_call)[len(per_call) // 2]}/{max(per_call)}"
               f"  total {int(bad.sum())}  row-group b {rows}  col%16 {cols}  explained-by {expl}", flush=True)
+        if v == 0 and len(idx):
+            # what ARE the wrong numbers?  For every deviant: relative error against the fp64 value, and a brute-force search over the
+            # (colsum, bias') pairs of all 64 rows of its wave strip - which rows' operands reproduce the stored fp16 value, if any
+            from collections import Counter
+            hist, errs, examples = Counter(), [], []
+            for c, m, n in idx[:400].tolist():
+                got = float(stack[c, m, n])
+                a, r, mu = float(acc[m, n]), float(rstd[n]), float(mean[n])
+                want = r * (a - mu * float(colsum[m])) + float(bias_f[m])
+                errs.append(abs(got - want) / max(abs(want), 1e-3))
+                base = m - m % 64
+                rows64 = torch.arange(base, base + 64, device=dev)
+                cand = (r * (a - mu * colsum[rows64].double()))[:, None] + bias_f[rows64].double()[None, :]        # [colsum row, bias row]
+                hit = (cand.half().float() == got).nonzero()
+                key = "no row pair" if len(hit) == 0 else ("unique " + str((int(hit[0, 0]) + base - m, int(hit[0, 1]) + base - m)) if len(hit) == 1 else f"{len(hit)} pairs")
+                hist[key] += 1
+                if len(examples) < 6:
+                    examples.append((m, n, got, float(ref[m, n]), round(want, 4)))
+            errs.sort()
+            print(f"    v0 deviants: relative error vs fp64 min/median/max {errs[0]:.2e}/{errs[len(errs) // 2]:.2e}/{errs[-1]:.2e};  (row, col, got, majority, fp64): {examples}")
+            print(f"    which rows' (colsum, bias') reproduce the wrong value [offsets relative to the element's own row]: {dict(hist.most_common(8))}", flush=True)
 
 
 if __name__ == "__main__":

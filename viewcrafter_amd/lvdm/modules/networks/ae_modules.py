@@ -83,21 +83,36 @@ class AttnBlock(PackedModule):
         pk = self.packed()
         n, H, W, C = x.shape
         N = H * W
-        if N % 8 != 0:
-            raise ValueError("VAE attention needs h*w % 8 == 0")
+        # The GEMMs address a frame's tokens at 16-byte granularity.  72x128 / 40x64 latents give N % 8 == 0; for any other
+        # --height / --width each frame's token rows are padded with zero rows to the next multiple of 8 for the length of this
+        # block, exactly as SpatialTransformer does for the UNet (round 4: this used to raise, so a free size that passed the UNet
+        # died in the decoder).  Pad KEYS never enter: the score GEMM writes the N real columns of a zero-initialised [Np, Np]
+        # buffer and the softmax runs over those N; pad QUERY rows compute garbage that is dropped on the way out.
+        Np = (N + 7) // 8 * 8
         hn = _gn(x, pk["g"], False).view(n * N, C)
+        xin = x.reshape(n * N, C)
+        if Np != N:
+            def pad_frames(src):
+                dst = torch.zeros((n * Np, C), dtype=torch.float16, device=x.device)
+                ops.copy2d(src, dst, n, N * C, N * C, Np * C)           # one "row" per frame
+                return dst
+            hn, xin = pad_frames(hn), pad_frames(xin)
         q = ops.linear(hn, *pk["q"])
         k = ops.linear(hn, *pk["k"])
-        vt = ops.gemm(pk["v"][0], hn, M=C, N=n * N, K=C, lda=C, bias=pk["v"][1], bias_m=True)      # [C, n*N]
-        o = torch.empty((n * N, C), dtype=torch.float16, device=x.device)
-        s = torch.empty((N, N), dtype=torch.float16, device=x.device)
+        vt = ops.gemm(pk["v"][0], hn, M=C, N=n * Np, K=C, lda=C, bias=pk["v"][1], bias_m=True)      # [C, n*Np]
+        o = torch.empty((n * Np, C), dtype=torch.float16, device=x.device)
+        s = torch.zeros((Np, Np), dtype=torch.float16, device=x.device)
         scale = float(int(C) ** (-0.5))
         for i in range(n):   # one frame at a time: S is N x N (170 MB at 72x128)
-            qi, ki = q[i * N:(i + 1) * N], k[i * N:(i + 1) * N]
-            ops.gemm(qi, ki, M=N, N=N, K=C, lda=C, out=s, ldc=N, alpha=scale)
-            ops.softmax_rows_(s)
-            ops.gemm(s, vt[:, i * N:], M=N, N=C, K=N, lda=N, ldw=n * N, out=o[i * N:(i + 1) * N], ldc=C)
-        out = ops.linear(o, *pk["o"], residual=x.reshape(n * N, C))
+            qi, ki = q[i * Np:(i + 1) * Np], k[i * Np:(i + 1) * Np]
+            ops.gemm(qi, ki, M=Np, N=N, K=C, lda=C, out=s, ldc=Np, alpha=scale)
+            ops.softmax_rows_(s, N)
+            ops.gemm(s, vt[:, i * Np:], M=Np, N=C, K=Np, lda=Np, ldw=n * Np, out=o[i * Np:(i + 1) * Np], ldc=C)
+        out = ops.linear(o, *pk["o"], residual=xin)
+        if Np != N:
+            unpadded = torch.empty((n * N, C), dtype=torch.float16, device=x.device)
+            ops.copy2d(out, unpadded, n, N * C, Np * C, N * C)
+            out = unpadded
         return out.view(n, H, W, C)
 
 
