@@ -194,8 +194,8 @@ int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T, int64_t P,
                               int64_t ld, int k_off, int v_off, int64_t ldo, float scale,
                               void* stream);
 
-/* Row softmax in place on fp16 [rows][ld] over the first n columns (fp32 math):
- * VAE AttnBlock, ae_modules.py:66-69. */
+/* Row softmax in place on fp16 [rows][ld] over the first n columns (fp32 math): VAE AttnBlock, ae_modules.py:66-69.
+ * ld % 8 == 0; when n is not a multiple of 8 the columns up to the next multiple of 8 (ld must cover them) are written as zeros. */
 int vcx_softmax_rows_f16(void* x, int64_t rows, int n, int64_t ld, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -103,6 +103,8 @@ class ViewCrafter:
         self.opts = opts
         self.setup_diffusion()
     def nvs_sparse_view_interp(self):
+        import os
+        open(os.path.join(os.path.dirname(__file__), "geometry_ran.rank" + os.environ.get("RANK", "0")), "w").close()
         renders = torch.arange(5 * 2 + 1, dtype=torch.float32).view(-1, 1, 1, 1).expand(-1, 16, 16, 3) / 100      # 5 clips of 3 frames sharing ends
         res = [self.run_diffusion(renders[i * 2: 3 + i * 2]) for i in range(5)]
         return torch.cat(res)
@@ -141,6 +143,8 @@ def test_inference_main_shards_trajectories_over_two_ranks(tmp_path, sparse):
     torch.manual_seed(1000)
     w_sum = float(_StubModel().w.detach().sum())                     # rank 0's weights, which rank 1 must have received
     if sparse:
+        # DUSt3R + render (here: the stand-in's nvs_sparse_view_interp) ran on rank 0 only; rank 1 received the clips by broadcast
+        assert os.path.exists(os.path.join(tmp, "ref", "geometry_ran.rank0")) and not os.path.exists(os.path.join(tmp, "ref", "geometry_ran.rank1"))
         clip_means = [sum(range(i * 2, i * 2 + 3)) / 3 / 100 for i in range(5)]
     else:
         clip_means = means

@@ -148,3 +148,26 @@ print("RCCL-ONE-RANK-OK")
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_gpus_2_launch_line_on_this_one_gpu_is_a_marked_smoke_test():
+    """The driver's multi-GPU command, `python bench.py --gpus 2`, executed for real on this box's ONE GPU with VCX_BENCH_SHARE_GPU=1:
+    bench.py re-executes itself under `python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1`, both ranks build
+    the full-width 320x512 model on the shared device, run the barrier-bracketed timed region, decode and gather their clips - and
+    the ONE line rank 0 prints says it is not a measurement (RCCL cannot place two ranks on one device, so the control plane is
+    gloo here; the RCCL collectives themselves are covered by test_rccl_collectives_of_the_sharded_launch_on_one_gpu).  What no
+    test can give on a one-GPU box is a scaling number: SCALE_rNN.json is the driver's to measure."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VCX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload",
+                        "ViewCrafter_25_512_320x512x25", "--no-cpu-baseline", "--no-gpu-legs", "--no-extra", "--no-video"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = lines[0]
+    assert out["n_gpus"] == 2 and len(out["per_rank_steps_per_s"]) == 2 and out["scaling"] == "weak"
+    assert "SMOKE TEST" in out["backend"] and "not a measurement" in out["backend"]
+    assert out["value"] > 0 and out["gather_s"] is not None
+    assert "torch.distributed.run" in r.stderr

@@ -1,0 +1,177 @@
+"""Hypothesis-driven shape fuzz of the dispatch boundaries (tier T2 "hypothesis-driven odd shapes").
+
+The one dispatcher bug this project has shipped (round 2: the descriptor extent of the tail-split launch) was caught by a hand-picked
+property test, by luck.  Here hypothesis draws the shapes - biased towards the boundaries where the dispatcher changes kernel or tile
+(multiples of 64 / 128 / 160 / 256 / 320 +- a few, the 384-tile threshold of the large tiles, the tail split, K % 64, N % 8, ragged M)
+- and every draw is checked against the plain PyTorch fp32 op (fp16 inputs, fp32 accumulate: rel-L2 <= 2e-3).  Derandomised
+(`derandomize=True`): the driver's run and a local run see the same examples; a failure prints the shrunk shape.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+hypothesis = pytest.importorskip("hypothesis")
+from hypothesis import HealthCheck, given, settings, strategies as st      # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FUZZ = settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _t(shape, seed, scale=1.0):
+    """N(0, scale^2) on the device (the draws are large: generating them on the host would dominate the run time)"""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return torch.randn(*shape, generator=g, device=DEV) * scale
+
+
+def near(*anchors, spread=9, lo=1, hi=1 << 20):
+    """integers within +-spread of one of the anchors (the dispatcher's thresholds), clipped to [lo, hi]"""
+    return st.one_of([st.integers(max(lo, a - spread), min(hi, a + spread)) for a in anchors])
+
+
+M_EDGES = near(1, 64, 128, 256, 257, 1000, 2048, 4096, 16384, 32768, 49152 + 128, 65536 + 256, 98304)
+N_EDGES = st.one_of(near(4, 8, 64, 128, 160, 256, 320, 640, 1280, spread=12), st.sampled_from([320, 640, 960, 1280, 2560, 5120]))
+K_EDGES = st.one_of(st.sampled_from([8, 64, 72, 128, 320, 512, 640, 1280, 2560]), st.integers(1, 48).map(lambda v: 8 * v))
+
+
+@FUZZ
+@given(M=M_EDGES, N=N_EDGES, K=K_EDGES, bias=st.booleans(), res=st.booleans(), f32=st.booleans(), seed=st.integers(0, 1 << 16))
+def test_fuzz_linear(M, N, K, bias, res, f32, seed):
+    from viewcrafter_amd import ops
+    if f32 or N % 4:
+        res = False                                   # the residual is fetched in 8-byte pieces: ldr % 4 == 0 (the fp32 epilogue takes none)
+    if M * K > 1 << 26:
+        K = 64                                        # bound the operand sizes (256 MB), keep the M / N edge
+    x = _t((M, K), seed).to(DEV).half()
+    w = (_t((N, K), seed + 1) / math.sqrt(K)).to(DEV).half()
+    b = _t((N,), seed + 2).to(DEV) if bias else None
+    r = _t((M, N), seed + 3).to(DEV).half() if res else None
+    ref = x.float() @ w.float().t()
+    if bias:
+        ref = ref + b
+    if res:
+        ref = ref + r.float()
+    out = ops.linear(x, w, b, residual=r, out_f32=f32)
+    assert out.shape == (M, N) and torch.isfinite(out.float()).all()
+    assert rel_l2(out, ref) <= (1e-4 if f32 else 2e-3), (M, N, K, bias, res, f32)
+
+
+@FUZZ
+@given(M=near(64, 128, 256, 4096, 16384, 49152, spread=5), Nh=st.sampled_from([32, 64, 160, 320, 640, 1280, 2560]), K=st.sampled_from([64, 128, 320, 640, 72]),
+       seed=st.integers(0, 1 << 16))
+def test_fuzz_geglu(M, Nh, K, seed):
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import pack_geglu
+    x = _t((M, K), seed).to(DEV).half()
+    w = (_t((2 * Nh, K), seed + 1) / math.sqrt(K)).to(DEV).half()
+    b = _t((2 * Nh,), seed + 2).to(DEV)
+    wg, bg = pack_geglu(w, b)
+    out = ops.linear(x, wg, bg, geglu=True)
+    y = x.float() @ w.float().t() + b
+    ref = y[:, :Nh] * F.gelu(y[:, Nh:])
+    assert out.shape == (M, Nh) and rel_l2(out, ref) <= 2e-3, (M, Nh, K)
+
+
+@FUZZ
+@given(n=st.integers(1, 6), H=st.integers(1, 40), W=st.integers(1, 40), cin=st.sampled_from([8, 64, 72, 128, 320]), cout=st.sampled_from([4, 8, 64, 128, 160, 320, 640]),
+       kind=st.sampled_from(["3x3", "3x3s2", "1x1", "3x3up", "3x1"]), res=st.booleans(), seed=st.integers(0, 1 << 16))
+def test_fuzz_conv(n, H, W, cin, cout, kind, res, seed):
+    """3x3 / stride-2 / 1x1 / fused nearest-2x / temporal (3,1,1) convolutions on images down to 1x1 pixels (every tap a border tap)."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import pack_conv
+    x = _t((n, H, W, cin), seed).to(DEV).half()
+    xn = x.float().permute(0, 3, 1, 2)
+    if kind == "3x1":                                  # x as [B=1, T=n, P=H*W, C]: convolution along T
+        w = _t((cout, cin, 3, 1, 1), seed + 1) / math.sqrt(3 * cin)
+        b = _t((cout,), seed + 2)
+        out = ops.temporal_conv3(x.view(1, n, H * W, cin), pack_conv(w).to(DEV).half(), b.to(DEV)).view(n, H, W, cout)
+        x5 = x.float().view(1, n, H, W, cin).permute(0, 4, 1, 2, 3)
+        ref = F.conv3d(x5, w.to(DEV).half().float(), b.to(DEV), padding=(1, 0, 0))[0].permute(1, 2, 3, 0)
+    else:
+        kh = 1 if kind == "1x1" else 3
+        w = _t((cout, cin, kh, kh), seed + 1) / math.sqrt(kh * kh * cin)
+        b = _t((cout,), seed + 2)
+        wp, wd, bd = pack_conv(w).to(DEV).half(), w.to(DEV).half().float(), b.to(DEV)
+        if kind == "3x3s2":
+            out = ops.conv2d(x, wp, bd, kh=3, kw=3, stride=2)
+            ref = F.conv2d(xn, wd, bd, stride=2, padding=1)
+        elif kind == "3x3up":
+            out = ops.conv2d(x, wp, bd, kh=3, kw=3, ups=1)
+            ref = F.conv2d(F.interpolate(xn, scale_factor=2.0, mode="nearest"), wd, bd, padding=1)
+        else:
+            r = _t((n * H * W, cout), seed + 3).to(DEV).half() if res else None
+            out = ops.conv2d(x, wp, bd, kh=kh, kw=kh, residual=r)
+            ref = F.conv2d(xn, wd, bd, padding=kh // 2)
+            if res:
+                ref = ref + r.float().view(n, H, W, cout).permute(0, 3, 1, 2)
+        ref = ref.permute(0, 2, 3, 1)
+    assert tuple(out.shape) == tuple(ref.shape) and rel_l2(out, ref) <= 2e-3, (n, H, W, cin, cout, kind, res)
+
+
+@FUZZ
+@given(n=st.integers(1, 3), heads=st.integers(1, 5), nq8=st.integers(1, 40), nk=st.one_of(st.integers(1, 200), near(64, 128, 2304, 4096, 4160, spread=9)),
+       accumulate=st.booleans(), log2=st.booleans(), seed=st.integers(0, 1 << 16))
+def test_fuzz_flash_attention(n, heads, nq8, nk, accumulate, log2, seed):
+    """Both flash kernels behind vcx_attn_flash_d64_f16: ragged key counts (masked tail tile), the 4096-key switch to the
+    software-pipelined kernel (nk % 64 == 0, log2 logits, no accumulate), tiny problems, accumulate mode."""
+    from viewcrafter_amd import ops
+    D, nq = heads * 64, 8 * nq8
+    kv_rows = (nk + 7) // 8 * 8
+    scale = 0.125
+    q = _t((n * nq, D), seed).to(DEV).half()
+    k = _t((n * kv_rows, D), seed + 1).to(DEV).half()
+    vt = _t((D, n * kv_rows), seed + 2).to(DEV).half()
+    o0 = _t((n * nq, D), seed + 3).to(DEV).half()
+    o = o0.clone()
+    qs = (q.float() * (scale * ops.LOG2E)).half() if log2 else q          # the caller folds scale * log2(e) into Q
+    ops.flash_attn(qs, k, vt, o, n_groups=n, heads=heads, nq=nq, nk=nk, kv_rows=kv_rows, kv_div=1, ldq=D, ldk=D, ldvt=n * kv_rows, ldo=D,
+                   scale=scale, accumulate=accumulate, log2_logits=log2)
+    qf = (qs.float() / (scale * ops.LOG2E) if log2 else q.float()).view(n, nq, heads, 64).permute(0, 2, 1, 3)
+    kf = k.float().view(n, kv_rows, heads, 64)[:, :nk].permute(0, 2, 1, 3)
+    vf = vt.float().view(heads, 64, n, kv_rows)[..., :nk].permute(2, 0, 3, 1)                      # [n, heads, nk, 64]
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ vf).permute(0, 2, 1, 3).reshape(n * nq, D)
+    if accumulate:
+        ref = ref + o0.float()
+    assert rel_l2(o, ref) <= 3e-3, (n, heads, nq, nk, accumulate, log2)
+
+
+@FUZZ
+@given(B=st.integers(1, 2), T=st.integers(1, 32), P=st.integers(1, 300), heads=st.integers(1, 5), seed=st.integers(0, 1 << 16))
+def test_fuzz_temporal_attention(B, T, P, heads, seed):
+    from viewcrafter_amd import ops
+    D = heads * 64
+    qkv = _t((B * T * P, 3 * D), seed).to(DEV).half()
+    o = torch.empty((B * T * P, D), dtype=torch.float16, device=DEV)
+    ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D, ldo=D, scale=0.125)
+    x = qkv.float().view(B, T, P, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)                            # [3, B, P, heads, T, 64]
+    ref = (torch.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, -1) @ x[2]).permute(0, 3, 1, 2, 4).reshape(B * T * P, D)
+    assert rel_l2(o, ref) <= 3e-3, (B, T, P, heads)
+
+
+@FUZZ
+@given(n=st.integers(1, 3), pix=st.one_of(st.integers(1, 700), near(4096, 9216, 57600, spread=3)), cg=st.sampled_from([1, 2, 4, 10, 20, 40]), silu=st.booleans(),
+       offset=st.sampled_from([0.0, 0.0, 50.0]), seed=st.integers(0, 1 << 16))
+def test_fuzz_groupnorm_and_layernorm(n, pix, cg, silu, offset, seed):
+    from viewcrafter_amd import ops
+    C = 32 * cg
+    if C % 8:
+        C = 32 * 2 * cg
+    x = (offset + _t((n, pix, C), seed)).to(DEV).half()
+    g, b = (1 + 0.2 * _t((C,), seed + 1)).to(DEV), (0.1 * _t((C,), seed + 2)).to(DEV)
+    out = ops.group_norm(x, g, b, 1e-5, silu)
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, g.double(), b.double(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    assert rel_l2(out, ref.permute(0, 2, 1)) <= 3e-3, (n, pix, C, silu, offset)
+    rows = x.view(-1, C)
+    ln = ops.layer_norm(rows, g, b, 1e-5)
+    assert rel_l2(ln, F.layer_norm(rows.double(), (C,), g.double(), b.double(), 1e-5)) <= 3e-3, (n * pix, C)
+    st_ = ops.row_stats(rows, 1e-5)
+    assert rel_l2(st_[:, 0], rows.double().mean(1)) <= 1e-4

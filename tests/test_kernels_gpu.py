@@ -767,6 +767,12 @@ def test_softmax_rows():
     ops.softmax_rows_(y, n=512)
     check(y[:, :512], ref, tol=2e-3, name="softmax rows")
     assert torch.equal(y[:, 512:], x[:, 512:])
+    # n not a multiple of 8 (VAE attention at 135 tokens): the rest of the last 16-byte chunk becomes zero, nothing beyond it moves
+    x = (rnd(37, 144, seed=62) * 3).to(DEV).half()
+    y = x.clone()
+    ops.softmax_rows_(y, n=135)
+    check(y[:, :135], x[:, :135].float().softmax(-1), tol=2e-3, name="softmax rows n=135")
+    assert (y[:, 135:136] == 0).all() and torch.equal(y[:, 136:], x[:, 136:])
 
 
 # ---------------------------------------------------------------- element-wise / layout / DDIM

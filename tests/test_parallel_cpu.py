@@ -98,3 +98,36 @@ def test_gather_results_rejects_mixed_shapes_on_every_rank_and_handles_zero_item
         assert p.exitcode == 0
     assert outs[0][1] == [] and outs[1][1] is None
     assert all("one shape and dtype" in o[2] for o in outs), outs
+
+
+def _bcast_list_worker(rank, world, port, fail, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_distributed("gloo")
+    clips = [torch.arange(24, dtype=torch.float32).view(2, 3, 4) + i for i in range(3)] + [torch.ones(5, dtype=torch.float64)] if rank == 0 else None
+    try:
+        got = parallel.broadcast_tensor_list(clips, src=0, error="DUSt3R went wrong" if (fail and rank == 0) else None)
+        q.put((rank, [(tuple(t.shape), str(t.dtype), float(t.sum())) for t in got]))
+    except RuntimeError as e:
+        q.put((rank, "raised: " + str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [False, True])
+def test_broadcast_tensor_list_two_ranks_and_a_failing_source(fail):
+    """The clips of the sparse-view mode travel from rank 0 (the only rank that runs DUSt3R + the render) to every rank; a failure
+    on rank 0 while producing them is raised on ALL ranks instead of leaving the others in a collective rank 0 never joins."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_list_worker, args=(r, 2, port, fail, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if fail:
+        assert all(isinstance(v, str) and "DUSt3R went wrong" in v for v in outs.values()), outs
+    else:
+        assert outs[0] == outs[1] and len(outs[0]) == 4 and outs[0][3] == ((5,), "torch.float64", 5.0)

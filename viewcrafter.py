@@ -33,7 +33,11 @@ class ViewCrafter:
         self.gradio = gradio
         self._ref = None
         self.setup_diffusion()
-        if getattr(opts, "renderings", None) is None and not gradio:
+        rank, world = parallel.rank_world()
+        # sparse-view mode under a torchrun launch: DUSt3R and the point render run on rank 0 ONLY (they are the reference's, and
+        # identical on every rank); the clips they produce are broadcast and sharded (nvs_sparse_view_interp below)
+        geometry_here = not (world > 1 and rank != 0 and getattr(opts, "mode", None) == "sparse_view_interp")
+        if getattr(opts, "renderings", None) is None and not gradio and geometry_here:
             self._attach_reference_geometry()
 
     # ------------------------------------------------------------------ diffusion leg (this repo)
@@ -157,8 +161,8 @@ class ViewCrafter:
 
     def nvs_sparse_view_interp(self):
         """Reference viewcrafter.py:196-277.  Its (N - 1) clips are independent `run_diffusion` calls (:272-274): under a
-        torchrun launch the reference's method runs in recording mode on every rank (DUSt3R and the render are the
-        reference's and deterministic; the clips are only collected), then the clips are sharded over the GPUs and rank 0
+        torchrun launch the reference's method runs in recording mode on RANK 0 ONLY (DUSt3R and the render are the
+        reference's; the clips are only collected), the clips are broadcast (parallel.broadcast_tensor_list), sharded over the GPUs and rank 0
         writes diffusion.mp4 (fps 8, the reference's writer default, pvd_utils.py:38) - instead of (N - 1) sequential 11 s
         generations on one GPU.  One process: the reference's own loop, i.e. its single sequential noise stream; N processes:
         clip i draws from seed + i (independent of N), so clips 1.. differ from the one-process run - by construction, a
@@ -167,12 +171,17 @@ class ViewCrafter:
         if world == 1:
             return self._ref.nvs_sparse_view_interp()
         from viewcrafter_amd.utils.video_io import save_video
-        clips = []
-        self._ref._record = clips
-        try:
-            self._ref.nvs_sparse_view_interp()
-        finally:
-            self._ref._record = None
+        clips, error = None, None
+        if rank == 0:       # geometry once: the reference's method in recording mode (run_diffusion only collects its clips)
+            clips = []
+            self._ref._record = clips
+            try:
+                self._ref.nvs_sparse_view_interp()
+            except Exception as e:          # reported to every rank by the broadcast below: all fail together, nobody hangs
+                error = f"{type(e).__name__}: {e}"
+            finally:
+                self._ref._record = None
+        clips = parallel.broadcast_tensor_list(clips, src=0, error=error)
         outs = self.run_diffusion_many(clips)
         if rank != 0:
             return None

@@ -666,16 +666,18 @@ __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
 // =======================================================================================
 // Row softmax in place (fp16 storage, fp32 math), one block per row.
 // =======================================================================================
+// n need not be a multiple of 8: the columns [n, ceil8(n)) of the last 16-byte chunk take no part in the maximum / sum and are
+// written as zeros (the VAE attention at token counts that are not multiples of 8 multiplies this matrix with zero-padded keys).
 __global__ void __launch_bounds__(256) softmax_rows_kernel(half_t* x, int n, int64_t ld) {
     __shared__ float red[8];
     half_t* row = x + (int64_t)blockIdx.x * ld;
     const int tid = threadIdx.x;
-    const int nch = n >> 3;
+    const int nch = (n + 7) >> 3;
     float mx = -1e30f;
     for (int c = tid; c < nch; c += 256) {
         const h8 v = *reinterpret_cast<const h8*>(row + c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[e]);
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, c * 8 + e < n ? (float)v[e] : -1e30f);
     }
     mx = vcx_wave_max(mx);
     if ((tid & 63) == 0) red[tid >> 6] = mx;
@@ -685,7 +687,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(half_t* x, int n, int
     for (int c = tid; c < nch; c += 256) {
         const h8 v = *reinterpret_cast<const h8*>(row + c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sum += __expf((float)v[e] - mx);
+        for (int e = 0; e < 8; ++e) sum += c * 8 + e < n ? __expf((float)v[e] - mx) : 0.f;
     }
     sum = vcx_wave_sum(sum);
     if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
@@ -695,7 +697,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(half_t* x, int n, int
     for (int c = tid; c < nch; c += 256) {
         h8 v = *reinterpret_cast<const h8*>(row + c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)(__expf((float)v[e] - mx) * inv);
+        for (int e = 0; e < 8; ++e) v[e] = c * 8 + e < n ? (half_t)(__expf((float)v[e] - mx) * inv) : (half_t)0.f;
         *reinterpret_cast<h8*>(row + c * 8) = v;
     }
 }
@@ -863,7 +865,8 @@ extern "C" int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T,
 
 extern "C" int vcx_softmax_rows_f16(void* x, int64_t rows, int n, int64_t ld, void* stream) {
     VCX_REQUIRE(x && rows > 0 && n > 0, "vcx_softmax_rows_f16: empty problem");
-    VCX_REQUIRE(n % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x & 15) == 0, "vcx_softmax_rows_f16: n, ld multiples of 8");
+    VCX_REQUIRE(ld % 8 == 0 && ld >= (n + 7) / 8 * 8 && ((uintptr_t)x & 15) == 0,
+                "vcx_softmax_rows_f16: ld must be a multiple of 8 that covers n rounded up to 8 (n=%d ld=%lld), x 16-byte aligned", n, (long long)ld);
     VCX_REQUIRE(rows < (1ll << 31), "vcx_softmax_rows_f16: too many rows");
     hipStream_t s = (hipStream_t)stream;
     VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 4.0 * rows * (double)n);

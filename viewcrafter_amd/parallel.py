@@ -100,6 +100,33 @@ def broadcast_tensor(t, src=0):
     return t
 
 
+def broadcast_tensor_list(tensors, src=0, error=None):
+    """Rank `src` holds a list of tensors (any shapes / dtypes), the others pass None: afterwards every rank holds the list.
+    The shapes travel first as one small object broadcast, the payload as one dist.broadcast per tensor (on the GPU under RCCL,
+    on the host under gloo).  `error` (rank src only): a failure that happened while PRODUCING the list - it is broadcast in place
+    of the metadata and raised on every rank together, so that nobody waits in a collective the source never joins."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        if error is not None:
+            raise RuntimeError(error)
+        return list(tensors)
+    rank = dist.get_rank()
+    meta = [None]
+    if rank == src:
+        meta = [("error", str(error)) if error is not None else
+                ("ok", [(tuple(t.shape), str(t.dtype).replace("torch.", "")) for t in tensors])]
+    dist.broadcast_object_list(meta, src=src)
+    kind, info = meta[0]
+    if kind == "error":
+        raise RuntimeError(f"rank {src} failed while producing the clips: {info}")
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    out = []
+    for i, (shape, dtype) in enumerate(info):
+        t = tensors[i].to(dev).contiguous() if rank == src else torch.empty(shape, dtype=getattr(torch, dtype), device=dev)
+        dist.broadcast(t, src=src)
+        out.append(tensors[i] if rank == src else t)
+    return out
+
+
 def gather_results(local, n_items, dst=0, _force=False):
     """local: {item index: tensor} owned by this rank (all tensors of one shape/dtype).  Returns on rank `dst` the list
     of all n_items results in item order (None elsewhere).  One all_gather of a padded stack per call.
