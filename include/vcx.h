@@ -85,12 +85,14 @@ int vcx_device_arch(char* name_host, int len);
  *                      ln_colsum[m], bias'[m] (BIAS_M)                                                                   */
 #define VCX_GEMM_LNFOLD 0x80
 #define VCX_GEMM_LNFOLD_T 0x100
-/* GroupNorm statistics from the producing convolution: besides out, the epilogue writes colstats[M / 64][N][2] fp32 - for every
+/* GroupNorm statistics from the producing layer: besides out, the epilogue writes colstats[M / 64][ldcs][2] fp32 - for every
  * 64-row strip of output rows and every output column the (mean, M2 = sum of squared deviations) of the fp16-rounded outputs,
  * accumulated around a per-strip shift (robust to |mean| >> std).  vcx_groupnorm_stats_from_colstats_f32 merges them into the
- * (mean, variance) pairs vcx_groupnorm_apply_f16 takes, so the GroupNorm behind the convolution (ResBlock out_layers, the norms
- * of TemporalConvBlock: openaimodel3d.py:174-186,255-266) needs no statistics pass over the tensor.  Convolution mode with
- * cin % 64 == 0, fp16 output, M % 64 == 0, no GEGLU. */
+ * (mean, variance) pairs vcx_groupnorm_apply_f16 takes, so the GroupNorm behind the layer needs no statistics pass over the
+ * tensor: ResBlock out_layers and the norms of TemporalConvBlock behind their convolutions (openaimodel3d.py:174-186,255-266),
+ * and - round 4, linear mode - the norms fed by a transformer's proj_out + residual (attention.py:290,362 -> the next block's
+ * GroupNorm) or by a concatenated skip (openaimodel3d.py:596: the two producers write their columns of ONE moment buffer,
+ * ldcs = C1 + C2).  DMA kernel only (K % 64 == 0 / cin % 64 == 0), fp16 output, M % 64 == 0, no GEGLU, no LNFOLD. */
 #define VCX_GEMM_COLSTATS 0x200
 
 typedef struct vcx_gemm_desc {
@@ -111,7 +113,8 @@ typedef struct vcx_gemm_desc {
     float alpha;
     const float* ln_stats;  /* VCX_GEMM_LNFOLD[_T]: fp32 (mean, rstd) per normalised row            */
     const float* ln_colsum; /* VCX_GEMM_LNFOLD[_T]: fp32 row sums of the folded weight              */
-    float* colstats;        /* VCX_GEMM_COLSTATS: out, fp32 [M / 64][N][2]                          */
+    float* colstats;        /* VCX_GEMM_COLSTATS: out, fp32 [M / 64][ldcs][2] (first of this call's N columns) */
+    int64_t ldcs;           /* columns between consecutive strips of colstats; 0 = N                */
 } vcx_gemm_desc;
 
 int vcx_gemm_f16(const vcx_gemm_desc* desc_host, void* stream);

@@ -1,0 +1,119 @@
+"""The HOST side of the product UNet / VAE - the Python graph that decides which libvcx kernel gets which pointers, strides, flags,
+moment buffers and concat targets - executed on a GPU-less machine against the reference goldens and the fp32 oracle.
+
+tests/cpu_kernels.py restates the `viewcrafter_amd.ops` launchers in plain PyTorch from the contracts of include/vcx.h and is swapped
+in for ONE test at a time; the product has no CPU path (test_forward_fails_loudly_without_gpu still holds).  This is where a plumbing
+mistake - a moment buffer with the wrong leading dimension, a skip copied behind the wrong columns, a missing replicate under the
+shared CFG prefix - shows up before a GPU minute is spent.
+"""
+import importlib
+
+import pytest
+import torch
+
+from oracle import lvdm_oracle as O
+from oracle.weights import synth_input
+from tests import cpu_kernels
+from tests.tiny_config import TINY_DDCONFIG, TINY_UNET
+from tests.util import golden, load_synth, rel_l2
+
+UNET_TOL = 5e-3
+
+
+def _unet(monkeypatch, level):
+    """A tiny product UNet whose launches go to tests/cpu_kernels.py, with VCX_GN_EPILOGUE_STATS = level."""
+    cpu_kernels.install(monkeypatch)
+    from viewcrafter_amd.lvdm.modules import attention, flow
+    from viewcrafter_amd.lvdm.modules.networks import openaimodel3d as om
+    for mod in (flow, attention, om):
+        monkeypatch.setattr(mod, "GN_STATS_LEVEL", level, raising=False)
+        monkeypatch.setattr(mod, "GN_EPILOGUE_STATS", level >= 1, raising=False)
+    m = om.UNetModel(**TINY_UNET).eval()
+    sd = load_synth(m)
+    return m, sd
+
+
+@pytest.mark.parametrize("level", [2, 1, 0])
+@pytest.mark.parametrize("tag,shape,L", [("perframe", (1, 4, 32, 16), 77 + 64), ("shared", (2, 3, 16, 32), 77 + 40)])
+def test_host_graph_of_the_unet_vs_reference_golden(monkeypatch, level, tag, shape, L):
+    m, _ = _unet(monkeypatch, level)
+    g = golden("unet_tiny")
+    b, t, h, w = shape
+    x = synth_input(f"unet_x_{tag}", (b, 8, t, h, w))
+    ctx = synth_input(f"unet_ctx_{tag}", (b, L, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = m(x, torch.tensor([999, 399][:b]), context=ctx, fs=torch.tensor([10, 3][:b]))
+    e = rel_l2(y, g[f"unet_out_{tag}"])
+    print(f"host graph on CPU kernels, GN statistics level {level}, {tag}: rel-L2 vs the reference golden = {e:.3e}")
+    assert y.shape == g[f"unet_out_{tag}"].shape and e <= UNET_TOL
+
+
+def test_moments_travel_with_the_activations_and_the_concat_is_written_in_place(monkeypatch):
+    """Level 2 (round 4): count what the graph asks of the kernels at a latent where every level but the deepest has whole 64-row
+    strips - statistics passes only where no producer could supply moments, one copy per concat instead of two - and check the
+    result against levels 1 / 0 (same graph, statistics passes) and the oracle, incl. the shared CFG prefix (replicated moments)."""
+    from viewcrafter_amd import ops
+    b, t, h, w, L = 1, 2, 32, 64, 77 + 32            # levels: 2048, 512, 128 and 32 pixels per frame
+    x = synth_input("hg_x", (b, 8, t, h, w))
+    ctx = synth_input("hg_ctx", (2, L, TINY_UNET["context_dim"]))
+    ts, fs = torch.tensor([459]), torch.tensor([10])
+    outs, counts, noise = {}, {}, {}
+    for level in (2, 1, 0):
+        with monkeypatch.context() as mp:
+            m, sd = _unet(mp, level)
+            calls = dict(stats_pass=0, from_moments=0, copy2d=0)
+            gn, from_cs, cp = ops.group_norm, ops.group_norm_stats_from_colstats, ops.copy2d
+
+            def counted_gn(x_, *a, stats=None, **k):
+                calls["stats_pass"] += stats is None
+                return gn(x_, *a, stats=stats, **k)
+
+            def counted_from(*a, **k):
+                calls["from_moments"] += 1
+                return from_cs(*a, **k)
+
+            def counted_copy(*a, **k):
+                calls["copy2d"] += 1
+                return cp(*a, **k)
+            mp.setattr(ops, "group_norm", counted_gn)
+            mp.setattr(ops, "group_norm_stats_from_colstats", counted_from)
+            mp.setattr(ops, "copy2d", counted_copy)
+            with torch.no_grad():
+                y = m(x, ts, context=ctx[:1].contiguous(), fs=fs)
+                counts[level] = dict(calls)
+                y2 = m(x, ts, context=ctx, fs=fs, cfg_repeat=2)
+                full = m(torch.cat([x, x]), torch.cat([ts, ts]), context=ctx, fs=torch.cat([fs, fs]))
+            outs[level] = y
+            # shared prefix == replicated batch (replicated moments included).  On the GPU kernels this holds bit for bit
+            # (tests/test_model_gpu.py::test_cfg_shared_prefix_is_bit_identical); the host BLAS behind these stand-ins is not
+            # batch-invariant, so here: to rounding noise
+            noise[level] = (rel_l2(y2, full), rel_l2(y2[:1], y))
+            assert max(noise[level]) <= 5e-3, (level, noise[level])       # (wrong moments for the replicated half would be >> this)
+    ref = O.unet_forward(sd, TINY_UNET, x, ts, ctx[:1], fs)
+    errs = {lv: rel_l2(o, ref) for lv, o in outs.items()}
+    print(f"statistics passes / norms fed by moments / copies per forward: {counts};  rel-L2 vs oracle: {errs};  prefix-vs-batch noise: {noise}")
+    assert all(e <= UNET_TOL for e in errs.values())
+    assert rel_l2(outs[2], outs[0]) <= 5e-3                           # (fp16 rounding chaos between two summation orders: ~2e-3)
+    total = {lv: c["stats_pass"] + c["from_moments"] for lv, c in counts.items()}
+    assert total[2] == total[1] == total[0]                           # same norms, different sources of their statistics
+    assert counts[0]["from_moments"] == 0
+    assert counts[2]["stats_pass"] < counts[1]["stats_pass"] < counts[0]["stats_pass"]
+    # what is left at level 2: the very first norms (behind conv_in: 8 input channels), and the levels with 128 / 32 pixels per
+    # frame where a frame is not a whole number of strips for a per-frame norm
+    assert counts[2]["stats_pass"] <= counts[0]["stats_pass"] // 2
+    assert counts[2]["copy2d"] < counts[1]["copy2d"]                   # one copy per concat (+ the moments) instead of two
+
+
+def test_host_graph_of_the_vae_vs_reference_golden(monkeypatch):
+    cpu_kernels.install(monkeypatch)
+    from viewcrafter_amd.lvdm.models.autoencoder import AutoencoderKL
+    m = AutoencoderKL(ddconfig=TINY_DDCONFIG, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4).eval()
+    load_synth(m)
+    g = golden("vae_tiny")
+    with torch.no_grad():
+        dec = m.decode(synth_input("vae_z", (2, 4, 8, 16)))
+        post = m.encode(synth_input("vae_img", (1, 3, 64, 32), scale=0.5))
+        odd = m.decode(synth_input("vae_z_9x15", (1, 4, 9, 15)))     # 135 tokens in the attention block: padded rows
+    assert rel_l2(dec, g["vae_decode"]) <= 8e-3 and rel_l2(post.parameters, g["vae_encode_moments"]) <= 8e-3
+    sd = {k: v for k, v in m.state_dict().items()}
+    assert rel_l2(odd, O.vae_decode(sd, TINY_DDCONFIG, synth_input("vae_z_9x15", (1, 4, 9, 15)))) <= 8e-3

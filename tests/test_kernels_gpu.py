@@ -326,6 +326,69 @@ def test_conv_colstats_feed_the_groupnorm_behind_it(kind, n, H, W, cin, cout, of
     assert rel_l2(out, three_pass) <= 1e-3
 
 
+@pytest.mark.parametrize("M,pixels,K,c1,c2,offset", [(4096, 2048, 320, 320, 320, 0.0),      # per-frame norm over a concat of two equal parts
+                                                     (50 * 576, 576, 1280, 1280, 640, 0.0),  # the 452-tile layer shape: large tiles + small-tile tail
+                                                     (2 * 25 * 256, 25 * 256, 640, 640, 320, 0.0),   # per-video statistics (T x P rows)
+                                                     (1024, 512, 64, 64, 192, 80.0)])        # group width 8: groups straddle the seam; |mean| >> std
+def test_linear_colstats_and_concat_moments(M, pixels, K, c1, c2, offset):
+    """Round 4: VCX_GEMM_COLSTATS in LINEAR mode (a transformer's proj_out + residual feeding the next block's GroupNorm) and the
+    concat case (reference openaimodel3d.py:596 h = torch.cat([h, hs.pop()], 1)): two producers write their outputs into the left /
+    right columns of ONE buffer (ldc) and their column moments into ONE moment buffer (ldcs); the GroupNorm over the concatenated
+    channels - whose groups may straddle the seam - then takes its statistics from the moments.  Against fp64 statistics of the
+    stored tensor and torch's group_norm of it."""
+    from viewcrafter_amd import ops
+    n_outer = M // pixels
+    scale = 0.1 if offset else 1.0
+    ct = c1 + c2
+    xa, xb = rnd(M, K, seed=701).to(DEV).half(), rnd(M, K, seed=702).to(DEV).half()
+    wa, wb = (rnd(c1, K, seed=703) * scale / math.sqrt(K)).to(DEV).half(), (rnd(c2, K, seed=704) * scale / math.sqrt(K)).to(DEV).half()
+    ba, bb = (rnd(c1, seed=705) * 0.1 * scale + offset).to(DEV), (rnd(c2, seed=706) * 0.1 * scale - offset / 2).to(DEV)
+    res = (rnd(M, c1, seed=707) * 0.5 * scale).to(DEV).half()
+    assert ops.colstats_ok(M, pixels, K, c1) and ops.colstats_ok(M, pixels, K, ct)
+    # (1) one producer, its own buffer: the output is unchanged by the moments, nothing is written behind the last strip
+    guard = torch.full((M // 64 + 4, c1, 2), 7.0, device=DEV)
+    cs = guard[:M // 64]
+    y = ops.linear(xa, wa, ba, residual=res, colstats=cs)
+    assert torch.equal(y, ops.linear(xa, wa, ba, residual=res)) and bool((guard[M // 64:] == 7.0).all())
+    yd = y.double().view(n_outer, pixels, 32, c1 // 32)
+    st = ops.group_norm_stats_from_colstats(cs, n_outer, pixels, c1)
+    assert float((st[..., 0].double() - yd.mean(dim=(1, 3))).abs().max()) <= 2e-6 * (abs(offset) + 1)
+    assert rel_l2(st[..., 1], yd.var(dim=(1, 3), unbiased=False)) <= 2e-5
+    # (2) two producers, one concatenated buffer and one moment buffer (the right part computed apart and copied in, as a skip is)
+    cat = torch.full((M, ct), 3.0, dtype=torch.float16, device=DEV)
+    cat_cs = torch.full((M // 64, ct, 2), 5.0, device=DEV)
+    ops.linear(xa, wa, ba, residual=res, out=cat, ldc=ct, colstats=cat_cs, colstats_ld=ct, colstats_col=0)
+    assert bool((cat[:, c1:] == 3.0).all()) and bool((cat_cs[:, c1:] == 5.0).all())              # the partner's columns are untouched
+    skip_cs = ops.colstats_buffer(M, c2, DEV)
+    skip = ops.linear(xb, wb, bb, colstats=skip_cs)
+    ops.copy2d(skip, cat[:, c1:], M, c2, c2, ct)
+    ops.copy2d(skip_cs.view(torch.float16).view(M // 64, c2 * 4), cat_cs.view(torch.float16).view(M // 64, ct * 4)[:, c1 * 4:], M // 64, c2 * 4, c2 * 4, ct * 4)
+    assert torch.equal(cat[:, :c1], y) and torch.equal(cat[:, c1:], skip)
+    st = ops.group_norm_stats_from_colstats(cat_cs, n_outer, pixels, ct)
+    cd = cat.double().view(n_outer, pixels, 32, ct // 32)
+    mean, var = cd.mean(dim=(1, 3)), cd.var(dim=(1, 3), unbiased=False)
+    assert float((st[..., 0].double() - mean).abs().max()) <= 2e-6 * (abs(offset) + 1)
+    assert rel_l2(st[..., 1], var) <= 2e-5, (st[0, :4, 1], var[0, :4])
+    g, be = (1 + 0.2 * rnd(ct, seed=708)).to(DEV), (0.1 * rnd(ct, seed=709)).to(DEV)
+    out = ops.group_norm(cat.view(n_outer, pixels, ct), g, be, 1e-5, True, stats=st)
+    ref = F.silu(F.group_norm(cat.double().view(n_outer, pixels, ct).permute(0, 2, 1), 32, g.double(), be.double(), 1e-5)).permute(0, 2, 1)
+    check(out, ref.float(), tol=3e-3 if offset else 2e-3, name="groupnorm over a concat from two producers' moments")
+    # (3) bit-reproducible, and every tile configuration writes the same moments to within rounding
+    try:
+        base = None
+        for cfg in (-1, 0, 1, 2, 3):
+            ops.tune_set("GEMM_CFG", cfg)
+            c = ops.colstats_buffer(M, c1, DEV)
+            yy = ops.linear(xa, wa, ba, residual=res, colstats=c)
+            c2_ = ops.colstats_buffer(M, c1, DEV)
+            assert torch.equal(ops.linear(xa, wa, ba, residual=res, colstats=c2_), yy) and torch.equal(c, c2_), cfg
+            assert torch.equal(yy, y), cfg
+            base = c if base is None else base
+            assert rel_l2(c[..., 0], base[..., 0]) <= 1e-6 and rel_l2(c[..., 1], base[..., 1]) <= 1e-4, cfg
+    finally:
+        ops.tune_set("GEMM_CFG", -1)
+
+
 def test_conv_colstats_rejects_what_the_kernel_cannot_do():
     from viewcrafter_amd import ops
     from viewcrafter_amd._lib import VcxError

@@ -7,8 +7,10 @@ the failure follows the instruction FORM or its TIMING:
     v1   `s_nop 7` AFTER every op_sel pk_fma   (result -> consumer distance; LLVM's dst-sel forwarding rule pads 1 slot)
     v2   `s_nop 7` BEFORE every op_sel pk_fma  (ds_read return / s_waitcnt -> packed read distance)
     v3   every op_sel pk_fma replaced by two scalar v_fma_f32 reading the same registers (same operands, no op_sel)
-    v4   the 128-bit store / ds_read pairs left alone, but the op_sel form rewritten to op_sel_hi-only by swapping to
-         explicit copies is NOT possible without free registers - instead: `s_nop 0` after (exactly one slot)
+    v4   `s_nop 0` after (exactly the one slot LLVM's rule asks for)
+    v5   `s_waitcnt vmcnt(0)` BEFORE every op_sel pk_fma (the next tile's LDS-DMA is in flight during the epilogue: drained)
+    v6   the same packed instruction WITHOUT op_sel: v4 := v5, v0 := v1 first (the low halves are dead there), so the plain form
+         computes the same numbers from the same 64-bit operand reads - separates "op_sel encoding" from "packed form"
 
 Build (CPU, no GPU needed):   python tools/pkfma_variants.py build        -> tools/_abl/libvcx_pkfma_v{0..4}.so
 Run on the GPU box:           python tools/pkfma_variants.py run [calls]  -> table on stdout
@@ -25,6 +27,7 @@ ABL = os.path.join(ROOT, "tools", "_abl")
 COMMIT = "5b23812"
 LLVM = "/opt/rocm/lib/llvm/bin"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
+NVAR = 7
 PK = re.compile(r"^\tv_pk_fma_f32 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\] op_sel:\[0,1,1\]\s*$")
 
 
@@ -51,6 +54,12 @@ def patch(asm, variant):
             out += [f"\tv_fma_f32 v{d0}, v{s0}, v{a1}, v{c1}", f"\tv_fma_f32 v{d1}, v{s1}, v{a1}, v{c1}"]
         elif variant == 4:
             out += [line, "\ts_nop 0"]
+        elif variant == 5:      # drain every outstanding vector-memory operation first - in particular the LDS-DMA of the next tile's first
+            out += ["\ts_waitcnt vmcnt(0)", line]      # K-step, which is in flight while the epilogue runs
+        elif variant == 6:      # same instruction, same 64-bit operand reads, NO op_sel: the low halves are made copies of the high halves
+            if n == 1:          # first (v4, v0 = the b = 0 row terms, dead by now; reloaded per tile)
+                out += [f"\tv_mov_b32_e32 v{a0}, v{a1}", f"\tv_mov_b32_e32 v{c0}, v{c1}"]
+            out += [line.replace(" op_sel:[0,1,1]", "")]
     return "\n".join(out), n
 
 
@@ -65,7 +74,7 @@ def build():
     sh(f"{LLVM}/../../../bin/hipcc", *FLAGS, "-S", "--cuda-device-only", "gemm_dma.hip", "-o", "dev.s", cwd=src)
     asm = open(os.path.join(src, "dev.s")).read()
     others = [os.path.join(src, "build", f"{n}.o") for n in ("api", "gemm", "attention", "attention_v2", "norm", "elementwise")]
-    for v in range(5):
+    for v in range(NVAR):
         text, n = patch(asm, v)
         assert n == 4, f"expected the four op_sel:[0,1,1] instructions of the 128x128 LNFOLD_T kernel, found {n}"
         open(os.path.join(src, f"dev{v}.s"), "w").write(text)
@@ -114,7 +123,7 @@ def run(calls):
     mean, var = xd.mean(1), xd.var(1, unbiased=False)
     rstd = (var + 1e-5).rsqrt()
     acc = wf.double() @ xd.t()                  # [D, tokens]
-    for v in range(5):
+    for v in range(NVAR):
         path = os.path.join(ABL, f"libvcx_pkfma_v{v}.so")
         L = ctypes.CDLL(path)
         L.vcx_last_error.restype = ctypes.c_char_p

@@ -39,7 +39,7 @@ class GemmDesc(ctypes.Structure):
         ("in_h", c_int32), ("in_w", c_int32), ("out_h", c_int32), ("out_w", c_int32), ("cin", c_int32),
         ("kh", c_int32), ("kw", c_int32), ("stride", c_int32), ("pad_h", c_int32), ("pad_w", c_int32),
         ("ups", c_int32), ("rowadd_div", c_int32), ("flags", c_int32), ("alpha", c_float),
-        ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("colstats", c_void_p),
+        ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("colstats", c_void_p), ("ldcs", c_int64),
     ]
 
     def __init__(self, *args, **kw):

@@ -183,10 +183,10 @@ __device__ __forceinline__ int mirror_index(int j, int n) {
     j = j < 0 ? -j : j;
     return j > n - 1 ? 2 * (n - 1) - j : j;
 }
+constexpr int CLIP_MAX_KS = 65;     // blur taps per axis: sigma <= 16, i.e. shrink factors up to 33 (a 7392-pixel side onto 224)
 struct ClipPreArgs {
     int B, C, H, W, S, ksy, ksx;
-    float sy, sx;          // Gaussian sigmas
-    float ry, rx;          // source step per output pixel: (in - 1) / (out - 1)
+    float gy[CLIP_MAX_KS], gx[CLIP_MAX_KS];     // normalised Gaussian taps (computed in fp64 on the host); {1} when ks = 1
     float mean[4], istd[4];
 };
 __global__ void clip_preprocess_kernel(const float* __restrict__ x, float* __restrict__ y, ClipPreArgs a) {
@@ -197,58 +197,64 @@ __global__ void clip_preprocess_kernel(const float* __restrict__ x, float* __res
     const int64_t bc = i / ((int64_t)a.S * a.S);
     const int c = (int)(bc % a.C);
     const float* src = x + bc * (int64_t)a.H * a.W;
-    const float fy = (float)oy * a.ry, fx = (float)ox * a.rx;
-    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    // align_corners source coordinate o (in - 1) / (out - 1) as an exact integer quotient + remainder: in fp32 the product would
+    // carry ~1e-4 of a pixel at 4K, which on a noisy image is ~1e-3 of the output (torch's own fp32 path has that error; the fp64
+    // restatement does not)
+    const int qy = oy * (a.H - 1), qx = ox * (a.W - 1), den = a.S - 1;
+    const int y0 = qy / den, x0 = qx / den;
     float cy[4], cx[4];
-    cubic_coeffs(fy - (float)y0, cy);
-    cubic_coeffs(fx - (float)x0, cx);
+    cubic_coeffs((float)(qy - y0 * den) / (float)den, cy);
+    cubic_coeffs((float)(qx - x0 * den) / (float)den, cx);
     const int hy = a.ksy >> 1, hx = a.ksx >> 1;
-    float ny = 0.f, nx = 0.f;          // Gaussian normalisers
-    for (int k = 0; k < a.ksy; ++k) { const float d = (float)(k - hy); ny += expf(-d * d / (2.f * a.sy * a.sy)); }
-    for (int k = 0; k < a.ksx; ++k) { const float d = (float)(k - hx); nx += expf(-d * d / (2.f * a.sx * a.sx)); }
     float acc = 0.f;
     for (int iy = 0; iy < 4; ++iy) {
         const int yc = min(max(y0 - 1 + iy, 0), a.H - 1);
         for (int k = 0; k < a.ksy; ++k) {
-            const float dy = (float)(k - hy);
-            const float wy = cy[iy] * (a.ksy > 1 ? expf(-dy * dy / (2.f * a.sy * a.sy)) / ny : 1.f);
             const float* row = src + (int64_t)mirror_index(yc + k - hy, a.H) * a.W;
             float racc = 0.f;
             for (int ix = 0; ix < 4; ++ix) {
                 const int xc = min(max(x0 - 1 + ix, 0), a.W - 1);
                 float g = 0.f;
-                for (int l = 0; l < a.ksx; ++l) {
-                    const float dx = (float)(l - hx);
-                    const float wx = a.ksx > 1 ? expf(-dx * dx / (2.f * a.sx * a.sx)) / nx : 1.f;
-                    g = fmaf(wx, row[mirror_index(xc + l - hx, a.W)], g);
-                }
+                for (int l = 0; l < a.ksx; ++l) g = fmaf(a.gx[l], row[mirror_index(xc + l - hx, a.W)], g);
                 racc = fmaf(cx[ix], g, racc);
             }
-            acc = fmaf(wy, racc, acc);
+            acc = fmaf(cy[iy] * a.gy[k], racc, acc);
         }
     }
     y[i] = ((acc + 1.f) * 0.5f - a.mean[c]) * a.istd[c];
+}
+
+static void clip_gauss_taps(int ks, double sigma, float* out) {
+    double g[CLIP_MAX_KS], sum = 0.0;
+    for (int k = 0; k < ks; ++k) {
+        const double d = (double)(k - ks / 2);
+        g[k] = exp(-d * d / (2.0 * sigma * sigma));
+        sum += g[k];
+    }
+    for (int k = 0; k < ks; ++k) out[k] = (float)(g[k] / sum);
 }
 
 extern "C" int vcx_clip_preprocess_f32(const float* x, float* y, int B, int C, int H, int W, int size, int antialias,
                                        const float* mean_host, const float* std_host, void* stream) {
     VCX_REQUIRE(x && y && mean_host && std_host, "vcx_clip_preprocess_f32: null pointer");
     VCX_REQUIRE(B > 0 && C > 0 && C <= 4 && H > 1 && W > 1 && size > 1, "vcx_clip_preprocess_f32: bad shape B=%d C=%d H=%d W=%d size=%d", B, C, H, W, size);
+    VCX_REQUIRE((int64_t)(size - 1) * (H > W ? H : W) < (1ll << 31), "vcx_clip_preprocess_f32: image too large");
     ClipPreArgs a;
     a.B = B; a.C = C; a.H = H; a.W = W; a.S = size;
     const double fy = (double)H / size, fx = (double)W / size;
     a.ksy = a.ksx = 1;
-    a.sy = a.sx = 1.f;
+    a.gy[0] = a.gx[0] = 1.f;
     if (antialias && (fy > 1.0 || fx > 1.0) && !(H == size && W == size)) {       // kornia: blur only when an axis shrinks, sigma = (factor - 1) / 2
         const double sy = fmax((fy - 1.0) / 2.0, 0.001), sx = fmax((fx - 1.0) / 2.0, 0.001);
         int ky = (int)fmax(4.0 * sy, 3.0), kx = (int)fmax(4.0 * sx, 3.0);
         ky += 1 - (ky & 1);
         kx += 1 - (kx & 1);
+        VCX_REQUIRE(ky <= CLIP_MAX_KS && kx <= CLIP_MAX_KS, "vcx_clip_preprocess_f32: shrink factors beyond 33 are not supported (%dx%d -> %d)", H, W, size);
         VCX_REQUIRE(ky / 2 < H && kx / 2 < W, "vcx_clip_preprocess_f32: blur kernel %dx%d exceeds the image %dx%d", ky, kx, H, W);
-        a.ksy = ky; a.ksx = kx; a.sy = (float)sy; a.sx = (float)sx;
+        a.ksy = ky; a.ksx = kx;
+        clip_gauss_taps(ky, sy, a.gy);
+        clip_gauss_taps(kx, sx, a.gx);
     }
-    a.ry = (float)((double)(H - 1) / (size - 1));
-    a.rx = (float)((double)(W - 1) / (size - 1));
     for (int c = 0; c < 4; ++c) {
         a.mean[c] = c < C ? mean_host[c] : 0.f;
         a.istd[c] = c < C ? 1.f / std_host[c] : 1.f;

@@ -431,8 +431,9 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     }
     if (flags & VCX_GEMM_COLSTATS) {
         VCX_REQUIRE(d->colstats && ((uintptr_t)d->colstats & 15) == 0, "vcx_gemm_f16: COLSTATS needs a 16-byte aligned colstats buffer");
-        VCX_REQUIRE(conv && !geglu && !f32 && !lnf && d->M % 64 == 0 && d->N % 8 == 0,
-                    "vcx_gemm_f16: COLSTATS is for fp16 convolutions with M %% 64 == 0 and N %% 8 == 0 (M=%d N=%d)", d->M, d->N);
+        VCX_REQUIRE(!geglu && !f32 && !lnf && d->M % 64 == 0 && d->N % 8 == 0,
+                    "vcx_gemm_f16: COLSTATS is for fp16 outputs (no GEGLU / LNFOLD) with M %% 64 == 0 and N %% 8 == 0 (M=%d N=%d)", d->M, d->N);
+        VCX_REQUIRE(d->ldcs == 0 || (d->ldcs >= d->N && d->ldcs % 2 == 0), "vcx_gemm_f16: COLSTATS ldcs (%lld) must be 0 or an even number >= N", (long long)d->ldcs);
     }
     if (conv) {
         VCX_REQUIRE(d->cin > 0 && d->cin % 8 == 0 && d->kh > 0 && d->kw > 0 && d->K == d->kh * d->kw * d->cin,
@@ -476,6 +477,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.ln_stats = d->ln_stats;
     a.ln_colsum = d->ln_colsum;
     a.colstats = d->colstats;
+    a.ldcs = d->ldcs > 0 ? d->ldcs : d->N;
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * (double)d->N * d->K;
     const double bytes = 2.0 * ((double)d->M * d->K / (conv ? d->kh * d->kw : 1) + (double)d->N * d->K + (double)d->M * d->N);
@@ -539,7 +541,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
         }
         return cfg >= 2 ? big(a, cfg) : launch_dma(a, cfg, conv, geglu, f32, s);
     }
-    VCX_REQUIRE(!(flags & VCX_GEMM_COLSTATS), "vcx_gemm_f16: COLSTATS needs the DMA kernel (cin %% 64 == 0, extents < 4 GiB); cin=%d", d->cin);
+    VCX_REQUIRE(!(flags & VCX_GEMM_COLSTATS), "vcx_gemm_f16: COLSTATS needs the DMA kernel (K / cin %% 64 == 0, extents < 4 GiB); K=%d cin=%d", d->K, d->cin);
     VCX_REQUIRE(!lnf, "vcx_gemm_f16: LNFOLD needs the DMA kernel (K %% 64 == 0, N %% 8 == 0, extents < 4 GiB); K=%d N=%d", d->K, d->N);
     return use160 ? dispatch<160>(a, conv, geglu, f32, s) : dispatch<128>(a, conv, geglu, f32, s);
 }

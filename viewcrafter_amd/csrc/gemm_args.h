@@ -29,6 +29,7 @@ struct GemmArgs {
     const float* ln_stats;    // VCX_GEMM_LNFOLD[_T]: (mean, rstd) pairs
     const float* ln_colsum;   // VCX_GEMM_LNFOLD[_T]: row sums of the folded weight
     float* colstats;          // VCX_GEMM_COLSTATS: (mean, M2) per 64-row strip and output column
+    int64_t ldcs;             // columns per strip of colstats (>= N: the buffer may hold a concatenated partner's columns too)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {

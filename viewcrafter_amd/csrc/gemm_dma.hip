@@ -46,7 +46,7 @@ struct TileCfg {
     static constexpr size_t SMEM_LNF = STAGES + 2 * STRIP;                        // + a second strip (folded-LayerNorm epilogue)
 };
 
-// LNF: 0 = plain epilogue, 1 = VCX_GEMM_LNFOLD, 2 = VCX_GEMM_LNFOLD_T (linear mode only), 3 = VCX_GEMM_COLSTATS (convolutions only);
+// LNF: 0 = plain epilogue, 1 = VCX_GEMM_LNFOLD, 2 = VCX_GEMM_LNFOLD_T (linear mode only), 3 = VCX_GEMM_COLSTATS (convolutions and, round 4, linear layers);
 // separate instantiations, so the plain kernels keep their register allocation
 template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32, int LNF = 0>
 __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, unsigned a_bytes, unsigned w_bytes) {
@@ -302,7 +302,8 @@ int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) 
         vcx_set_error("vcx_gemm_f16(dma): GEGLU needs whole 64-column packed blocks per wave");
         return VCX_EINVAL;
     }
-    if (a.flags & VCX_GEMM_COLSTATS) return launch<Cfg, true, false, false, 3>(a, s);      // convolution, fp16 output (checked by vcx_gemm_f16)
+    if (a.flags & VCX_GEMM_COLSTATS)      // fp16 output, no GEGLU / LNFOLD (checked by vcx_gemm_f16)
+        return conv ? launch<Cfg, true, false, false, 3>(a, s) : launch<Cfg, false, false, false, 3>(a, s);
     if (geglu) {
         if constexpr (Cfg::NF % 4 == 0) return conv ? launch<Cfg, true, true, false>(a, s) : launch<Cfg, false, true, false>(a, s);
         vcx_set_error("vcx_gemm_f16(dma): GEGLU needs whole 64-column packed blocks per wave");

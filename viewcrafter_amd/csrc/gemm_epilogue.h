@@ -330,9 +330,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
                 return x;
             };
-            // one (mean, M2) pair per 64-row strip and column: colstats[strip][N][2], strip = first row of the wave's rows / 64
+            // one (mean, M2) pair per 64-row strip and column: colstats[strip][ldcs][2], strip = first row of the wave's rows / 64
             const int strip = (p.m_begin + tile_m * TBM + wm * WM) >> 6;
-            float* dst = p.colstats + ((size_t)strip * p.N + nstrip) * 2;
+            float* dst = p.colstats + ((size_t)strip * (size_t)p.ldcs + nstrip) * 2;
 #pragma unroll
             for (int u = 0; u < UNITS; ++u) {
                 float mo[8], qo[8];

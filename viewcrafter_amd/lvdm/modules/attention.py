@@ -19,6 +19,7 @@ from torch import nn
 from ... import ops
 from ...packing import fold_layernorm, pack_geglu
 from ..common import default
+from .flow import GN_STATS_LEVEL, out_kwargs
 
 
 def _f16(t):
@@ -329,13 +330,15 @@ class SpatialTransformer(PackedModule):
     def project_context(self, ctx):
         return [project_context(blk.attn2, ctx) for blk in self.transformer_blocks]
 
-    def forward(self, x, context_kv=None, frames_per_video=1, cfg_repeat=1, colstats=None, **kwargs):
+    def forward(self, x, context_kv=None, frames_per_video=1, cfg_repeat=1, colstats=None, want_colstats=False, **kwargs):
         """x [n, H, W, C] fp16 channels-last, n = b*t frames; context_kv from project_context().
         cfg_repeat = r > 1: x holds ONE copy of a batch whose r conditionings (classifier-free guidance: cond / uncond / ...)
         share everything up to here; everything that does not depend on the context - GroupNorm, proj_in, the whole
         self-attention of the first block, LayerNorm and the Q projection of its cross-attention - is computed once and the
         token stream is replicated r times right before the first cross-attention (context_kv holds r * b videos).  The
-        result [r * n, H, W, C] equals the forward of the r-fold replicated input bit for bit."""
+        result [r * n, H, W, C] equals the forward of the r-fold replicated input bit for bit.
+        colstats: column moments of x (no statistics pass for the norm); want_colstats: let proj_out write the moments of the
+        result for the GroupNorm of the layer behind this one.  -> (result, its moments or None)"""
         n, H, W, C = x.shape
         N_img = H * W
         pk = self.packed()
@@ -392,12 +395,13 @@ class SpatialTransformer(PackedModule):
             t = ops.linear(o2, a2["wo"], a2["bo"], residual=t)
             # ---- feed-forward
             t = blk.ff.run(t, ln[2])
-        out = ops.linear(t, pk["wout"], pk["bout"], residual=xin)
+        kw, cs_out = out_kwargs(None, want_colstats and N == N_img, tokens, N_img, D, C, x.device)
+        out = ops.linear(t, pk["wout"], pk["bout"], residual=xin, **kw)
         if N != N_img:
             unpadded = torch.empty((n * N_img, C), dtype=torch.float16, device=x.device)
             ops.copy2d(out, unpadded, n, N_img * C, N * C, N_img * C)
             out = unpadded
-        return out.view(n, H, W, C)
+        return out.view(n, H, W, C), cs_out
 
 
 class TemporalTransformer(PackedModule):
@@ -439,13 +443,16 @@ class TemporalTransformer(PackedModule):
         return dict(gn_w=_f32(self.norm.weight), gn_b=_f32(self.norm.bias), win=_f16(win), bin=_f32(self.proj_in.bias),
                     wout=_f16(wout), bout=_f32(self.proj_out.bias))
 
-    def forward(self, x, context=None):
-        """x [B, T, P, C] fp16 channels-last (P = h*w)."""
+    def forward(self, x, context=None, colstats=None, want_colstats=False, target=None):
+        """x [B, T, P, C] fp16 channels-last (P = h*w).  colstats: column moments of x (the per-video norm then needs no statistics
+        pass); want_colstats / target: proj_out writes the moments of the result / the result itself into a concat buffer
+        (lvdm/modules/flow.py).  -> (result [B, T, P, C or ld], its moments or None)"""
         B, T, P, C = x.shape
         pk = self.packed()
         tokens = B * T * P
         xin = x.reshape(tokens, C)
-        a = ops.group_norm(x.view(B, T * P, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False)
+        stats = None if (colstats is None or GN_STATS_LEVEL < 2) else ops.group_norm_stats_from_colstats(colstats, B, T * P, C)
+        a = ops.group_norm(x.view(B, T * P, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False, stats=stats)
         t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
         D, heads = t.shape[1], self.n_heads
         for blk in self.transformer_blocks:
@@ -458,5 +465,6 @@ class TemporalTransformer(PackedModule):
                                   scale=attn.scale)
                 t = ops.linear(o, ap["wo"], ap["bo"], residual=t)
             t = blk.ff.run(t, ln[2])
-        out = ops.linear(t, pk["wout"], pk["bout"], residual=xin)
-        return out.view(B, T, P, C)
+        kw, cs_out = out_kwargs(target, want_colstats, tokens, P, D, C, x.device)
+        out = ops.linear(t, pk["wout"], pk["bout"], residual=xin, **kw)
+        return out.view(B, T, P, -1), cs_out

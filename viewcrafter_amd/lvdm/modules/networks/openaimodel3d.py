@@ -21,11 +21,7 @@ from torch import nn
 from .... import ops
 from ....packing import pack_conv
 from ..attention import PackedModule, SpatialTransformer, TemporalTransformer, _f16, _f32
-
-# GroupNorm statistics from the producing convolution's epilogue where the chain allows it (ResBlock / TemporalConvBlock);
-# VCX_GN_EPILOGUE_STATS=0 keeps the statistics pass over the tensor everywhere (A/B runs).
-GN_EPILOGUE_STATS = os.environ.get("VCX_GN_EPILOGUE_STATS", "1") != "0"
-
+from ..flow import GN_EPILOGUE_STATS, GN_STATS_LEVEL, CatTarget, Flow, out_kwargs as _out_kwargs
 
 class TimestepBlock(nn.Module):
     """Marker: modules whose forward takes the timestep embedding (reference openaimodel3d.py:19-28)."""
@@ -35,21 +31,26 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """Reference openaimodel3d.py:30-48: routes (emb | context | 5-D view) to each child by type.
     x is channels-last [n = b*t, H, W, C]."""
 
-    def forward(self, x, emb, context=None, batch_size=None, cfg_repeat=1):
+    def forward(self, x, emb, context=None, batch_size=None, cfg_repeat=1, flow=None):
         """cfg_repeat = r > 1 (only for a block that holds the first SpatialTransformer of the graph): the input is one copy
         of an r-fold replicated batch; the transformer replicates it where the conditionings start to differ and the
-        layers after it see batch_size * r videos."""
+        layers after it see batch_size * r videos.  flow (Flow): moments of x in, moments of the result out, and the concat
+        target of the last layer; with a target the returned tensor is a strided view of its left columns."""
         layers = list(self)
-        colstats = None         # column moments of x from the convolution that produced it (for the GroupNorm of a SpatialTransformer right behind a ResBlock)
+        colstats = flow.colstats if flow is not None else None      # column moments of x from the layer that produced it
         for i, layer in enumerate(layers):
+            last = i + 1 == len(layers)
+            nxt = None if last else layers[i + 1]
+            if GN_STATS_LEVEL >= 2:     # whoever consumes the output starts with a GroupNorm
+                want = isinstance(nxt, (ResBlock, SpatialTransformer, TemporalTransformer)) if not last else bool(flow is not None and flow.want)
+            else:                       # round-3 behaviour: only the SpatialTransformer right behind a ResBlock
+                want = isinstance(layer, ResBlock) and isinstance(nxt, SpatialTransformer)
+            target = flow.target if (last and flow is not None) else None
             if isinstance(layer, ResBlock):
-                want = i + 1 < len(layers) and isinstance(layers[i + 1], SpatialTransformer)
-                x = layer(x, emb, batch_size=batch_size, want_colstats=want)
-                if want:
-                    x, colstats = x
+                x, colstats = layer(x, emb, batch_size=batch_size, want_colstats=want, colstats=colstats, target=target)
             elif isinstance(layer, SpatialTransformer):
-                x = layer(x, context_kv=context[id(layer)], frames_per_video=x.shape[0] // batch_size, cfg_repeat=cfg_repeat, colstats=colstats)
-                colstats = None
+                x, colstats = layer(x, context_kv=context[id(layer)], frames_per_video=x.shape[0] // batch_size, cfg_repeat=cfg_repeat,
+                                    colstats=colstats, want_colstats=want and GN_STATS_LEVEL >= 2)
                 if cfg_repeat > 1:
                     # x now holds batch_size * r videos: a ResBlock FOLLOWING the transformer inside this block reads one emb row
                     # per video through a raw pointer (rowadd), so emb must grow with x here, not after the block returns
@@ -57,10 +58,23 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 batch_size, cfg_repeat = batch_size * cfg_repeat, 1
             elif isinstance(layer, TemporalTransformer):
                 n, H, W, C = x.shape
-                x = layer(x.view(batch_size, n // batch_size, H * W, C)).view(n, H, W, C)
+                x, colstats = layer(x.view(batch_size, n // batch_size, H * W, C), colstats=colstats, want_colstats=want, target=target)
+                x = x.view(n, H, W, -1)
+            elif isinstance(layer, (Downsample, Upsample)):
+                x, colstats = layer(x, want_colstats=want, target=target)
             else:
-                x = layer(x)
+                x, colstats = layer(x), None
+        if flow is not None:
+            flow.colstats = colstats
+        if flow is not None and flow.target is not None:      # x is the whole concat buffer: hand back the block's own columns
+            return x[..., :flow.target.c_left]
         return x
+
+
+def _out_channels_of(block):
+    """channels of the tensor a TimestepEmbedSequential returns"""
+    last = list(block)[-1]
+    return last.out_channels if hasattr(last, "out_channels") else last.in_channels
 
 
 class Downsample(PackedModule):
@@ -77,9 +91,13 @@ class Downsample(PackedModule):
     def _pack(self):
         return dict(w=_f16(pack_conv(self.op.weight.detach())), b=_f32(self.op.bias))
 
-    def forward(self, x):
+    def forward(self, x, want_colstats=False, target=None):
+        """-> (y [n, H/2, W/2, C] - or [.., ld] when written into a concat target -, column moments of y or None)"""
         pk = self.packed()
-        return ops.conv2d(x, pk["w"], pk["b"], kh=3, kw=3, stride=2)
+        n, H, W, cin = x.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        kw, cs = _out_kwargs(target, want_colstats, n * Ho * Wo, Ho * Wo, cin, self.out_channels, x.device, in_rows=n * H * W)
+        return ops.conv2d(x, pk["w"], pk["b"], kh=3, kw=3, stride=2, **kw), cs
 
 
 class Upsample(PackedModule):
@@ -97,9 +115,11 @@ class Upsample(PackedModule):
     def _pack(self):
         return dict(w=_f16(pack_conv(self.conv.weight.detach())), b=_f32(self.conv.bias))
 
-    def forward(self, x):
+    def forward(self, x, want_colstats=False, target=None):
         pk = self.packed()
-        return ops.conv2d(x, pk["w"], pk["b"], kh=3, kw=3, ups=1)
+        n, H, W, cin = x.shape
+        kw, cs = _out_kwargs(target, want_colstats, n * 4 * H * W, 4 * H * W, cin, self.out_channels, x.device, in_rows=n * H * W)
+        return ops.conv2d(x, pk["w"], pk["b"], kh=3, kw=3, ups=1, **kw), cs
 
 
 class TemporalConvBlock(PackedModule):
@@ -130,10 +150,11 @@ class TemporalConvBlock(PackedModule):
             out.append((_f32(gn.weight), _f32(gn.bias), gn.eps, _f16(pack_conv(conv.weight.detach())), _f32(conv.bias)))
         return out
 
-    def forward(self, x, colstats=None, want_colstats=False):
-        """x [B, T, P, C] fp16.  `colstats`: column moments of x written by the convolution that produced it (ops.gemm colstats=):
+    def forward(self, x, colstats=None, want_colstats=False, target=None):
+        """x [B, T, P, C] fp16.  `colstats`: column moments of x written by the layer that produced it (ops.gemm colstats=):
         the first norm then needs no statistics pass; the three inner norms get theirs from this block's own convolutions.
-        want_colstats: also return the moments of the OUTPUT (or None), for a per-frame GroupNorm behind this block."""
+        want_colstats: also produce the moments of the OUTPUT (for the per-frame GroupNorm behind this block); target: write the
+        output (and its moments) into a concat buffer.  -> (y, moments of y or None)"""
         B, T, P, C = x.shape
         y = x
         stages = self.packed()
@@ -143,10 +164,17 @@ class TemporalConvBlock(PackedModule):
             a = ops.group_norm(y.reshape(B, T * P, cy), gw, gb, eps, True, stats=stats)
             last = i == len(stages) - 1
             cout = w.shape[0]
-            need = (not last and ops.colstats_ok(B * T * P, T * P, cy, cout)) or (last and want_colstats and ops.colstats_ok(B * T * P, P, cy, cout))
-            colstats = ops.colstats_buffer(B * T * P, cout, x.device) if (GN_EPILOGUE_STATS and need) else None
-            y = ops.temporal_conv3(a.view(B, T, P, -1), w, b, residual=x.reshape(B * T * P, C) if last else None, colstats=colstats)
-        return (y, colstats) if want_colstats else y
+            kw = {}
+            if last and target is not None:
+                kw = target.kwargs(cy, B * T * P)
+                colstats = target.moments
+            else:
+                need = (not last and ops.colstats_ok(B * T * P, T * P, cy, cout)) or (last and want_colstats and ops.colstats_ok(B * T * P, P, cy, cout))
+                colstats = ops.colstats_buffer(B * T * P, cout, x.device) if (GN_EPILOGUE_STATS and need) else None
+                if colstats is not None:
+                    kw = dict(colstats=colstats)
+            y = ops.temporal_conv3(a.view(B, T, P, -1), w, b, residual=x.reshape(B * T * P, C) if last else None, **kw)
+        return y, colstats
 
 
 class ResBlock(PackedModule, TimestepBlock):
@@ -186,15 +214,18 @@ class ResBlock(PackedModule, TimestepBlock):
             pk["bs"] = _f32(self.skip_connection.bias)
         return pk
 
-    def forward(self, x, emb, batch_size=None, want_colstats=False):
+    def forward(self, x, emb, batch_size=None, want_colstats=False, colstats=None, target=None):
         """x [n, H, W, Cin] fp16; emb = SiLU(time+fs embedding) as fp16 [B, emb_channels] (one row per video: the
-        reference repeats it over the T frames, openaimodel3d.py:563).  want_colstats: return (h, column moments of h or None)
-        for a per-frame GroupNorm right behind this block (SpatialTransformer.norm)."""
+        reference repeats it over the T frames, openaimodel3d.py:563).  colstats: column moments of x (the in_layers norm then
+        needs no statistics pass); want_colstats: produce the moments of the output for a per-frame GroupNorm behind this block
+        (SpatialTransformer.norm, the next block's in_layers); target: write output and moments into a concat buffer.
+        -> (h, moments of h or None)"""
         n, H, W, cin = x.shape
         pk = self.packed()
         cout = self.out_channels
         B = emb.shape[0]
-        a = ops.group_norm(x.view(n, H * W, cin), *pk["g1"], True)
+        stats_in = None if colstats is None else ops.group_norm_stats_from_colstats(colstats, n, H * W, cin)
+        a = ops.group_norm(x.view(n, H * W, cin), *pk["g1"], True, stats=stats_in)
         emb_out = ops.linear(emb, pk["we"], pk["be"], out_f32=True)                           # [B, Cout] fp32
         # The norms behind this block's own convolutions take their statistics from those convolutions' epilogues (column moments
         # per 64-row strip, VCX_GEMM_COLSTATS) instead of a pass over the tensor: out_layers' norm (per frame) from conv 1, the
@@ -209,17 +240,21 @@ class ResBlock(PackedModule, TimestepBlock):
         else:
             skip = x.reshape(n * H * W, cout)
         temporal = self.use_temporal_conv and batch_size
-        need2 = (ops.colstats_ok(M, (n // batch_size) * H * W, cout, cout) if temporal
-                 else (want_colstats and ops.colstats_ok(M, H * W, cout, cout)))
-        cs2 = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and need2) else None
-        h = ops.conv2d(a.view(n, H, W, cout), pk["w2"], pk["b2"], kh=3, kw=3, residual=skip, colstats=cs2)
-        cs_out = cs2
         if temporal:
-            h = self.temopral_conv(h.view(batch_size, n // batch_size, H * W, cout), colstats=cs2, want_colstats=want_colstats)
-            if want_colstats:
-                h, cs_out = h
-            h = h.view(n, H, W, cout)
-        return (h, cs_out) if want_colstats else h
+            need2 = ops.colstats_ok(M, (n // batch_size) * H * W, cout, cout)
+            cs2 = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and need2) else None
+            h = ops.conv2d(a.view(n, H, W, cout), pk["w2"], pk["b2"], kh=3, kw=3, residual=skip, colstats=cs2)
+            h, cs_out = self.temopral_conv(h.view(batch_size, n // batch_size, H * W, cout), colstats=cs2, want_colstats=want_colstats,
+                                           target=target)
+            return h.view(n, H, W, -1), cs_out
+        if target is not None:
+            kw = target.kwargs(cout, M)
+            cs_out = target.moments
+        else:
+            cs_out = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and want_colstats and ops.colstats_ok(M, H * W, cout, cout)) else None
+            kw = {} if cs_out is None else dict(colstats=cs_out)
+        h = ops.conv2d(a.view(n, H, W, cout), pk["w2"], pk["b2"], kh=3, kw=3, residual=skip, **kw)
+        return h, cs_out
 
 
 class UNetModel(PackedModule):
@@ -468,30 +503,75 @@ class UNetModel(PackedModule):
             off += p.shape[1]
         h = h.view(b * t, hh, ww, cin)
 
-        hs = []
+        lvl2 = GN_STATS_LEVEL >= 2
+
+        def replicate_cs(c):   # the moments of a replicated tensor: its strips, r times
+            if c is None:
+                return None
+            strips, C_, _ = c.shape
+            return ops.repeat_rows(c.view(torch.float16).view(strips, C_ * 4), r).view(torch.float32).view(r * strips, C_, 2)
+
+        hs = []                # (skip tensor, its column moments or None)
+        cs = None              # column moments of h (None: not known - the consumer makes its statistics pass)
         for i, module in enumerate(self.input_blocks):
+            flow = Flow(colstats=cs, want=lvl2)
             if i == 0:
                 h = ops.conv2d(h, pk["w_in"], pk["b_in"], kh=3, kw=3)
+                flow.colstats = None
                 if self.addition_attention:
-                    h = self.init_attn(h, emb, context=ckv, batch_size=cur_b)
+                    h = self.init_attn(h, emb, context=ckv, batch_size=cur_b, flow=flow)
             elif cur_b != b * r and any(isinstance(layer, SpatialTransformer) for layer in module):
-                h = module(h, emb, context=ckv, batch_size=cur_b, cfg_repeat=r)     # the conditionings enter here
+                h = module(h, emb, context=ckv, batch_size=cur_b, cfg_repeat=r, flow=flow)     # the conditionings enter here
                 cur_b = b * r
                 emb = ops.repeat_rows(emb, r)
-                hs = [replicate(a) for a in hs]                                      # skips recorded so far
+                hs = [(replicate(a), replicate_cs(c)) for a, c in hs]                           # skips recorded so far
             else:
-                h = module(h, emb, context=ckv, batch_size=cur_b)
-            hs.append(h)
+                h = module(h, emb, context=ckv, batch_size=cur_b, flow=flow)
+            cs = flow.colstats
+            hs.append((h, cs))
         if cur_b != b * r:     # a graph without attention in the input path: replicate ahead of the middle block
-            h, hs, emb, cur_b = replicate(h), [replicate(a) for a in hs], ops.repeat_rows(emb, r), b * r
+            h, cs, hs, emb, cur_b = replicate(h), replicate_cs(cs), [(replicate(a), replicate_cs(c)) for a, c in hs], ops.repeat_rows(emb, r), b * r
         b = cur_b
-        h = self.middle_block(h, emb, context=ckv, batch_size=b)
-        for module in self.output_blocks:
-            skip = hs.pop()
-            n, H, W, c1 = h.shape
-            h = ops.concat_channels(h.view(n * H * W, c1), skip.view(n * H * W, skip.shape[-1])).view(n, H, W, -1)
-            h = module(h, emb, context=ckv, batch_size=b)
+        if not lvl2:           # round-3 data path: materialised concat (two copies), statistics pass for every cross-module norm
+            h = self.middle_block(h, emb, context=ckv, batch_size=b)
+            for module in self.output_blocks:
+                skip, _ = hs.pop()
+                n, H, W, c1 = h.shape
+                h = ops.concat_channels(h.view(n * H * W, c1), skip.view(n * H * W, skip.shape[-1])).view(n, H, W, -1)
+                h = module(h, emb, context=ckv, batch_size=b)
+            cs = None
+        else:
+            # Up path (openaimodel3d.py:595-597: h = torch.cat([h, hs.pop()], dim=1); h = module(h, ...)).  The block that PRODUCES h
+            # writes it straight into the left columns of the next block's concatenated input - and its column moments into the left
+            # columns of that tensor's moment buffer - so only the skip half is copied, and the GroupNorm in front of the next
+            # ResBlock takes its statistics from the two producers' epilogues.
+            def target_for(n_, H_, W_, c_left):
+                skip, skip_cs = hs[-1]
+                M_ = n_ * H_ * W_
+                ok = skip_cs is not None and ops.colstats_ok(M_, H_ * W_, 64, c_left + skip.shape[-1])
+                return CatTarget(M_, c_left, skip.shape[-1], device, with_moments=ok)
+            n, H, W, _ = h.shape
+            tgt = target_for(n, H, W, _out_channels_of(self.middle_block))
+            flow = Flow(colstats=cs, target=tgt)
+            h = self.middle_block(h, emb, context=ckv, batch_size=b, flow=flow)
+            for j, module in enumerate(self.output_blocks):
+                skip, skip_cs = hs.pop()
+                n, H, W, c1 = h.shape
+                M, c2 = n * H * W, skip.shape[-1]
+                ops.copy2d(skip.view(M, c2), tgt.data[:, c1:], M, c2, c2, tgt.ld)
+                if tgt.moments is not None:      # the skip's moments behind the producer's: 8 bytes per (strip, column), as fp16 quads
+                    ops.copy2d(skip_cs.view(torch.float16).view(M // 64, c2 * 4), tgt.moments.view(torch.float16).view(M // 64, tgt.ld * 4)[:, c1 * 4:],
+                               M // 64, c2 * 4, c2 * 4, tgt.ld * 4)
+                hcat, cat_cs = tgt.data.view(n, H, W, tgt.ld), tgt.moments
+                tgt = None
+                if j + 1 < len(self.output_blocks):
+                    up = 2 if isinstance(list(module)[-1], Upsample) else 1
+                    tgt = target_for(n, H * up, W * up, _out_channels_of(module))
+                flow = Flow(colstats=cat_cs, want=tgt is None, target=tgt)
+                h = module(hcat, emb, context=ckv, batch_size=b, flow=flow)
+            cs = flow.colstats
         n, H, W, c = h.shape
-        a = ops.group_norm(h.view(n, H * W, c), *pk["g_out"], True)
+        stats = None if cs is None else ops.group_norm_stats_from_colstats(cs, n, H * W, c)
+        a = ops.group_norm(h.view(n, H * W, c), *pk["g_out"], True, stats=stats)
         y = ops.conv2d(a.view(n, H, W, c), pk["w_out"], pk["b_out"], kh=3, kw=3, out_f32=True)   # [n, H, W, out] fp32
         return ops.nthwc_to_ncthw(y.view(b, t, H, W, self.out_channels))

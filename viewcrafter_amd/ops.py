@@ -52,12 +52,14 @@ def require_gpu():
 # GEMM / convolution
 # ------------------------------------------------------------------------------------------
 def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, residual=None, ldr=None, rowadd=None,
-         rowadd_div=0, geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None, ln_stats=None, ln_colsum=None, ln_t=False, colstats=None):
+         rowadd_div=0, geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None, ln_stats=None, ln_colsum=None, ln_t=False, colstats=None,
+         colstats_ld=None, colstats_col=0):
     """out[M, N] = epilogue(alpha * X W^T); see include/vcx.h.  `conv` = dict(in_h, in_w, out_h, out_w, cin, kh, kw,
     stride, pad_h, pad_w, ups) switches X to the im2col gather of a channels-last image.  `ln_stats` (from row_stats) +
     `ln_colsum` select the folded-LayerNorm epilogue (VCX_GEMM_LNFOLD; `ln_t`: the normalised rows are the W operand).
-    `colstats` (fp32 [M / 64, N, 2], see colstats_buffer) makes a convolution write the column moments of its output for the
-    GroupNorm behind it (VCX_GEMM_COLSTATS)."""
+    `colstats` (fp32 [M / 64, N, 2], see colstats_buffer) makes the layer write the column moments of its output for the
+    GroupNorm behind it (VCX_GEMM_COLSTATS); with `colstats_ld` / `colstats_col` the buffer is [M / 64, colstats_ld, 2] and this
+    call fills the columns [colstats_col, colstats_col + N) - the moments of a tensor that is one part of a channel concat."""
     n_out = N // 2 if geglu else N
     _dev16(a, w, residual)
     _dev32(bias, rowadd)
@@ -90,9 +92,11 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
         flags |= GEMM_LNFOLD_T if ln_t else GEMM_LNFOLD
     if colstats is not None:
         _dev32(colstats)
-        if colstats.numel() != (M // 64) * n_out * 2:
-            raise VcxError(f"colstats must hold [M / 64, N, 2] floats (M={M}, N={n_out}), got {tuple(colstats.shape)}")
-        d.colstats = colstats.data_ptr()
+        cld = n_out if colstats_ld is None else int(colstats_ld)
+        if colstats.numel() != (M // 64) * cld * 2 or colstats_col < 0 or colstats_col + n_out > cld:
+            raise VcxError(f"colstats must hold [M / 64, {cld}, 2] floats (M={M}, N={n_out}, first column {colstats_col}), got {tuple(colstats.shape)}")
+        d.colstats = colstats.data_ptr() + 8 * int(colstats_col)
+        d.ldcs = cld
         flags |= GEMM_COLSTATS
     d.lda, d.M, d.N, d.K = lda, M, N, K
     d.ldw = ldw if ldw is not None else K
@@ -161,9 +165,9 @@ def temporal_conv3(x, w, bias, **kwargs):
 # normalisation
 # ------------------------------------------------------------------------------------------
 def colstats_ok(M, pixels, cin, cout, in_rows=None):
-    """Can the convolution producing an [M, cout] output from a cin-channel image write column moments for a GroupNorm whose
-    statistics span `pixels` consecutive output rows?  (VCX_GEMM_COLSTATS: DMA kernel - cin % 64 == 0, cout % 8 == 0, 32-bit byte
-    offsets - whole 64-row strips per statistics unit.)"""
+    """Can the layer producing an [M, cout] output - a convolution over a cin-channel image, or a linear layer with K = cin - write
+    column moments for a GroupNorm whose statistics span `pixels` consecutive output rows?  (VCX_GEMM_COLSTATS: DMA kernel -
+    cin % 64 == 0, cout % 8 == 0, 32-bit byte offsets - whole 64-row strips per statistics unit.)"""
     lim = 0xFFFF0000
     return (pixels % 64 == 0 and M % 64 == 0 and cin % 64 == 0 and cout % 8 == 0 and 2 * (M + 256) * cout < lim
             and 2 * (in_rows if in_rows is not None else M) * cin < lim)
