@@ -193,8 +193,57 @@ def run(calls):
             print(f"    which rows' (colsum, bias') reproduce the wrong value [offsets relative to the element's own row]: {dict(hist.most_common(8))}", flush=True)
 
 
+def run_load(calls):
+    """Does the failure rate of the UNPATCHED kernel (v0) depend on how loaded the chip is?  The same epilogue code runs per tile
+    whatever the problem size, so the number of op_sel instruction instances scales with the tile count - the failure RATE per
+    instance should not.  tokens = 6216 fills the chip (490 tiles of 128x128 on 256 CUs x 2 blocks), tokens = 256 leaves it 4 %
+    occupied (20 tiles); the calls are scaled so that both legs execute the same number of instances."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from viewcrafter_amd.packing import fold_layernorm
+    dev, D = "cuda", 1280
+    def load(v):
+        lib_ = ctypes.CDLL(os.path.join(ABL, f"libvcx_pkfma_v{v}.so"))
+        lib_.vcx_last_error.restype = ctypes.c_char_p
+        lib_.vcx_gemm_f16.argtypes = [ctypes.POINTER(GemmDesc4), ctypes.c_void_p]
+        lib_.vcx_rowstats_f16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+        lib_.vcx_tune_set.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib_.vcx_tune_set(0, 0)
+        return lib_
+    L, Lref = load(0), load(3)          # v3 (scalar fmas on the same registers) never failed: its output is the reference, bit for bit
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(5)
+    gamma, beta = (1 + 0.3 * torch.randn(D, generator=g)).to(dev), (0.2 * torch.randn(D, generator=g)).to(dev)
+    wf, colsum, bias_f = fold_layernorm((torch.randn(D, D, generator=g) / math.sqrt(D)).to(dev), gamma, beta, None)
+    wf, colsum, bias_f = wf.contiguous(), colsum.float().contiguous(), bias_f.float().contiguous()
+    for tokens, n in ((6216, calls), (256, calls * 24), (6216, calls)):
+        x = (torch.randn(tokens, D, generator=g) * 2 + 0.5).to(dev).half()
+        st = torch.empty(tokens, 2, device=dev, dtype=torch.float32)
+        assert L.vcx_rowstats_f16(x.data_ptr(), st.data_ptr(), tokens, D, 1e-5, stream) == 0
+        def call(lib_):
+            o = torch.empty(D, tokens, device=dev, dtype=torch.float16)
+            d = GemmDesc4(A=wf.data_ptr(), W=x.data_ptr(), C=o.data_ptr(), bias=bias_f.data_ptr(), lda=D, M=D, N=tokens, K=D, ldw=D,
+                          ldc=tokens, mode=0, rowadd_div=0, flags=0x2 | 0x100, alpha=1.0, ln_stats=st.data_ptr(), ln_colsum=colsum.data_ptr())
+            assert lib_.vcx_gemm_f16(ctypes.byref(d), stream) == 0, lib_.vcx_last_error()
+            return o
+        ref = call(Lref)
+        assert torch.equal(call(Lref), ref)
+        bad_calls, bad_elems = 0, 0
+        for _ in range(n):
+            nd = int((call(L) != ref).sum())
+            bad_calls += nd > 0
+            bad_elems += nd
+        torch.cuda.synchronize()
+        tiles = ((tokens + 127) // 128) * (D // 128)
+        print(f"v0, tokens {tokens:5d} ({tiles:3d} tiles per call, {n} calls = {tiles * n * 16} op_sel instruction instances): "
+              f"{bad_calls} calls differ from the scalar-fma build, {bad_elems} elements ({bad_elems / 16:.0f} instances) -> "
+              f"{bad_elems / 16 / (tiles * n * 16) * 1e6:.1f} failures per million instances", flush=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "load":
+        run_load(int(sys.argv[2]) if len(sys.argv) > 2 else 60)
     else:
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 30)
