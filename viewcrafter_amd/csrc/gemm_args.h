@@ -83,6 +83,19 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
         tm = vid / tiles_n;
         return;
     }
+#ifdef VCX_TILE_PANEL      // tools/panel_ab.py only: other panel heights, built into tools/_abl/ (the product code below is untouched)
+    constexpr int PNL = VCX_TILE_PANEL;
+    const int tiles_m = ntiles / tiles_n, full = tiles_m / PNL, split = full * PNL * tiles_n;
+    if (vid < split) {
+        const int pnl = vid / (PNL * tiles_n), r = vid - pnl * PNL * tiles_n;
+        tn = r / PNL;
+        tm = pnl * PNL + r % PNL;
+    } else {
+        const int rem = tiles_m - full * PNL, r = vid - split;
+        tn = r / rem;
+        tm = full * PNL + r % rem;
+    }
+#else
     const int tiles_m = ntiles / tiles_n, full = tiles_m >> 3, split = full * 8 * tiles_n;
     if (vid < split) {
         const int pnl = vid / (8 * tiles_n), r = vid - pnl * 8 * tiles_n;
@@ -93,6 +106,7 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
         tn = r / rem;
         tm = full * 8 + r % rem;
     }
+#endif
 }
 
 int persistent_grid(int ntiles, int blocks_per_cu = 2);
