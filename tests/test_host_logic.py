@@ -631,3 +631,41 @@ def test_reference_yaml_selects_this_implementation(name):
     assert model.model.conditioning_key == "hybrid" and model.parameterization == "v" and model.use_dynamic_rescale
     assert sum(p.numel() for p in model.model.diffusion_model.parameters()) == 1438854980        # SURVEY: 1438.85 M
     assert sum(p.numel() for p in model.parameters()) == 2609129005
+
+
+def test_folded_packs_follow_the_parent_blocks_layernorm_and_lnfold_ok_mirrors_the_kernel(monkeypatch):
+    """the packed projection weights of CrossAttention embed the LayerNorm of the OWNING BasicTransformerBlock; changing
+    that norm by any route (`.data` assignment, in-place edit, norm.load_state_dict) must rebuild them - they used to be dropped only
+    through the block's own _apply / load_state_dict hooks.  And ops.lnfold_ok says where the folded kernel applies, so that a shape
+    outside it takes LayerNorm + the plain projection instead of VCX_EINVAL from every transformer block."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.lvdm.modules import attention as A
+    torch.manual_seed(0)
+    blk = A.BasicTransformerBlock(128, 2, 64, context_dim=None)
+    blk.set_kind("temporal")
+    with torch.no_grad():
+        blk.norm1.weight.copy_(1 + 0.1 * torch.randn(128))
+    first = blk.attn1.packed()
+    assert first["qkv"]["colsum"] is not None and blk.attn1.packed() is first            # folded, and cached
+    w0 = first["qkv"]["w"].clone()
+    with torch.no_grad():
+        blk.norm1.weight.mul_(2.0)                                                        # in place: version counter moves
+    second = blk.attn1.packed()
+    assert second is not first and torch.allclose(second["qkv"]["w"].float(), 2 * w0.float(), rtol=2e-3, atol=1e-4)
+    blk.norm1.weight.data = torch.ones(128)                                               # storage swapped under the parameter
+    third = blk.attn1.packed()
+    assert third is not second and not torch.equal(third["qkv"]["w"], second["qkv"]["w"])
+    blk.norm1.load_state_dict({"weight": torch.full((128,), 0.5), "bias": torch.zeros(128)})
+    assert blk.attn1.packed() is not third
+    # the un-folded form of a folded pack, built on demand, is the plain fp16 weight
+    plain_w, plain_b = A._plain_of(blk.attn1.packed()["qkv"])
+    assert plain_b is None and torch.equal(plain_w, torch.cat([blk.attn1.to_q.weight, blk.attn1.to_k.weight, blk.attn1.to_v.weight]).detach().half())
+    # lnfold_ok: mirrors dma_ok of csrc/gemm.hip (knob, K % 64, GEMM N % 8, 32-bit extents incl. 256 rows past the end)
+    monkeypatch.setattr(ops, "tune_get", lambda name: 1)
+    assert ops.lnfold_ok(460800, 960, 320) and ops.lnfold_ok(460800, 320, 320, transposed=True)
+    assert not ops.lnfold_ok(460800, 960, 72)                       # K % 64
+    assert not ops.lnfold_ok(1001, 320, 320, transposed=True)       # GEMM N = tokens % 8
+    assert not ops.lnfold_ok(3_500_000, 960, 640)                   # 4.5 GB of token rows: beyond 32-bit byte offsets
+    assert not ops.lnfold_ok(1_200_000, 2560, 320)                  # output rows x ldc beyond 4 GiB
+    monkeypatch.setattr(ops, "tune_get", lambda name: 0)
+    assert not ops.lnfold_ok(460800, 960, 320)                      # knob GEMM_DMA = 0: register-staged kernel, no folded epilogue
