@@ -17,7 +17,11 @@ from hypothesis import HealthCheck, given, settings, strategies as st      # noq
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-FUZZ = settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+import os      # noqa: E402
+# default: 40 derandomised examples per property (the driver's run and a local run see the same shapes).  A deeper exploration run:
+# VCX_FUZZ_EXAMPLES=300 VCX_FUZZ_RANDOM=1 python -m pytest tests/test_fuzz_gpu.py -m gpu   (profiles/r04g_fuzz_deep.log)
+FUZZ = settings(max_examples=int(os.environ.get("VCX_FUZZ_EXAMPLES", "40")), deadline=None,
+                derandomize=os.environ.get("VCX_FUZZ_RANDOM") != "1", suppress_health_check=list(HealthCheck), database=None)
 
 
 def rel_l2(a, b):

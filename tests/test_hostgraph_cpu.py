@@ -7,6 +7,7 @@ mistake - a moment buffer with the wrong leading dimension, a skip copied behind
 shared CFG prefix - shows up before a GPU minute is spent.
 """
 import importlib
+import math
 
 import pytest
 import torch
@@ -117,3 +118,71 @@ def test_host_graph_of_the_vae_vs_reference_golden(monkeypatch):
     assert rel_l2(dec, g["vae_decode"]) <= 8e-3 and rel_l2(post.parameters, g["vae_encode_moments"]) <= 8e-3
     sd = {k: v for k, v in m.state_dict().items()}
     assert rel_l2(odd, O.vae_decode(sd, TINY_DDCONFIG, synth_input("vae_z_9x15", (1, 4, 9, 15)))) <= 8e-3
+
+
+def _clip_preprocess_cpu(x, size, antialias, mean, std):
+    from oracle import clip_oracle as C
+    return C.kornia_normalize((C.kornia_resize(x.float(), (size, size), antialias) + 1.0) / 2.0, mean, std)
+
+
+@pytest.mark.parametrize("tag,kw", [("cfg", dict(n_samples=2, multiple_cond_cfg=False, cfg_img=None)),
+                                    ("multicond", dict(n_samples=1, multiple_cond_cfg=True, cfg_img=3.0))])
+def test_host_graph_of_image_guided_synthesis_vs_the_references_own_run(monkeypatch, tag, kw):
+    """The whole driver - both OpenCLIP towers, Resampler, VAE encode, DDIM sampler (CFG / multi-condition, 5 steps, eta 1), UNet,
+    VAE decode - as the product's host code issues it, on the CPU stand-ins, against the fixture the reference's OWN
+    `image_guided_synthesis` wrote (tests/golden/gen_golden.py::gen_igs).  The GPU twin is tests/test_entry_gpu.py."""
+    from oracle.weights import NamedRandn
+    from tests.tiny_config import CLIP_TINY, CLIP_TINY_CFG, IGS_H, IGS_T, IGS_W, igs_model_params
+    from tests.util import SCHEDULE_BUFFERS
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.config import Config
+    from viewcrafter_amd.lvdm.modules.encoders import condition as cond
+    from viewcrafter_amd.utils.diffusion_utils import image_guided_synthesis, instantiate_from_config
+    cpu_kernels.install(monkeypatch)
+    monkeypatch.setattr(ops, "clip_preprocess", _clip_preprocess_cpu)
+    monkeypatch.setattr(ops, "ddim_step", _ddim_step_cpu)
+    cond.CLIP_CONFIGS[CLIP_TINY] = CLIP_TINY_CFG
+    R = "lvdm.modules.encoders."
+    params = Config.wrap(igs_model_params("lvdm.modules.networks.openaimodel3d.UNetModel", "lvdm.models.autoencoder.AutoencoderKL",
+                                          R + "condition.FrozenOpenCLIPEmbedder", R + "condition.FrozenOpenCLIPImageEmbedderV2",
+                                          R + "resampler.Resampler", device="cpu"))
+    m = instantiate_from_config(Config(target="lvdm.models.ddpm3d.VIPLatentDiffusion", params=params)).eval()
+    load_synth(m, skip=SCHEDULE_BUFFERS)
+    g = golden("igs_tiny")
+    videos = torch.tanh(synth_input("igs_videos", (1, 3, IGS_T, IGS_H, IGS_W)))
+    fake = NamedRandn(f"igs_{tag}_randn")
+    monkeypatch.setattr(torch, "randn", fake)
+    with torch.no_grad():
+        vid = image_guided_synthesis(m, [""], videos, [1, 4, IGS_T, IGS_H // 8, IGS_W // 8], ddim_steps=5, ddim_eta=1.0,
+                                     unconditional_guidance_scale=7.5, fs=10, text_input=False, timestep_spacing="uniform_trailing",
+                                     guidance_rescale=0.7, condition_index=[0], **kw)
+    monkeypatch.undo()
+    assert fake.calls == int(g[f"igs_{tag}_randn_calls"])
+    e = rel_l2(vid[..., ::4, ::4], g[f"igs_{tag}_sub4"])
+    print(f"host graph of image_guided_synthesis[{tag}] on CPU stand-ins vs the reference's own run: rel-L2 {e:.3e}")
+    assert e <= 3e-2
+
+
+def _ddim_step_cpu(x, v_cond, v_uncond, noise, coef, ws=None, v_img=None, cfg_img=0.0):
+    """include/vcx.h vcx_ddim_step3_f32 in plain PyTorch (fp64 sums): coef = {sqrt_acp_t, sqrt_1m_acp_t, a_prev, sigma_t, scale_ratio,
+    cfg_scale, guidance_rescale, parameterization_is_v}."""
+    sa, s1, a_prev, sigma, ratio, cfg, resc, is_v = [float(c) for c in coef[:8]]
+    if v_uncond is None:
+        v = v_cond
+    elif v_img is None:
+        v = v_uncond + cfg * (v_cond - v_uncond)
+    else:
+        v = v_uncond + cfg_img * (v_img - v_uncond) + cfg * (v_cond - v_img)
+    if v_uncond is not None and resc > 0:
+        dims = tuple(range(1, v.dim()))
+        std_pos, std_cfg = v_cond.double().std(dim=dims, keepdim=True), v.double().std(dim=dims, keepdim=True)
+        v = (resc * (v.double() * (std_pos / std_cfg)) + (1 - resc) * v.double()).float()
+    if is_v:
+        e_t, pred_x0 = sa * v + s1 * x, sa * x - s1 * v
+    else:
+        e_t, pred_x0 = v, (x - s1 * v) / sa
+    pred_x0 = pred_x0 * ratio
+    x_prev = math.sqrt(a_prev) * pred_x0 + math.sqrt(max(1.0 - a_prev - sigma ** 2, 0.0)) * e_t
+    if noise is not None and sigma != 0:
+        x_prev = x_prev + sigma * noise
+    return x_prev, pred_x0
