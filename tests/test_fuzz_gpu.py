@@ -175,7 +175,11 @@ def test_fuzz_groupnorm_and_layernorm(n, pix, cg, silu, offset, seed):
     ref = ((xg - mean) / (var + 1e-5).sqrt()).view(n, pix, C) * g.double() + b.double()
     if silu:
         ref = F.silu(ref)
-    assert rel_l2(out, ref) <= 3e-3, (n, pix, C, silu, offset)
+    # a "group" of one or two values has variance ~0: rsqrt(eps) = 316 then multiplies the fp32 rounding of mean (|mean| = 50), and
+    # the result is noise around beta whatever the implementation (torch refuses the single-value case outright) - not a shape the
+    # graph can produce (>= 10 channels per group x >= 15 pixels), so it only has to stay finite and near beta
+    degenerate = pix * (C // 32) < 4
+    assert torch.isfinite(out).all() and rel_l2(out, ref) <= (5e-2 if degenerate else 3e-3), (n, pix, C, silu, offset)
     rows = x.view(-1, C)
     ln = ops.layer_norm(rows, g, b, 1e-5)
     assert rel_l2(ln, F.layer_norm(rows.double(), (C,), g.double(), b.double(), 1e-5)) <= 3e-3, (n * pix, C)
