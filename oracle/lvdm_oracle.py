@@ -211,13 +211,19 @@ def temporal_conv_block(sd, p, x):
 
 
 def res_block(sd, p, x, emb, batch, temporal_conv=True):
-    """openaimodel3d.py:210-236 (no up/down, no scale-shift norm): GN->SiLU->conv3x3, + Linear(SiLU(emb)),
-    GN->SiLU->conv3x3, + skip (identity or 1x1 conv), then the TemporalConvBlock on 'b c t h w'."""
+    """openaimodel3d.py:210-236 (no up/down): GN->SiLU->conv3x3, + Linear(SiLU(emb)), GN->SiLU->conv3x3, + skip (identity or
+    1x1 conv), then the TemporalConvBlock on 'b c t h w'.  use_scale_shift_norm (:221-225: emb_layers emits 2 x C_out and the
+    second norm becomes norm(h) * (1 + scale) + shift) is recognised by the shape of emb_layers.1.weight."""
     h = F.conv2d(F.silu(_gn(sd, p + ".in_layers.0", x, 1e-5)), sd[p + ".in_layers.2.weight"], sd[p + ".in_layers.2.bias"],
                  padding=1)
-    h = h + _lin(sd, p + ".emb_layers.1", F.silu(emb))[:, :, None, None]
-    h = F.conv2d(F.silu(_gn(sd, p + ".out_layers.0", h, 1e-5)), sd[p + ".out_layers.3.weight"],
-                 sd[p + ".out_layers.3.bias"], padding=1)
+    emb_out = _lin(sd, p + ".emb_layers.1", F.silu(emb))[:, :, None, None]
+    cout = sd[p + ".out_layers.3.weight"].shape[0]
+    if emb_out.shape[1] == 2 * cout:
+        scale, shift = emb_out[:, :cout], emb_out[:, cout:]
+        h = F.silu(_gn(sd, p + ".out_layers.0", h, 1e-5) * (1 + scale) + shift)
+    else:
+        h = F.silu(_gn(sd, p + ".out_layers.0", h + emb_out, 1e-5))
+    h = F.conv2d(h, sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
     if p + ".skip_connection.weight" in sd:
         x = F.conv2d(x, sd[p + ".skip_connection.weight"], sd[p + ".skip_connection.bias"])
     h = x + h

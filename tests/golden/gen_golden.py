@@ -135,6 +135,25 @@ def gen_unet(out):
             print("unet", tag, tuple(y.shape), float(y.abs().mean()))
 
 
+def gen_unet_ssn(out):
+    """The same tiny graph with use_scale_shift_norm=True (openaimodel3d.py:221-225: FiLM-style conditioning of every ResBlock) -
+    not used by the two shipped YAMLs, accepted by the reference's constructor, so accepted here."""
+    from lvdm.modules.networks.openaimodel3d import UNetModel
+    torch.manual_seed(0)
+    hp = dict(TINY_UNET, use_scale_shift_norm=True)
+    unet = UNetModel(**hp).eval()
+    shapes = load_synth(unet)
+    out["unet_keys"] = np.array(sorted(shapes.keys()))
+    out["unet_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    with torch.no_grad():
+        b, t, h, w, L = 2, 3, 16, 32, 77 + 40
+        x = synth_input("unet_ssn_x", (b, 8, t, h, w))
+        ctx = synth_input("unet_ssn_ctx", (b, L, TINY_UNET["context_dim"]))
+        y = unet(x, torch.tensor([999, 399]), context=ctx, fs=torch.tensor([10, 3]))
+        out["unet_out"] = y.numpy()
+        print("unet ssn", tuple(y.shape), float(y.abs().mean()))
+
+
 def gen_vae(out):
     from lvdm.models.autoencoder import AutoencoderKL
     torch.manual_seed(0)
@@ -460,7 +479,7 @@ def main():
         print("transformers not importable:", e)
     import_reference()
     torch.set_num_threads(8)
-    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
+    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
                      ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs),
                      ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli), ("api_signatures", gen_api), ("reference_yaml", gen_yaml)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:

@@ -186,3 +186,22 @@ def _ddim_step_cpu(x, v_cond, v_uncond, noise, coef, ws=None, v_img=None, cfg_im
     if noise is not None and sigma != 0:
         x_prev = x_prev + sigma * noise
     return x_prev, pred_x0
+
+
+def test_host_graph_with_scale_shift_norm_vs_reference_golden(monkeypatch):
+    """ResBlock(use_scale_shift_norm=True): (1 + scale, shift) folded into per-video GroupNorm affine parameters."""
+    import numpy as np
+    import os
+    cpu_kernels.install(monkeypatch)
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    m = UNetModel(**dict(TINY_UNET, use_scale_shift_norm=True)).eval()
+    load_synth(m)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_ssn.npz"))
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g["unet_keys"]]
+    x = synth_input("unet_ssn_x", (2, 8, 3, 16, 32))
+    ctx = synth_input("unet_ssn_ctx", (2, 77 + 40, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = m(x, torch.tensor([999, 399]), context=ctx, fs=torch.tensor([10, 3]))
+    e = rel_l2(y, g["unet_out"])
+    print(f"host graph with use_scale_shift_norm vs the reference golden: {e:.3e}")
+    assert e <= UNET_TOL

@@ -64,6 +64,23 @@ def test_unet_forward_vs_reference_golden(unet, tag, shape, L):
     assert e <= UNET_TOL
 
 
+def test_unet_with_scale_shift_norm_vs_reference_golden():
+    """use_scale_shift_norm=True (reference openaimodel3d.py:221-225; golden by the reference's own UNetModel): the FiLM form of
+    the ResBlock conditioning, folded into per-video GroupNorm affine parameters - B = 2 videos with different timesteps."""
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    m = UNetModel(**dict(TINY_UNET, use_scale_shift_norm=True)).eval()
+    load_synth(m)
+    m = m.to(DEV)
+    g = golden("unet_tiny_ssn")
+    x = synth_input("unet_ssn_x", (2, 8, 3, 16, 32)).to(DEV)
+    ctx = synth_input("unet_ssn_ctx", (2, 77 + 40, TINY_UNET["context_dim"])).to(DEV)
+    with torch.no_grad():
+        y = m(x, torch.tensor([999, 399], device=DEV), context=ctx, fs=torch.tensor([10, 3], device=DEV))
+    e = rel_l2(y, g["unet_out"])
+    print(f"unet with use_scale_shift_norm: rel-L2 vs reference = {e:.3e}")
+    assert e <= UNET_TOL
+
+
 def test_unet_forward_vs_oracle_fresh_inputs_and_cfg_batching(unet):
     """Seeded inputs at another shape (T=5, odd spatial tiling); also checks that a B=2 call equals two B=1 calls
     (the sampler batches cond/uncond) and that the context-K/V cache does not leak between conditionings."""

@@ -279,3 +279,16 @@ def test_clip_preprocess_against_pillow_documents_the_delta():
     psnr_db = 10 * np.log10(1.0 / float(((pil - ours) ** 2).mean()))
     assert 38.0 <= psnr_db <= 46.0, psnr_db
     assert 10 * np.log10(1.0 / float(((pil - ours.T[:224, :224]) ** 2).mean())) < 25.0      # ... and a transposed result would not pass
+
+
+def test_oracle_unet_with_scale_shift_norm_matches_reference():
+    """use_scale_shift_norm=True (reference openaimodel3d.py:221-225) - not used by the shipped YAMLs, accepted by the reference's
+    constructor: golden written by the reference's own UNetModel with that flag (gen_golden.py::gen_unet_ssn)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_ssn.npz"))
+    shapes = {str(k): eval(str(s)) for k, s in zip(g["unet_keys"], g["unet_shapes"])}
+    sd = synth_state_dict(shapes)
+    x = synth_input("unet_ssn_x", (2, 8, 3, 16, 32))
+    ctx = synth_input("unet_ssn_ctx", (2, 77 + 40, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = O.unet_forward(sd, dict(TINY_UNET, use_scale_shift_norm=True), x, torch.tensor([999, 399]), ctx, torch.tensor([10, 3]))
+    assert np.abs(y.numpy() - g["unet_out"]).max() <= 2e-5 * np.abs(g["unet_out"]).max() + 1e-6

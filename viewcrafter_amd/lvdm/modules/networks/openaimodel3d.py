@@ -178,19 +178,21 @@ class TemporalConvBlock(PackedModule):
 
 
 class ResBlock(PackedModule, TimestepBlock):
-    """Reference openaimodel3d.py:109-236 (no up/down, no scale-shift norm, 1x1 skip when channels change)."""
+    """Reference openaimodel3d.py:109-236 (no up/down, 1x1 skip when channels change; use_scale_shift_norm - the FiLM form of
+    :221-225, not used by the shipped YAMLs - folds (1 + scale, shift) into per-video GroupNorm affine parameters)."""
 
     def __init__(self, channels, emb_channels, dropout, out_channels=None, use_scale_shift_norm=False, dims=2,
                  use_checkpoint=False, use_conv=False, up=False, down=False, use_temporal_conv=False,
                  tempspatial_aware=False):
         super().__init__()
-        if use_scale_shift_norm or up or down or use_conv or dims != 2:
+        if up or down or use_conv or dims != 2:
             raise NotImplementedError("ResBlock variant not used by the ViewCrafter configs")
         self.channels, self.emb_channels = channels, emb_channels
         self.out_channels = out_channels or channels
         self.use_temporal_conv = use_temporal_conv
+        self.use_scale_shift_norm = use_scale_shift_norm
         self.in_layers = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Conv2d(channels, self.out_channels, 3, padding=1))
-        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, self.out_channels))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, 2 * self.out_channels if use_scale_shift_norm else self.out_channels))
         self.out_layers = nn.Sequential(nn.GroupNorm(32, self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
                                         nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1))
         nn.init.zeros_(self.out_layers[-1].weight)
@@ -232,9 +234,22 @@ class ResBlock(PackedModule, TimestepBlock):
         # first norm of the temporal block (per video) from conv 2 - where frames are whole strips (not at 9x16 = 144 pixels).
         M = n * H * W
         cs1 = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and ops.colstats_ok(M, H * W, cin, cout)) else None
-        h = ops.conv2d(a.view(n, H, W, cin), pk["w1"], pk["b1"], kh=3, kw=3, rowadd=emb_out, rowadd_div=(n // B) * H * W, colstats=cs1)
-        stats = None if cs1 is None else ops.group_norm_stats_from_colstats(cs1, n, H * W, cout)
-        a = ops.group_norm(h.view(n, H * W, cout), *pk["g2"], True, stats=stats)
+        if not self.use_scale_shift_norm:
+            h = ops.conv2d(a.view(n, H, W, cin), pk["w1"], pk["b1"], kh=3, kw=3, rowadd=emb_out, rowadd_div=(n // B) * H * W, colstats=cs1)
+            stats = None if cs1 is None else ops.group_norm_stats_from_colstats(cs1, n, H * W, cout)
+            a = ops.group_norm(h.view(n, H * W, cout), *pk["g2"], True, stats=stats)
+        else:
+            # norm(h) * (1 + scale) + shift with (scale, shift) = the two halves of emb_out, one pair per video: the GroupNorm's
+            # affine parameters of that video become gamma (1 + scale) and beta (1 + scale) + shift ([C] vectors, a few hundred
+            # floats of host-side plumbing per video), the statistics are untouched
+            h = ops.conv2d(a.view(n, H, W, cin), pk["w1"], pk["b1"], kh=3, kw=3, colstats=cs1)
+            stats = None if cs1 is None else ops.group_norm_stats_from_colstats(cs1, n, H * W, cout)
+            h3, a, fpv = h.view(n, H * W, cout), torch.empty((n, H * W, cout), dtype=torch.float16, device=x.device), n // B
+            gam, bet, eps = pk["g2"]
+            for v in range(B):
+                sc1 = 1.0 + emb_out[v, :cout]
+                ops.group_norm(h3[v * fpv:(v + 1) * fpv], (gam * sc1).contiguous(), (bet * sc1 + emb_out[v, cout:]).contiguous(), eps, True,
+                               stats=None if stats is None else stats[v * fpv:(v + 1) * fpv], out=a[v * fpv:(v + 1) * fpv])
         if "ws" in pk:
             skip = ops.conv2d(x, pk["ws"], pk["bs"], kh=1, kw=1).view(n * H * W, cout)
         else:
