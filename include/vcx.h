@@ -34,7 +34,8 @@ extern "C" {
 
 /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*.  3: vcx_gemm_desc grows ln_stats / ln_colsum (VCX_GEMM_LNFOLD*),
  * vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32.  5: vcx_gemm_desc starts with
- * struct_size - a descriptor of another layout is rejected instead of read past its end; vcx_clip_preprocess_f32. */
+ * struct_size - a descriptor of another layout is rejected instead of read past its end; ldcs; vcx_clip_preprocess_f32,
+ * vcx_add_nchw_f32_to_nhwc_f16. */
 #define VCX_ABI_VERSION 5
 
 int vcx_abi_version(void);
@@ -226,6 +227,9 @@ int vcx_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream);
  * openaimodel3d.py:596). cols, ldd, lds multiples of 8. */
 int vcx_copy2d_f16(const void* src, void* dst, int64_t rows, int cols, int64_t lds, int64_t ldd,
                    void* stream);
+/* h[n][p][c] += src[n][c][p] (h fp16 channels-last [n, HW, C], src fp32 [n, C, HW]): the adapter feature maps the reference adds
+ * behind every third input block when `features_adapter` is given (openaimodel3d.py:582-585). */
+int vcx_add_nchw_f32_to_nhwc_f16(const float* src, void* h, int n, int C, int64_t HW, void* stream);
 /* fp32 [B, C, T, H, W] -> fp16 channels-last [B, T, H, W, ldc] at channel offset c_off
  * (DiffusionWrapper concat, ddpm3d.py:1437-1443; 'b c t h w -> (b t) c h w',
  * openaimodel3d.py:566); `scale` multiplies (VAE 1/scale_factor, ddpm3d.py:657-661). */

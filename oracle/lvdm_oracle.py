@@ -300,10 +300,11 @@ def _run_layers(sd, prefix, layers, h, emb, context, batch):
     return h
 
 
-def unet_forward(sd, hp, x, timesteps, context, fs=None, taps=None):
+def unet_forward(sd, hp, x, timesteps, context, fs=None, taps=None, features_adapter=None):
     """UNetModel.forward, openaimodel3d.py:548-603.  sd keys are relative to the UNet ('input_blocks.0.0.weight'...).
     x [b, in_ch, t, h, w]; timesteps [b] int64; context [b, L, ctx_dim]; fs [b] int64.  `taps`: optional dict that
-    receives every block's output [(b t), C, h, w] under its module name (per-block error tables in the tests)."""
+    receives every block's output [(b t), C, h, w] under its module name (per-block error tables in the tests).
+    features_adapter: list of [(b t), C, h, w] maps added behind input blocks 2, 5, 8, 11 (:582-588)."""
     b, _, t, _, _ = x.shape
     mc = hp["model_channels"]
     emb = _lin(sd, "time_embed.2", F.silu(_lin(sd, "time_embed.0", timestep_embedding(timesteps, mc))))
@@ -323,6 +324,7 @@ def unet_forward(sd, hp, x, timesteps, context, fs=None, taps=None):
         emb = emb + fe.repeat_interleave(t, dim=0)
     inputs, middle, outputs = unet_layout(hp)
     hs = []
+    adapter_idx = 0
     for i, layers in enumerate(inputs):
         h = _run_layers(sd, f"input_blocks.{i}", layers, h, emb, context, b)
         if i == 0 and hp.get("addition_attention", False):
@@ -330,9 +332,13 @@ def unet_forward(sd, hp, x, timesteps, context, fs=None, taps=None):
             h5 = h.view(b, t, c, hh, ww).permute(0, 2, 1, 3, 4)
             h5 = temporal_transformer(sd, "init_attn.0", h5, 8)
             h = h5.permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)
+        if (i + 1) % 3 == 0 and features_adapter is not None:
+            h = h + features_adapter[adapter_idx]
+            adapter_idx += 1
         hs.append(h)
         if taps is not None:
             taps[f"input_blocks.{i}"] = h
+    assert features_adapter is None or len(features_adapter) == adapter_idx, "Wrong features_adapter"
     h = _run_layers(sd, "middle_block", middle, h, emb, context, b)
     if taps is not None:
         taps["middle_block"] = h

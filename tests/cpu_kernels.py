@@ -181,6 +181,11 @@ def copy2d(src, dst, rows, cols, lds, ldd):
     _view2d(dst, rows, cols, ldd).copy_(_view2d(src, rows, cols, lds))
 
 
+def add_nchw_(h, feat):
+    h.copy_((h.float() + feat.float().permute(0, 2, 3, 1)).to(_f16))
+    return h
+
+
 def ncthw_to_nthwc(src, dst, c_off=0, scale=1.0):
     C = src.shape[1]
     dst[..., c_off:c_off + C] = (src.float() * scale).permute(0, 2, 3, 4, 1).to(_f16)
@@ -209,7 +214,7 @@ def install(monkeypatch):
     _TUNE.clear()
     table = dict(require_gpu=lambda: None, gemm=gemm, group_norm_stats_from_colstats=group_norm_stats_from_colstats, group_norm=group_norm,
                  row_stats=row_stats, layer_norm=layer_norm, flash_attn=flash_attn, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn,
-                 softmax_rows_=softmax_rows_, copy2d=copy2d, ncthw_to_nthwc=ncthw_to_nthwc, nthwc_to_ncthw=nthwc_to_ncthw,
+                 softmax_rows_=softmax_rows_, copy2d=copy2d, add_nchw_=add_nchw_, ncthw_to_nthwc=ncthw_to_nthwc, nthwc_to_ncthw=nthwc_to_ncthw,
                  timestep_embedding=timestep_embedding, silu_f32=lambda x: F.silu(x.float()), gelu_=lambda x: x.copy_(F.gelu(x.float()).to(_f16)),
                  to_f16=lambda x: x.to(_f16).contiguous(), to_f32=lambda x: x.float().contiguous(),
                  tune_get=lambda name: _TUNE.get(name, _lib.TUNE[name][1]),

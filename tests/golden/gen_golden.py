@@ -154,6 +154,26 @@ def gen_unet_ssn(out):
         print("unet ssn", tuple(y.shape), float(y.abs().mean()))
 
 
+def adapter_features(b, t, h, w, mc=TINY_UNET["model_channels"], mult=TINY_UNET["channel_mult"]):
+    """What a T2I-adapter hands to UNetModel.forward(features_adapter=...): one [(b t), C, h, w] map per level, added behind input
+    blocks 2, 5, 8, 11 (openaimodel3d.py:582-588)."""
+    return [synth_input(f"adapter_{i}", (b * t, mc * m, h >> i, w >> i), scale=0.5) for i, m in enumerate(mult)]
+
+
+def gen_unet_adapter(out):
+    from lvdm.modules.networks.openaimodel3d import UNetModel
+    torch.manual_seed(0)
+    unet = UNetModel(**TINY_UNET).eval()
+    load_synth(unet)
+    with torch.no_grad():
+        b, t, h, w, L = 1, 3, 16, 32, 77 + 40
+        x = synth_input("unet_ad_x", (b, 8, t, h, w))
+        ctx = synth_input("unet_ad_ctx", (b, L, TINY_UNET["context_dim"]))
+        y = unet(x, torch.tensor([599]), context=ctx, fs=torch.tensor([10]), features_adapter=adapter_features(b, t, h, w))
+        out["unet_out"] = y.numpy()
+        print("unet adapter", tuple(y.shape), float(y.abs().mean()))
+
+
 def gen_vae(out):
     from lvdm.models.autoencoder import AutoencoderKL
     torch.manual_seed(0)
@@ -479,7 +499,7 @@ def main():
         print("transformers not importable:", e)
     import_reference()
     torch.set_num_threads(8)
-    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
+    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("unet_tiny_adapter", gen_unet_adapter), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
                      ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs),
                      ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli), ("api_signatures", gen_api), ("reference_yaml", gen_yaml)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:

@@ -205,3 +205,27 @@ def test_host_graph_with_scale_shift_norm_vs_reference_golden(monkeypatch):
     e = rel_l2(y, g["unet_out"])
     print(f"host graph with use_scale_shift_norm vs the reference golden: {e:.3e}")
     assert e <= UNET_TOL
+
+
+def test_host_graph_with_features_adapter_vs_reference_golden(monkeypatch):
+    """UNetModel.forward(features_adapter=[...]) (reference openaimodel3d.py:582-588), also under the shared CFG prefix (the maps are
+    given once per video and shared by the r evaluations); a list of the wrong length is refused like the reference's assert."""
+    import numpy as np
+    import os
+    from tests.test_oracle_golden import _adapter_features
+    m, _ = _unet(monkeypatch, 2)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_adapter.npz"))
+    x = synth_input("unet_ad_x", (1, 8, 3, 16, 32))
+    ctx = synth_input("unet_ad_ctx", (1, 77 + 40, TINY_UNET["context_dim"]))
+    feats = _adapter_features(1, 3, 16, 32)
+    ts, fs = torch.tensor([599]), torch.tensor([10])
+    with torch.no_grad():
+        y = m(x, ts, context=ctx, fs=fs, features_adapter=feats)
+        y2 = m(x, ts, context=torch.cat([ctx, ctx]), fs=fs, features_adapter=feats, cfg_repeat=2)
+    e = rel_l2(y, g["unet_out"])
+    print(f"host graph with features_adapter vs the reference golden: {e:.3e}")
+    assert e <= UNET_TOL and rel_l2(y2[1:], g["unet_out"]) <= UNET_TOL and rel_l2(y2[:1], g["unet_out"]) <= UNET_TOL
+    with pytest.raises(ValueError, match="Wrong features_adapter"):        # one map too many: the reference's assert (:588)
+        m(x, ts, context=ctx, fs=fs, features_adapter=feats + [feats[0]])
+    with pytest.raises(IndexError):                                         # one too few: the reference's list index fails as well
+        m(x, ts, context=ctx, fs=fs, features_adapter=feats[:3])

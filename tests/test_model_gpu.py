@@ -81,6 +81,22 @@ def test_unet_with_scale_shift_norm_vs_reference_golden():
     assert e <= UNET_TOL
 
 
+def test_unet_with_features_adapter_vs_reference_golden(unet):
+    """features_adapter (reference openaimodel3d.py:582-588): adapter maps in the reference's own [(b t), C, h, w] layout, added
+    behind input blocks 2, 5, 8, 11 by vcx_add_nchw_f32_to_nhwc_f16; golden by the reference's own forward."""
+    m, _ = unet
+    g = golden("unet_tiny_adapter")
+    x = synth_input("unet_ad_x", (1, 8, 3, 16, 32)).to(DEV)
+    ctx = synth_input("unet_ad_ctx", (1, 77 + 40, TINY_UNET["context_dim"])).to(DEV)
+    feats = [synth_input(f"adapter_{i}", (3, TINY_UNET["model_channels"] * mu, 16 >> i, 32 >> i), scale=0.5).to(DEV)
+             for i, mu in enumerate(TINY_UNET["channel_mult"])]
+    with torch.no_grad():
+        y = m(x, torch.tensor([599], device=DEV), context=ctx, fs=torch.tensor([10], device=DEV), features_adapter=feats)
+    e = rel_l2(y, g["unet_out"])
+    print(f"unet with features_adapter: rel-L2 vs reference = {e:.3e}")
+    assert e <= UNET_TOL
+
+
 def test_unet_forward_vs_oracle_fresh_inputs_and_cfg_batching(unet):
     """Seeded inputs at another shape (T=5, odd spatial tiling); also checks that a B=2 call equals two B=1 calls
     (the sampler batches cond/uncond) and that the context-K/V cache does not leak between conditionings."""

@@ -292,3 +292,25 @@ def test_oracle_unet_with_scale_shift_norm_matches_reference():
     with torch.no_grad():
         y = O.unet_forward(sd, dict(TINY_UNET, use_scale_shift_norm=True), x, torch.tensor([999, 399]), ctx, torch.tensor([10, 3]))
     assert np.abs(y.numpy() - g["unet_out"]).max() <= 2e-5 * np.abs(g["unet_out"]).max() + 1e-6
+
+
+def _adapter_features(b, t, h, w):
+    return [synth_input(f"adapter_{i}", (b * t, TINY_UNET["model_channels"] * m, h >> i, w >> i), scale=0.5)
+            for i, m in enumerate(TINY_UNET["channel_mult"])]
+
+
+def test_oracle_unet_with_features_adapter_matches_reference():
+    """features_adapter (reference openaimodel3d.py:582-588: adapter maps added behind input blocks 2, 5, 8, 11) - golden written by
+    the reference's own UNetModel.forward (gen_golden.py::gen_unet_adapter)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_adapter.npz"))
+    u = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny.npz"))
+    sd = synth_state_dict({str(k): eval(str(s)) for k, s in zip(u["unet_keys"], u["unet_shapes"])})
+    x = synth_input("unet_ad_x", (1, 8, 3, 16, 32))
+    ctx = synth_input("unet_ad_ctx", (1, 77 + 40, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = O.unet_forward(sd, TINY_UNET, x, torch.tensor([599]), ctx, torch.tensor([10]), features_adapter=_adapter_features(1, 3, 16, 32))
+        y0 = O.unet_forward(sd, TINY_UNET, x, torch.tensor([599]), ctx, torch.tensor([10]))
+    assert np.abs(y.numpy() - g["unet_out"]).max() <= 2e-5 * np.abs(g["unet_out"]).max() + 1e-6
+    assert np.abs(y0.numpy() - g["unet_out"]).max() > 1e-2                       # the adapter maps matter
+    with pytest.raises(AssertionError, match="Wrong features_adapter"):
+        O.unet_forward(sd, TINY_UNET, x, torch.tensor([599]), ctx, torch.tensor([10]), features_adapter=_adapter_features(1, 3, 16, 32) + [x])

@@ -266,6 +266,28 @@ extern "C" int vcx_clip_preprocess_f32(const float* x, float* y, int B, int C, i
     return vcx_check_launch("vcx_clip_preprocess_f32");
 }
 
+// h[n][p][c] += src[n][c][p]: the T2I-adapter feature maps the reference adds behind every third input block
+// (openaimodel3d.py:582-585), handed over in the reference's own [(b t), C, h, w] layout.  Never on the ViewCrafter path proper.
+__global__ void add_nchw_to_nhwc_kernel(const float* __restrict__ src, half_t* __restrict__ h, int n, int C, int64_t HW) {
+    const int64_t total = (int64_t)n * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t r = i / C;
+        const int64_t p = r % HW;
+        const int64_t b = r / HW;
+        h[i] = (half_t)((float)h[i] + src[(b * C + c) * HW + p]);
+    }
+}
+
+extern "C" int vcx_add_nchw_f32_to_nhwc_f16(const float* src, void* h, int n, int C, int64_t HW, void* stream) {
+    VCX_REQUIRE(src && h && n > 0 && C > 0 && HW > 0, "vcx_add_nchw_f32_to_nhwc_f16: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)n * C * HW;
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 8.0 * total);
+    hipLaunchKernelGGL(add_nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, (half_t*)h, n, C, HW);
+    return vcx_check_launch("vcx_add_nchw_f32_to_nhwc_f16");
+}
+
 extern "C" int vcx_gelu_f16(const void* x, void* y, int64_t n, void* stream) {
     VCX_REQUIRE(x && y && n > 0 && n % 8 == 0, "vcx_gelu_f16: bad arguments (n must be a multiple of 8)");
     VCX_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "vcx_gelu_f16: pointers must be 16-byte aligned");

@@ -490,8 +490,6 @@ class UNetModel(PackedModule):
         conditionings enter; the output [r * B, ...] is bit-identical to the forward of the r-fold replicated batch
         (tests/test_model_gpu.py::test_cfg_shared_prefix_is_bit_identical)."""
         ops.require_gpu()
-        if features_adapter is not None:
-            raise NotImplementedError("features_adapter is not used on the ViewCrafter path")
         parts = list(x) if isinstance(x, (list, tuple)) else [x]
         b, _, t, hh, ww = parts[0].shape
         device = parts[0].device
@@ -527,6 +525,7 @@ class UNetModel(PackedModule):
             return ops.repeat_rows(c.view(torch.float16).view(strips, C_ * 4), r).view(torch.float32).view(r * strips, C_, 2)
 
         hs = []                # (skip tensor, its column moments or None)
+        adapter_idx = 0
         cs = None              # column moments of h (None: not known - the consumer makes its statistics pass)
         for i, module in enumerate(self.input_blocks):
             flow = Flow(colstats=cs, want=lvl2)
@@ -543,7 +542,15 @@ class UNetModel(PackedModule):
             else:
                 h = module(h, emb, context=ckv, batch_size=cur_b, flow=flow)
             cs = flow.colstats
+            if features_adapter is not None and (i + 1) % 3 == 0:      # plug-in adapter features (openaimodel3d.py:582-585)
+                feat = features_adapter[adapter_idx]
+                if feat.shape[0] * r == h.shape[0] and r > 1:           # given per un-replicated batch: the r evaluations share it
+                    feat = feat.repeat(r, 1, 1, 1)
+                h = ops.add_nchw_(h.contiguous(), feat)
+                adapter_idx, cs = adapter_idx + 1, None                 # the moments of h no longer describe it
             hs.append((h, cs))
+        if features_adapter is not None and len(features_adapter) != adapter_idx:
+            raise ValueError("Wrong features_adapter")                  # the reference's assertion, openaimodel3d.py:588
         if cur_b != b * r:     # a graph without attention in the input path: replicate ahead of the middle block
             h, cs, hs, emb, cur_b = replicate(h), replicate_cs(cs), [(replicate(a), replicate_cs(c)) for a, c in hs], ops.repeat_rows(emb, r), b * r
         b = cur_b

@@ -347,6 +347,18 @@ def concat_channels(a, b):
     return out
 
 
+def add_nchw_(h, feat):
+    """h [n, H, W, C] fp16 channels-last += feat [n, C, H, W] (any float dtype): adapter features (openaimodel3d.py:582-585)."""
+    n, H, W, C = h.shape
+    feat = feat.float().contiguous()
+    if tuple(feat.shape) != (n, C, H, W):
+        raise VcxError(f"adapter feature {tuple(feat.shape)} does not match the activation [{n}, {C}, {H}, {W}]")
+    _dev16(h)
+    _dev32(feat)
+    check(lib().vcx_add_nchw_f32_to_nhwc_f16(feat.data_ptr(), h.data_ptr(), n, C, H * W, _stream()), "add_nchw")
+    return h
+
+
 def ncthw_to_nthwc(src, dst, c_off=0, scale=1.0):
     """src fp32 [B, C, T, H, W] -> dst fp16 [B, T, H, W, ldc][..., c_off:c_off+C]."""
     B, C, T, H, W = src.shape
