@@ -229,3 +229,24 @@ def test_host_graph_with_features_adapter_vs_reference_golden(monkeypatch):
         m(x, ts, context=ctx, fs=fs, features_adapter=feats + [feats[0]])
     with pytest.raises(IndexError):                                         # one too few: the reference's list index fails as well
         m(x, ts, context=ctx, fs=fs, features_adapter=feats[:3])
+
+
+@pytest.mark.parametrize("variant", [dict(temporal_attention=False), dict(temporal_conv=False), dict(addition_attention=False, fs_condition=False)])
+def test_host_graph_of_graph_variants_the_shipped_yamls_do_not_use(monkeypatch, variant):
+    """Blocks that end in a SpatialTransformer (no temporal attention: its result is COPIED into the next block's concat target),
+    ResBlocks without the temporal convolution (the spatial conv 2 writes the target itself), no init_attn / fps embedding: same
+    constructor arguments as the reference accepts, checked against the oracle on the same weights."""
+    cpu_kernels.install(monkeypatch)
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    hp = dict(TINY_UNET, **variant)
+    m = UNetModel(**hp).eval()
+    sd = load_synth(m)
+    x = synth_input("var_x", (1, 8, 2, 16, 32))
+    ctx = synth_input("var_ctx", (1, 77 + 32, TINY_UNET["context_dim"]))
+    ts, fs = torch.tensor([459]), torch.tensor([10])
+    with torch.no_grad():
+        y = m(x, ts, context=ctx, fs=fs)
+        ref = O.unet_forward(sd, hp, x, ts, ctx, fs)
+    e = rel_l2(y, ref)
+    print(f"host graph variant {variant}: rel-L2 vs oracle {e:.3e}")
+    assert e <= UNET_TOL

@@ -97,6 +97,24 @@ def test_unet_with_features_adapter_vs_reference_golden(unet):
     assert e <= UNET_TOL
 
 
+@pytest.mark.parametrize("variant", [dict(temporal_attention=False), dict(temporal_conv=False)])
+def test_unet_graph_variants_vs_oracle(variant):
+    """Graphs the shipped YAMLs do not use but the constructor accepts: blocks ending in a SpatialTransformer (its result is copied
+    into the next block's concat target), ResBlocks without the temporal convolution (conv 2 writes the target).  vs the fp32 oracle."""
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    hp = dict(TINY_UNET, **variant)
+    m = UNetModel(**hp).eval()
+    sd = load_synth(m)
+    m = m.to(DEV)
+    x = synth_input("var_x", (1, 8, 2, 16, 32))
+    ctx = synth_input("var_ctx", (1, 77 + 32, TINY_UNET["context_dim"]))
+    ts, fs = torch.tensor([459]), torch.tensor([10])
+    with torch.no_grad():
+        y = m(x.to(DEV), ts.to(DEV), context=ctx.to(DEV), fs=fs.to(DEV))
+        ref = O.unet_forward(sd, hp, x, ts, ctx, fs)
+    assert rel_l2(y, ref) <= UNET_TOL
+
+
 def test_unet_forward_vs_oracle_fresh_inputs_and_cfg_batching(unet):
     """Seeded inputs at another shape (T=5, odd spatial tiling); also checks that a B=2 call equals two B=1 calls
     (the sampler batches cond/uncond) and that the context-K/V cache does not leak between conditionings."""

@@ -64,6 +64,13 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 x, colstats = layer(x, want_colstats=want, target=target)
             else:
                 x, colstats = layer(x), None
+            if target is not None and not isinstance(layer, (ResBlock, TemporalTransformer, Downsample, Upsample)):
+                # a last layer that cannot write into a concat target (a SpatialTransformer in a graph without temporal attention, a
+                # bare convolution): its result is copied into the target's left columns, and the next norm makes its statistics pass
+                n_, H_, W_, C_ = x.shape
+                ops.copy2d(x.reshape(n_ * H_ * W_, C_), target.data, n_ * H_ * W_, C_, C_, target.ld)
+                target.moments, colstats = None, None
+                x = target.data.view(n_, H_, W_, target.ld)
         if flow is not None:
             flow.colstats = colstats
         if flow is not None and flow.target is not None:      # x is the whole concat buffer: hand back the block's own columns
