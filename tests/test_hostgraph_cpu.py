@@ -250,3 +250,18 @@ def test_host_graph_of_graph_variants_the_shipped_yamls_do_not_use(monkeypatch, 
     e = rel_l2(y, ref)
     print(f"host graph variant {variant}: rel-L2 vs oracle {e:.3e}")
     assert e <= UNET_TOL
+
+
+@pytest.mark.parametrize("t,h,w,r", [(3, 24, 40, 2), (2, 8, 24, 3), (5, 16, 16, 1), (1, 32, 32, 2)])
+def test_host_graph_at_odd_sizes_and_three_conditionings(monkeypatch, t, h, w, r):
+    """Latents whose token counts are not multiples of 8 / 64 at some level (padded attention rows, no moments there), T = 1,
+    and r = 3 conditionings (multi-condition CFG) through the shared prefix - against the oracle and the replicated batch."""
+    m, sd = _unet(monkeypatch, 2)
+    x = synth_input(f"odd_x_{h}", (1, 8, t, h, w))
+    ctx = synth_input(f"odd_ctx_{h}", (r, 77 + 48, TINY_UNET["context_dim"]))
+    ts, fs = torch.tensor([459]), torch.tensor([10])
+    with torch.no_grad():
+        y = m(x, ts, context=ctx, fs=fs, cfg_repeat=r) if r > 1 else m(x, ts, context=ctx, fs=fs)
+        for i in range(r):
+            ref = O.unet_forward(sd, TINY_UNET, x, ts, ctx[i:i + 1], fs)
+            assert rel_l2(y[i:i + 1], ref) <= UNET_TOL, (i, rel_l2(y[i:i + 1], ref))
