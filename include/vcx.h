@@ -35,7 +35,7 @@ extern "C" {
 /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*.  3: vcx_gemm_desc grows ln_stats / ln_colsum (VCX_GEMM_LNFOLD*),
  * vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32.  5: vcx_gemm_desc starts with
  * struct_size - a descriptor of another layout is rejected instead of read past its end; ldcs; vcx_clip_preprocess_f32,
- * vcx_add_nchw_f32_to_nhwc_f16, vcx_attn_temporal_proj_d64_f16. */
+ * vcx_add_nchw_f32_to_nhwc_f16. */
 #define VCX_ABI_VERSION 5
 
 int vcx_abi_version(void);
@@ -197,16 +197,6 @@ int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const void* vt1, 
 int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads,
                               int64_t ld, int k_off, int v_off, int64_t ldo, float scale,
                               void* stream);
-
-/* Temporal attention + its output projection + residual in one launch (round 4):
- *   out[token, :] = residual[token, :] + bias + concat_h( softmax(scale q_h k_h^T) v_h ) Wo^T
- * - CrossAttention.forward + to_out.0 + the `+ x` of BasicTransformerBlock in temporal blocks (attention.py:81-126, 57, 243-245).
- * qkv as for vcx_attn_temporal_d64_f16; wo fp16 [cout][heads * 64] (nn.Linear weight), bias fp32 [cout] or NULL, residual fp16
- * [tokens][ldr] or NULL (may alias out).  cout % 32 == 0, cout <= 320: a wave keeps one pixel's [cout, T] output tile in
- * accumulators while it walks the heads, so O is never written; wider layers use vcx_attn_temporal_d64_f16 + vcx_gemm_f16. */
-int vcx_attn_temporal_proj_d64_f16(const void* qkv, void* out, const void* wo, const float* bias, const void* residual, int B, int T,
-                                   int64_t P, int heads, int cout, int64_t ld, int k_off, int v_off, int64_t ldo, int64_t ldr,
-                                   float scale, void* stream);
 
 /* Row softmax in place on fp16 [rows][ld] over the first n columns (fp32 math): VAE AttnBlock, ae_modules.py:66-69.
  * ld % 8 == 0; when n is not a multiple of 8 the columns up to the next multiple of 8 (ld must cover them) are written as zeros. */

@@ -169,20 +169,6 @@ def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale):
     return out
 
 
-def temporal_attn_proj(qkv, wo, bias, residual, out=None, *, B, T, P, heads, ld, k_off, v_off, scale):
-    o = torch.empty((B * T * P, heads * 64), dtype=_f16)
-    temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=ld, k_off=k_off, v_off=v_off, ldo=heads * 64, scale=scale)
-    y = o.float() @ wo.float().t()
-    if bias is not None:
-        y = y + bias.float()
-    if residual is not None:
-        y = y + residual.float()
-    if out is None:
-        out = torch.empty((B * T * P, wo.shape[0]), dtype=_f16)
-    out.copy_(y.to(_f16))
-    return out
-
-
 def softmax_rows_(x, n=None):
     n = x.shape[1] if n is None else n
     n8 = (n + 7) // 8 * 8
@@ -227,7 +213,7 @@ def install(monkeypatch):
     from viewcrafter_amd import _lib, ops
     _TUNE.clear()
     table = dict(require_gpu=lambda: None, gemm=gemm, group_norm_stats_from_colstats=group_norm_stats_from_colstats, group_norm=group_norm,
-                 row_stats=row_stats, layer_norm=layer_norm, flash_attn=flash_attn, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn, temporal_attn_proj=temporal_attn_proj,
+                 row_stats=row_stats, layer_norm=layer_norm, flash_attn=flash_attn, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn,
                  softmax_rows_=softmax_rows_, copy2d=copy2d, add_nchw_=add_nchw_, ncthw_to_nthwc=ncthw_to_nthwc, nthwc_to_ncthw=nthwc_to_ncthw,
                  timestep_embedding=timestep_embedding, silu_f32=lambda x: F.silu(x.float()), gelu_=lambda x: x.copy_(F.gelu(x.float()).to(_f16)),
                  to_f16=lambda x: x.to(_f16).contiguous(), to_f32=lambda x: x.float().contiguous(),

@@ -822,38 +822,6 @@ def test_temporal_attention(B, T, P, heads):
     check(out, ref, tol=3e-3, name="temporal attn")
 
 
-@pytest.mark.parametrize("B,T,P,heads,cout", [(2, 25, 300, 5, 320), (1, 16, 64, 8, 320), (1, 1, 9, 1, 64), (2, 32, 17, 2, 128), (1, 3, 1000, 4, 256),
-                                              (1, 25, 13, 3, 192), (1, 7, 8, 1, 32)])
-def test_temporal_attention_with_fused_output_projection(B, T, P, heads, cout):
-    """vcx_attn_temporal_proj_d64_f16: x + bias + temporal_attention(qkv) Wo^T in one launch (reference attention.py:81-126 + to_out.0
-    + the residual of :243-245) - against fp32 torch, against the unfused pair (attention kernel -> GEMM), in place on the residual,
-    with pixel counts that leave waves of the last block idle, T = 1 and T = 32, 1 to 8 heads, every supported output width class."""
-    from viewcrafter_amd import ops
-    C = heads * 64
-    tokens = B * T * P
-    qkv = rnd(tokens, 3 * C, seed=801).to(DEV).half()
-    wo = (rnd(cout, C, seed=802) / math.sqrt(C)).to(DEV).half()
-    bias = rnd(cout, seed=803).to(DEV)
-    res = rnd(tokens, cout, seed=804).to(DEV).half()
-    scale = 0.125
-    x = qkv.float().view(B, T, P, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)
-    att = (torch.softmax(x[0] @ x[1].transpose(-1, -2) * scale, -1) @ x[2]).permute(0, 3, 1, 2, 4).reshape(tokens, C)
-    ref = att.half().float() @ wo.float().t() + bias + res.float()
-    out = ops.temporal_attn_proj(qkv, wo, bias, res, B=B, T=T, P=P, heads=heads, ld=3 * C, k_off=C, v_off=2 * C, scale=scale)
-    check(out, ref, tol=3e-3, name="temporal attention + projection")
-    o = torch.empty((tokens, C), dtype=torch.float16, device=DEV)
-    ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=3 * C, k_off=C, v_off=2 * C, ldo=C, scale=scale)
-    unfused = ops.linear(o, wo, bias, residual=res)
-    assert rel_l2(out, unfused) <= 1e-3
-    for _ in range(5):
-        assert torch.equal(ops.temporal_attn_proj(qkv, wo, bias, res, B=B, T=T, P=P, heads=heads, ld=3 * C, k_off=C, v_off=2 * C, scale=scale), out)
-    inplace = res.clone()
-    ops.temporal_attn_proj(qkv, wo, bias, inplace, out=inplace, B=B, T=T, P=P, heads=heads, ld=3 * C, k_off=C, v_off=2 * C, scale=scale)
-    assert torch.equal(inplace, out)
-    nobias = ops.temporal_attn_proj(qkv, wo, None, None, B=B, T=T, P=P, heads=heads, ld=3 * C, k_off=C, v_off=2 * C, scale=scale)
-    check(nobias, att.half().float() @ wo.float().t(), tol=3e-3, name="temporal attention + projection, no bias / residual")
-
-
 def test_softmax_rows():
     from viewcrafter_amd import ops
     x = (rnd(100, 520, seed=61) * 3).to(DEV).half()

@@ -37,10 +37,6 @@ FOLD_LAYERNORM = os.environ.get("VCX_LN_FOLD", "1") != "0"
 # ... except in front of the GEGLU projection: its epilogue is arithmetic-bound (GELU) and the two extra multiply-adds per output pair
 # cost more than the LayerNorm write they save (profiles/r03_experiments.md section 8: +2.6 ... +7.5 % on the pair) - opt-in only.
 FOLD_LAYERNORM_FF = os.environ.get("VCX_LN_FOLD_FF", "0") == "1"
-# Temporal attention, its output projection and the residual as ONE launch where the block is at most 320 channels wide (level 0 and
-# init_attn: vcx_attn_temporal_proj_d64_f16 keeps the output tile in accumulators, O never goes to HBM); VCX_TATTN_FUSED=0 keeps the
-# attention kernel + K = C GEMM everywhere (A/B runs).
-TATTN_FUSED = os.environ.get("VCX_TATTN_FUSED", "0") != "0"          # (off until the GPU A/B of this round is in)
 
 
 def _ln_projection(w, ln, alpha=1.0, bias=None):
@@ -464,10 +460,6 @@ class TemporalTransformer(PackedModule):
             for attn, lnp in ((blk.attn1, ln[0]), (blk.attn2, ln[1])):
                 ap = attn.packed()
                 qkv = ln_linear(t, ap["qkv"], lnp)                                   # [tokens, 3D]
-                if TATTN_FUSED and ops.temporal_attn_proj_ok(ap["wo"].shape[0]):
-                    t = ops.temporal_attn_proj(qkv, ap["wo"], ap["bo"], t, B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D,
-                                               scale=attn.scale)
-                    continue
                 o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
                 ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D, ldo=D,
                                   scale=attn.scale)

@@ -265,24 +265,6 @@ def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale):
     return out
 
 
-def temporal_attn_proj_ok(cout):
-    """vcx_attn_temporal_proj_d64_f16 keeps a pixel's [cout, T] output tile in accumulators: cout % 32 == 0 and <= 320."""
-    return cout % 32 == 0 and 32 <= cout <= 320
-
-
-def temporal_attn_proj(qkv, wo, bias, residual, out=None, *, B, T, P, heads, ld, k_off, v_off, scale):
-    """out = residual + bias + temporal_attention(qkv) Wo^T in one launch (O is never written); wo [cout, heads * 64] fp16."""
-    cout = wo.shape[0]
-    _dev16(qkv, wo, residual, out)
-    _dev32(bias)
-    if out is None:
-        out = torch.empty((B * T * P, cout), dtype=_f16, device=qkv.device)
-    check(lib().vcx_attn_temporal_proj_d64_f16(qkv.data_ptr(), out.data_ptr(), wo.data_ptr(), _ptr(bias), _ptr(residual), B, T, P, heads, cout,
-                                               ld, k_off, v_off, out.stride(0), residual.stride(0) if residual is not None else 0, scale,
-                                               _stream()), "attn_temporal_proj_d64")
-    return out
-
-
 def softmax_rows_(x, n=None):
     rows = x.shape[0]
     check(lib().vcx_softmax_rows_f16(x.data_ptr(), rows, n if n is not None else x.shape[1], x.stride(0), _stream()),
