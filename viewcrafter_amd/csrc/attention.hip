@@ -550,8 +550,10 @@ struct TAttnArgs {
 __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
     constexpr int VLD = 72;                                           // LDS row pitch (halfs): 144 B keeps 16-B alignment
     constexpr int WAVES = 8;
-    // wave-private patch: V, Q, K rows of this (pixel, head), 32 x 64 halfs each
-    __shared__ __attribute__((aligned(16))) half_t sVt[WAVES][3 * 32 * VLD];
+    // wave-private patch: the V rows of this (pixel, head), 32 x 64 halfs, and ONE more such area that holds the Q rows and then -
+    // once their fragments are in registers - the K rows (round 4: 9.2 KB per wave instead of 13.8, so that two blocks fit a CU
+    // and sixteen waves, not eight, hide each other's HBM round trips)
+    __shared__ __attribute__((aligned(16))) half_t sVt[WAVES][2 * 32 * VLD];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int lq = lane & 31, hi = lane >> 5;
@@ -570,8 +572,7 @@ __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
     // 32 bytes from each of 32 frame rows per instruction: 4.2 TB/s; staged: 4.95 TB/s, profiles/r02_experiments.md.)
     h8 qf[4], kf[4];
     half_t* sv = sVt[wave];
-    half_t* sq = sv + 32 * VLD;
-    half_t* sk = sv + 64 * VLD;
+    half_t* sqk = sv + 32 * VLD;
     {
         h8 q4[4], k4[4], v4[4];
 #pragma unroll
@@ -586,15 +587,21 @@ __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = (lane >> 3) + 8 * it, ch = lane & 7;
-            *reinterpret_cast<h8*>(sq + row * VLD + ch * 8) = q4[it];
-            *reinterpret_cast<h8*>(sk + row * VLD + ch * 8) = k4[it];
+            *reinterpret_cast<h8*>(sqk + row * VLD + ch * 8) = q4[it];
             *reinterpret_cast<h8*>(sv + row * VLD + ch * 8) = v4[it];
         }
+        // LDS operations of one wave complete in order: no barrier (the patch is wave-private), and the K rows may overwrite the Q
+        // rows as soon as the Q fragment reads have been ISSUED
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {     // LDS operations of one wave complete in order: no barrier, the patch is wave-private
-            qf[s] = *reinterpret_cast<const h8*>(sq + lq * VLD + s * 16 + hi * 8);
-            kf[s] = *reinterpret_cast<const h8*>(sk + lq * VLD + s * 16 + hi * 8);
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const h8*>(sqk + lq * VLD + s * 16 + hi * 8);
+        asm volatile("" ::: "memory");                                // keep the compiler from moving the K stores above the Q reads
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = (lane >> 3) + 8 * it, ch = lane & 7;
+            *reinterpret_cast<h8*>(sqk + row * VLD + ch * 8) = k4[it];
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const h8*>(sqk + lq * VLD + s * 16 + hi * 8);
     }
 
     // S^T[key, q]: lane (q = lq, hi) holds keys (r&3) + 8*(r>>2) + 4*hi
