@@ -400,7 +400,7 @@ def test_conv_colstats_rejects_what_the_kernel_cannot_do():
         ops.conv2d(x, w, None, kh=3, kw=3, colstats=ops.colstats_buffer(128, 64, DEV))
 
 
-@pytest.mark.parametrize("rows,C", [(10, 64), (1001, 320), (333, 1280), (5, 512)])
+@pytest.mark.parametrize("rows,C", [(10, 64), (1001, 320), (333, 1280), (5, 512), (777, 640), (50, 304), (33, 576)])
 def test_layernorm(rows, C):
     from viewcrafter_amd import ops
     x = (rnd(rows, C, seed=43) * 3 + 1).to(DEV).half()

@@ -301,6 +301,11 @@ void launch_ln(const half_t* x, half_t* y, const float* g, const float* b, int64
 
 void dispatch_ln(const half_t* xp, half_t* yp, const float* gamma, const float* beta, int64_t rows, int C, float eps, hipStream_t s) {
     const int nc8 = C >> 3;
+    // C = 320 and C = 640 (the token widths of levels 0 / 1): half the lanes per row and five 16-byte chunks per lane - 5 loads in flight
+    // per thread, 32 / 16 rows per block - measured 3-8 % faster than the 3-chunk forms on those widths (profiles/r04o_ln_variants.txt;
+    // twice the lanes per row is 20-40 % slower)
+    if (nc8 > 32 && nc8 <= 40) return launch_ln<8, 5>(xp, yp, gamma, beta, rows, C, eps, s);
+    if (nc8 > 64 && nc8 <= 80) return launch_ln<16, 5>(xp, yp, gamma, beta, rows, C, eps, s);
     if (nc8 <= 8) launch_ln<8, 1>(xp, yp, gamma, beta, rows, C, eps, s);
     else if (nc8 <= 16) launch_ln<8, 2>(xp, yp, gamma, beta, rows, C, eps, s);
     else if (nc8 <= 32) launch_ln<16, 2>(xp, yp, gamma, beta, rows, C, eps, s);
