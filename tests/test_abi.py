@@ -146,3 +146,34 @@ def test_no_kernel_overwrites_the_data_registers_of_a_wide_store_right_behind_it
     # ... and the packed fma form that was not bit-reproducible (LNFOLD_T epilogue, 128x128 tile): low result from a high source half
     assert len(mod.store_data_hazards("_Zk:\n\tv_pk_fma_f32 v[60:61], v[60:61], v[4:5], v[0:1] op_sel:[0,1,1]\n")) == 1
     assert mod.store_data_hazards("_Zk:\n\tv_pk_fma_f32 v[60:61], v[60:61], v[4:5], v[0:1] op_sel_hi:[1,0,0]\n") == []
+
+
+def test_product_build_reads_no_scratch_knob_on_a_launch_path():
+    """VCX_TUNE_EXP0 / EXP1 are "free for one-off experiments" (vcx.h) - a default build must not consult them, or an
+    unrelated experiment that sets one changes (or, as in round 3, breaks) a production dispatch.  Every read in csrc/ has to sit
+    inside a preprocessor region that only an ablation / experiment build enables."""
+    csrc = os.path.join(ROOT, "viewcrafter_amd", "csrc")
+    offenders = []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        stack = []                                   # (macro, active_in_default_build)
+        for ln, line in enumerate(open(os.path.join(csrc, name)), 1):
+            t = line.strip()
+            m = re.match(r"#\s*(ifdef|ifndef|if|else|elif|endif)\b\s*(.*)", t)
+            if m:
+                kind, rest = m.group(1), m.group(2).split("//")[0].strip()
+                if kind in ("ifdef", "if"):
+                    stack.append((rest, not re.search(r"VCX_\w*(ABLATION|EXPERIMENT)\w*", rest)))
+                elif kind == "ifndef":
+                    stack.append((rest, True))
+                elif kind == "else" and stack:
+                    macro, active = stack.pop()
+                    was_ifndef_of_ablation = bool(re.search(r"VCX_\w*(ABLATION|EXPERIMENT)\w*", macro)) and active
+                    stack.append((macro, (not active) and not was_ifndef_of_ablation))
+                elif kind == "endif" and stack:
+                    stack.pop()
+                continue
+            if re.search(r"vcx_tune\(\s*VCX_TUNE_EXP[01]\s*\)", t) and all(active for _, active in stack):
+                offenders.append(f"{name}:{ln}: {t}")
+    assert not offenders, offenders

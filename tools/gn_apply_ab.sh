@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs csrc/norm.hip built with -DVCX_EXPERIMENT_KNOBS: the product library ignores the knob)
 # In-situ A/B of the GroupNorm apply block size: VCX_TUNE_EXP0=-1 (rule of rounds 1-3: >= 128 pixels per block) vs default (32 / 16).
 #   gpurun -- 'bash tools/gn_apply_ab.sh r04l'
 tag=${1:-rXX}

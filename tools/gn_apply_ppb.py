@@ -1,4 +1,4 @@
-"""GroupNorm apply pass: pixels per block (knob EXP0 in an experiment build of norm.hip; 0 = the shipped rule max(128, pixels / 1024)).
+"""GroupNorm apply pass: pixels per block (knob EXP0; needs norm.hip built with -DVCX_EXPERIMENT_KNOBS - the product ignores the knob; 0 = the shipped rule max(128, pixels / 1024)).
 The apply pass has no reduction, so its block size is free; the shipped value was inherited from the statistics kernel.
     python tools/gn_apply_ppb.py"""
 import os, sys, torch
