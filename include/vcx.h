@@ -285,8 +285,7 @@ int vcx_profile_end(double* out_host);
 #define VCX_TUNE_FLASH_IMPL 4      /* 0 auto | 1 phased v1 kernel | 2 software-pipelined v2 kernel           */
 #define VCX_TUNE_EXP0 5            /* free for one-off experiments (0)                                       */
 #define VCX_TUNE_EXP1 6
-#define VCX_TUNE_GEGLU_IMPL 7      /* 0 auto | 1 phased epilogue | 2 deferred epilogue wherever eligible | 3 its 16x16x32 form */
-#define VCX_TUNE_COUNT 8
+#define VCX_TUNE_COUNT 7
 int vcx_tune_set(int knob, int value);
 int vcx_tune_get(int knob);
 

@@ -43,9 +43,7 @@ def _soak(fn, calls, what):
 
 
 # variant -> (conv?, needs NF % 4 == 0 i.e. tile configs 0 / 2 only)
-# ("geglu" on the 256x256 tile is the deferred-epilogue kernel of gemm_geglu.hip since round 5; "geglu_phased" keeps the phased
-# instantiation of gemm_dma.hip, which K < 320 problems and the tail launches still reach, under the soak)
-VARIANTS = {"plain": (False, False), "f32": (False, False), "geglu": (False, True), "geglu_phased": (False, True), "lnfold": (False, False), "lnfold_geglu": (False, True),
+VARIANTS = {"plain": (False, False), "f32": (False, False), "geglu": (False, True), "lnfold": (False, False), "lnfold_geglu": (False, True),
             "lnfold_t": (False, False), "conv": (True, False), "conv_f32": (True, False), "conv_geglu": (True, True),
             "conv_colstats": (True, False)}
 
@@ -87,16 +85,9 @@ def test_every_dma_gemm_instantiation_is_bit_reproducible(cfg, variant):
             fn = lambda: ops.linear(x, w, bias, residual=res)
         elif variant == "f32":
             fn = lambda: ops.linear(x, w, bias, out_f32=True)
-        elif variant in ("geglu", "geglu_phased"):
+        elif variant == "geglu":
             wg, bg = pack_geglu(w, bias)
-            impl = 1 if variant == "geglu_phased" else 0
-
-            def fn():
-                p_ = ops.tune_set("GEGLU_IMPL", impl)
-                try:
-                    return ops.linear(x, wg, bg, geglu=True)
-                finally:
-                    ops.tune_set("GEGLU_IMPL", p_)
+            fn = lambda: ops.linear(x, wg, bg, geglu=True)
         elif variant in ("lnfold", "lnfold_geglu", "lnfold_t"):
             wf, colsum, bias_f = fold_layernorm(w32, gamma, beta, bias if variant != "lnfold_t" else None)
             st = ops.row_stats(x, 1e-5)

@@ -46,7 +46,6 @@ for r in range(rounds):
     for t in tunes:
         ops.tune_set("GEMM_CFG", int(t[3:]) if t.startswith("cfg") else -1)
         ops.tune_set("EXP0", int(t[3:]) if t.startswith("exp") else 0)
-        ops.tune_set("GEGLU_IMPL", int(t[5:]) if t.startswith("geglu") else 0)      # geglu1 = phased epilogue, geglu2 = deferred wherever eligible, geglu3 = its 16x16x32 form
         for i, (name, fn, fl) in enumerate(cases):
             res[t][i].append(timeit(fn, iters=6))
 med = lambda v: sorted(v)[len(v) // 2]

@@ -510,9 +510,6 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
             if (tiles >= 384) cfg = big_bn == 320 ? 3 : 2;
         }
         if (force >= 0 && !(geglu && (force == 1 || force == 3))) cfg = force;
-        // GEGLU_IMPL >= 2 (tests, A/B tools): the deferred-epilogue kernel wherever it is eligible, i.e. also on problems too small
-        // for the dispatcher to pick the 256 x 256 tile by itself
-        if (force < 0 && geglu && !conv && big_bn == 256 && d->K >= 5 * BK && vcx_tune(VCX_TUNE_GEGLU_IMPL) >= 2) cfg = 2;
         const int tbm = cfg >= 2 ? 256 : 128, tbn = cfg == 0 ? 128 : cfg == 1 ? 160 : cfg == 2 ? 256 : 320;
         a.tiles_m = (d->M + tbm - 1) / tbm;
         a.tiles_n = (d->N + tbn - 1) / tbn;

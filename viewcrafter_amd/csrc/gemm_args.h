@@ -110,7 +110,6 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
 }
 
 int persistent_grid(int ntiles, int blocks_per_cu = 2);
-int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);
-int launch_geglu_deferred(const GemmArgs& a, hipStream_t s);   // gemm_geglu.hip: 256 x 256 tile, linear GEGLU with BIAS_N at most, K >= 320   // a.flags & VCX_GEMM_LNFOLD[_T] selects the folded-LayerNorm epilogue
+int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);   // a.flags & VCX_GEMM_LNFOLD[_T] selects the folded-LayerNorm epilogue
 
 }  // namespace vcxgemm

@@ -316,11 +316,6 @@ int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) 
 }  // namespace
 
 int vcxgemm::launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s) {
-    // GEGLU projections on the 256 x 256 tile: the epilogue of a tile is finished under the MFMAs of the next one (gemm_geglu.hip)
-    // wherever that kernel's preconditions hold - a plain linear GEGLU (bias at most) with at least five K-steps
-    if (cfg == 2 && geglu && !conv && !f32 && a.K >= 5 * BK && vcx_tune(VCX_TUNE_GEGLU_IMPL) != 1 &&
-        !(a.flags & (VCX_GEMM_LNFOLD | VCX_GEMM_LNFOLD_T | VCX_GEMM_COLSTATS | VCX_GEMM_ROWADD | VCX_GEMM_RESIDUAL | VCX_GEMM_BIAS_M)))
-        return launch_geglu_deferred(a, s);
     switch (cfg) {
         case 0: return dispatch<TileCfg<128, 128, 2, 2>>(a, conv, geglu, f32, s);
         case 1: return dispatch<TileCfg<128, 160, 2, 2>>(a, conv, geglu, f32, s);
