@@ -127,6 +127,65 @@ def test_gemm_geglu(C):
     check(out, ref, name="geglu")
 
 
+@pytest.mark.parametrize("M,variant", [(10000, "bias+res"), (8192, "bias"), (16400 + 31, "plain"), (9216 * 3, "rowadd+res"), (460800, "bias+res")])
+def test_gemm_weight_stationary_320_matches_the_tiled_engine(M, variant):
+    """csrc/gemm_ws.hip (N = K = 320: the weight lives in the register file, 64-row activation tiles stream through a three-deep
+    LDS ring) against fp32 and against the tiled engine (knob GEMM_WS = 0): same MFMA shape, same K order, same epilogue code -
+    the same bits.  Ragged M, one to many tiles per block, guard band of a padded output."""
+    from viewcrafter_amd import ops
+    N = K = 320
+    x = rnd(M, K, seed=141).to(DEV).half()
+    w = (rnd(N, K, seed=142) / math.sqrt(K)).to(DEV).half()
+    b = rnd(N, seed=143).to(DEV) if variant != "plain" else None
+    res = rnd(M, N, seed=144).to(DEV).half() if "res" in variant else None
+    ra = rnd(3, N, seed=145).to(DEV) if "rowadd" in variant else None
+    kw = dict(residual=res, rowadd=ra, rowadd_div=9216 if ra is not None else 0)
+    outs = {}
+    for ws in (1, 0):
+        prev = ops.tune_set("GEMM_WS", ws)
+        try:
+            outs[ws] = ops.linear(x, w, b, **kw)
+            torch.cuda.synchronize()
+        finally:
+            ops.tune_set("GEMM_WS", prev)
+    if M <= 30000:
+        ref = x.float() @ w.float().t()
+        if b is not None:
+            ref = ref + b
+        if ra is not None:
+            ref = ref + ra.repeat_interleave(9216, 0)
+        if res is not None:
+            ref = ref + res.float()
+        check(outs[1], ref, name=f"ws320 {variant}")
+    assert torch.equal(outs[1], outs[0]), f"weight-stationary and tiled results differ in {int((outs[1] != outs[0]).sum())} elements"
+    big = torch.full((M + 5, N + 8), 3.0, device=DEV, dtype=torch.float16)
+    ops.gemm(x, w, M=M, N=N, K=K, lda=K, out=big, ldc=N + 8, bias=b, residual=res, ldr=N if res is not None else None, rowadd=ra,
+             rowadd_div=9216 if ra is not None else 0)
+    torch.cuda.synchronize()
+    assert torch.equal(big[:M, :N], outs[1]) and bool((big[M:] == 3.0).all()) and bool((big[:, N:] == 3.0).all())
+
+
+def test_gemm_weight_stationary_320_column_moments():
+    """The COLSTATS epilogue on the weight-stationary kernel: data and (mean, M2) strips identical to the tiled engine's."""
+    from viewcrafter_amd import ops
+    M, N, K = 9216 * 2, 320, 320
+    x = (rnd(M, K, seed=151) + 0.5).to(DEV).half()
+    w = (rnd(N, K, seed=152) / math.sqrt(K)).to(DEV).half()
+    b = rnd(N, seed=153).to(DEV)
+    res = rnd(M, N, seed=154).to(DEV).half()
+    got = {}
+    for ws in (1, 0):
+        prev = ops.tune_set("GEMM_WS", ws)
+        try:
+            cs = ops.colstats_buffer(M, N, DEV)
+            y = ops.linear(x, w, b, residual=res, colstats=cs)
+            torch.cuda.synchronize()
+            got[ws] = (y, cs)
+        finally:
+            ops.tune_set("GEMM_WS", prev)
+    assert torch.equal(got[1][0], got[0][0]) and torch.equal(got[1][1], got[0][1])
+
+
 # ---------------------------------------------------------------- convolutions
 def conv_ref(x_nhwc, w, b, stride=1, padding=1):
     y = F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w.float(), b, stride=stride, padding=padding)

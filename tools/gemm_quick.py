@@ -32,7 +32,7 @@ def tconv(C, P, T=25, B=2):
 
 conv(320, 72, 128); conv(640, 36, 64); conv(1280, 18, 32); conv(640, 36, 64, ups=1)
 tconv(320, 9216); tconv(1280, 576)
-lin(460800, 320, 320, res=True); lin(460800, 960, 320); lin(460800, 320, 1280, res=True)
+lin(460800, 320, 320, res=True); lin(460800, 320, 320); lin(460800, 960, 320); lin(460800, 320, 1280, res=True)
 lin(115200, 640, 640, res=True); lin(28800, 1280, 5120, res=True); lin(28800, 3840, 1280)
 geglu(460800, 320); geglu(115200, 640); geglu(28800, 1280)
 lin(28800, 1280, 1280, res=True); lin(115200, 640, 2560, res=True); lin(460800, 640, 320)
@@ -46,6 +46,7 @@ for r in range(rounds):
     for t in tunes:
         ops.tune_set("GEMM_CFG", int(t[3:]) if t.startswith("cfg") else -1)
         ops.tune_set("EXP0", int(t[3:]) if t.startswith("exp") else 0)
+        ops.tune_set("GEMM_WS", int(t[2:]) if t.startswith("ws") else 1)        # ws0 = tiled engine for the N = K = 320 layers too
         for i, (name, fn, fl) in enumerate(cases):
             res[t][i].append(timeit(fn, iters=6))
 med = lambda v: sorted(v)[len(v) // 2]

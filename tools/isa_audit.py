@@ -176,7 +176,7 @@ def audit_all(listing):
 # went out stale, in some runs).  No kernel of libvcx may contain that pattern.
 # ---------------------------------------------------------------------------------------------------------------------------
 CSRC = os.path.join(ROOT, "viewcrafter_amd", "csrc")
-LIB_SOURCES = ("gemm.hip", "gemm_dma.hip", "attention.hip", "attention_v2.hip", "norm.hip", "elementwise.hip")
+LIB_SOURCES = ("gemm.hip", "gemm_dma.hip", "gemm_ws.hip", "attention.hip", "attention_v2.hip", "norm.hip", "elementwise.hip")
 WIDE_STORES = ("ds_write_b128", "ds_write_b96", "ds_write2_b64", "ds_write2st64_b64", "buffer_store_dwordx4", "buffer_store_dwordx3",
                "global_store_dwordx4", "global_store_dwordx3", "flat_store_dwordx4", "flat_store_dwordx3")
 

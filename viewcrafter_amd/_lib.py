@@ -24,7 +24,7 @@ SYMBOLS = [
 ABI_VERSION = 5          # include/vcx.h VCX_ABI_VERSION
 # experiment knobs (include/vcx.h VCX_TUNE_*): name -> (index, default)
 TUNE = {"GEMM_CFG": (0, -1), "GEMM_DMA": (1, 1), "FLASH_QB": (2, 0), "XATTN_RESIDENT": (3, 1), "FLASH_IMPL": (4, 0), "EXP0": (5, 0),
-        "EXP1": (6, 0)}
+        "EXP1": (6, 0), "GEMM_WS": (7, 1)}
 GEMM_BIAS_N, GEMM_BIAS_M, GEMM_ROWADD, GEMM_RESIDUAL, GEMM_GEGLU, GEMM_OUT_F32, GEMM_CONV_SLABK = 1, 2, 4, 8, 16, 32, 64
 GEMM_LNFOLD, GEMM_LNFOLD_T, GEMM_COLSTATS = 0x80, 0x100, 0x200
 PROF_FAMILIES = ("gemm", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "elementwise")

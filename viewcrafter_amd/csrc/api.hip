@@ -55,7 +55,7 @@ extern "C" int vcx_device_arch(char* name_host, int len) {
 static std::atomic<int> g_tune[VCX_TUNE_COUNT];
 static std::once_flag g_tune_once;
 static const struct { const char* name; int dflt; } g_tune_def[VCX_TUNE_COUNT] = {
-    {"GEMM_CFG", -1}, {"GEMM_DMA", 1}, {"FLASH_QB", 0}, {"XATTN_RESIDENT", 1}, {"FLASH_IMPL", 0}, {"EXP0", 0}, {"EXP1", 0}};
+    {"GEMM_CFG", -1}, {"GEMM_DMA", 1}, {"FLASH_QB", 0}, {"XATTN_RESIDENT", 1}, {"FLASH_IMPL", 0}, {"EXP0", 0}, {"EXP1", 0}, {"GEMM_WS", 1}};
 
 static void tune_init() {
     for (int i = 0; i < VCX_TUNE_COUNT; ++i) {

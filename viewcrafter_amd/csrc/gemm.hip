@@ -394,6 +394,8 @@ int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) 
 
 }  // namespace
 
+static bool force_cfg_unset() { return vcx_tune(VCX_TUNE_GEMM_CFG) < 0; }      // a forced tile configuration (A/B tools, soak) means the tiled engine
+
 extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     VCX_REQUIRE(d != nullptr, "vcx_gemm_f16: null descriptor");
     // ABI 5: the caller states the size of the struct it filled in.  A binding written against another header version (the
@@ -500,6 +502,11 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.w_bytes = (unsigned)w_ext;
     a.c_bytes = (unsigned)c_ext;
     a.r_bytes = (unsigned)r_ext;
+    // Weight-stationary kernel (gemm_ws.hip) for the memory-bound N = K = 320 linear layers: the weight stays in the register file,
+    // only the activation rows stream.  From 128 tiles of 64 rows on (below that the tiled engine's small configuration is as good).
+    if (dma_ok && !conv && !geglu && !f32 && !lnf && d->N == 320 && d->K == 320 && d->M >= 8192 && !(flags & VCX_GEMM_BIAS_M) &&
+        vcx_tune(VCX_TUNE_GEMM_WS) != 0 && force_cfg_unset())
+        return launch_ws320(a, s);
     if (dma_ok) {
         // tile choice: the large (256-row, 8-wave) tiles halve the LDS traffic per MFMA but need >= ~1.5 waves of 256 tiles
         const int force = vcx_tune(VCX_TUNE_GEMM_CFG);      // -1 in production; tools/gemm_quick.py A/Bs tile configurations

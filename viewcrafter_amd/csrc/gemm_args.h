@@ -110,6 +110,7 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
 }
 
 int persistent_grid(int ntiles, int blocks_per_cu = 2);
-int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);   // a.flags & VCX_GEMM_LNFOLD[_T] selects the folded-LayerNorm epilogue
+int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);
+int launch_ws320(GemmArgs& a, hipStream_t s);        // gemm_ws.hip: weight-stationary linear layer, N = K = 320 (plain / COLSTATS epilogues)   // a.flags & VCX_GEMM_LNFOLD[_T] selects the folded-LayerNorm epilogue
 
 }  // namespace vcxgemm

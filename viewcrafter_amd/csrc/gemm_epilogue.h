@@ -8,15 +8,49 @@
 namespace vcxgemm {
 
 [[maybe_unused]] constexpr unsigned EPI_OOB = 0xFFFFFFFFu;
+typedef unsigned epi_u4v __attribute__((ext_vector_type(4)));
+
+// Residual pieces of a whole wave tile, fetched AHEAD of the tile's main loop (fp16 output, plain epilogue: the wide / narrow access
+// units of gemm_epilogue below, in its order i = b UNITS + u).  For a kernel that runs one wave per SIMD (gemm_ws.hip): a residual
+// load inside its epilogue is waited for with the whole vector-memory queue - output stores and operand DMA included - and nothing
+// else runs on the SIMD meanwhile; requested before the MFMAs, the pieces are there when the epilogue starts and the epilogue
+// issues stores only.  `gemm_epilogue<..., RPRE = true>` takes the array instead of fetching.
+template <class Cfg>
+__device__ __forceinline__ void gemm_epilogue_fetch_residual(const GemmArgs& p, int tile_m, int tile_n, int wm, int wn, int lane,
+                                                             epi_u4v (&out)[(Cfg::NF / 2 + Cfg::NF % 2) * Cfg::MF]) {
+    constexpr int WM = Cfg::TBM / Cfg::NWM, WN = Cfg::TBN / Cfg::NWN, NPAIRF = Cfg::NF / 2, UNITS = NPAIRF + Cfg::NF % 2;
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const int lr = lane & 15, lg = lane >> 4;
+    const unsigned odd = lg & 1, half = lg >> 1;
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.R), 0, (int)p.r_bytes, 0x00020000);
+    const int mbase = p.m_begin + tile_m * Cfg::TBM + wm * WM + lr;
+    const unsigned roff0 = ((unsigned)mbase * (unsigned)p.ldr + (unsigned)(tile_n * Cfg::TBN + wn * WN)) * 2u;
+    const unsigned rstep = 32u * (unsigned)p.ldr;
+#pragma unroll
+    for (int b = 0; b < Cfg::MF; ++b)
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int col = u < NPAIRF ? (2 * u + (int)odd) * 16 + (int)half * 8 : (2 * NPAIRF + (u - NPAIRF)) * 16 + lg * 4;
+            const unsigned o = roff0 + (unsigned)b * rstep + (unsigned)col * 2u;
+            if (u < NPAIRF) out[b * UNITS + u] = __builtin_amdgcn_raw_buffer_load_b128(srd_r, o, 0, 0);
+            else {
+                const u2v t = __builtin_amdgcn_raw_buffer_load_b64(srd_r, o, 0, 0);
+                const unsigned t0 = t[0], t1 = t[1];
+                out[b * UNITS + u] = epi_u4v{t0, t1, 0u, 0u};
+            }
+        }
+}
 
 // sB: the wave's private LDS strip of WN floats (column addends); sS: a second one, only allocated for LNF != 0.
 // LNF (folded LayerNorm, include/vcx.h VCX_GEMM_LNFOLD*): the accumulator holds x W'^T of the UN-normalised rows;
 //   LNF = 1  out = alpha rstd_m (acc - mean_m colsum_n) + bias'_n  = fma(acc, rb, fma(qb, colsum_n, bias'_n)),  rb = alpha rstd_m, qb = -rb mean_m
 //   LNF = 2  out = alpha rstd_n (acc - mean_n colsum_m) + bias'_m  = fma(acc, cs_n, fma(cq_n, colsum_m, bias'_m)), cs / cq in the two strips
-template <class Cfg, bool GEGLU, bool OUT_F32, int LNF = 0>
+template <class Cfg, bool GEGLU, bool OUT_F32, int LNF = 0, bool RPRE = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::NF][Cfg::MF], int tile_m, int tile_n, int wm, int wn,
                                               int lane, float* sB, [[maybe_unused]] float* sS = nullptr,
-                                              [[maybe_unused]] const float* ln_r0 = nullptr, [[maybe_unused]] const float* ln_r1 = nullptr) {
+                                              [[maybe_unused]] const float* ln_r0 = nullptr, [[maybe_unused]] const float* ln_r1 = nullptr,
+                                              [[maybe_unused]] const epi_u4v* rpre = nullptr,      // RPRE: gemm_epilogue_fetch_residual's pieces
+                                              bool strip_ready = false) {      // the strip(s) still hold THIS column tile's addends (a caller that walks rows only)
     // ln_r0 / ln_r1 [MFRAG]: per-lane row terms fetched by the caller ahead of the last K-step - LNF 1: (mean, rstd) of row
     // mbase + 16 b, LNF 2: (colsum, bias') of it
     constexpr int TBM = Cfg::TBM, BN = Cfg::TBN, NFRAG = Cfg::NF, MFRAG = Cfg::MF;
@@ -124,7 +158,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
         constexpr int NPAIRF = OUT_F32 ? 0 : NFRAG / 2;                 // fragment pairs handled wide (fp16 output only)
         constexpr int UNITS = NPAIRF + (NFRAG - 2 * NPAIRF);            // accesses per 16-row group
         constexpr int NUNIT = UNITS * MFRAG;
-        constexpr int RDU = UNITS;                                       // residual prefetch distance: one 16-row group
+        constexpr int RDU = RPRE ? NUNIT : UNITS;                        // residual prefetch distance: one 16-row group (RPRE: the caller fetched every piece)
         const unsigned odd = lg & 1, half = lg >> 1;
         // byte offset (within the row, relative to the wave's strip) of this lane's access for unit u
         auto unit_col = [&](int u) { return u < NPAIRF ? (2 * u + (int)odd) * 16 + (int)half * 8 : (2 * NPAIRF + (u - NPAIRF)) * 16 + lg * 4; };
@@ -146,13 +180,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
                 rr[i % RDU] = u4v{t0, t1, 0u, 0u};
             }
         };
-        if (has_res) {
+        if (RPRE) {
+#pragma unroll
+            for (int i = 0; i < RDU; ++i) rr[i] = rpre[i];
+        } else if (has_res) {
 #pragma unroll
             for (int i = 0; i < RDU; ++i) fetch(i);
         }
         // Column addends (bias, plus the tile's time-embedding row when it is uniform over the tile) live in a private
         // LDS strip of the wave, not in registers: a 160-column strip would pin 40 VGPRs through the whole epilogue.
-        if (lane < WN / 4) {
+        if (lane < WN / 4 && !strip_ready) {
             const int nc = min(nstrip + lane * 4, p.N - 4);
             if (LNF == 2) {         // per-column (alpha rstd_n, -alpha rstd_n mean_n)
                 const f4 s01 = *reinterpret_cast<const f4*>(p.ln_stats + 2 * nc), s23 = *reinterpret_cast<const f4*>(p.ln_stats + 2 * nc + 4);
