@@ -35,10 +35,14 @@ constexpr int WS_RING = 3;
 constexpr size_t WS_STRIP = (size_t)WsCfg::TBN * sizeof(float);
 constexpr size_t WS_SMEM = (size_t)WS_RING * WS_STAGE + 2 * WS_STRIP;
 
-template <int LNF>      // 0 plain epilogue, 3 VCX_GEMM_COLSTATS
+// MODE 0 / 1: the lean epilogue below without / with a residual (bias at most);  MODE 2: the shared epilogue of gemm_epilogue.h
+// (per-image addend);  MODE 3: the shared epilogue with VCX_GEMM_COLSTATS
+template <int MODE>
 __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs p, unsigned a_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MF = WsCfg::MF, NF = WsCfg::NF;
+    constexpr int LNF = MODE == 3 ? 3 : 0;
+    constexpr bool LEAN = MODE < 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
 
@@ -82,23 +86,43 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
     float* sB = reinterpret_cast<float*>(smem_raw + WS_RING * WS_STAGE) + wave * (NF * 16);      // the wave's strip of column addends
     float* sS = sB + WsCfg::TBN;
 
+    // ---- lean epilogue (MODE 0 / 1): the lane's bias pieces stay in registers for the whole kernel (the shared epilogue re-reads an LDS
+    // strip per 16-row group - with an exposed LDS round trip per fragment, which a 256-register kernel with a partner wave on its
+    // SIMD can afford and this one cannot: 3.9 us per tile, profiles/r05h_ws_ablate.txt)
+    [[maybe_unused]] f4 bv[NF];
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
+    if (LEAN) {
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+            bv[a] = (p.flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + wave * (NF * 16) + a * 16 + lg * 4) : f4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
+
     int t = blockIdx.x;
     if (t < ntiles) issue_tile(t, 0);
     if (t + G < ntiles) issue_tile(t + G, 1);
     for (int i = 0; t < ntiles; t += G, ++i) {
         const int buf = i % WS_RING;
         // The vector-memory counter retires in order.  Younger than this tile's ten pieces are: from the second iteration on the previous
-        // epilogue's >= 12 output stores, and - if there is a next tile - its ten pieces.  Waiting for all but 10 (+ 10) operations
-        // therefore covers this tile's pieces and leaves the next tile's, and most of the stores, in flight.
+        // epilogue's output stores - EXACTLY 12 buffer stores (two dwordx4 + one dwordx2 per 16-row group), plus 10 column-moment stores
+        // with COLSTATS (the ISA listing has them behind an execz branch that is never taken: lanes with lr = 0 exist in every wave
+        // and every tile of a COLSTATS launch is a whole 64-row strip) - and, if there is a next tile, its ten pieces.  The wait must
+        // leave ALL of those stores in flight: forcing even the two oldest to be acknowledged here costs their full write latency in
+        // every iteration - 3.7 us per tile, 70 % of the kernel's time, in the first version (profiles/r05g_ws_ablate.txt).
         __builtin_amdgcn_sched_barrier(0);
         {
+#if defined(VCX_WS_ABL) && (VCX_WS_ABL == 2 || VCX_WS_ABL == 3)
+            constexpr int S = 0;
+#else
+            constexpr int S = LNF == 3 ? 22 : 12;
+#endif
             const bool next_in_flight = t + G < ntiles;        // (issued in the prologue or at the end of the previous iteration)
             if (i == 0) {
                 if (next_in_flight) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-                if (next_in_flight) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S + 10) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
             }
         }
         __builtin_amdgcn_s_barrier();            // every wave's pieces have landed; every wave is done with the tile before last
@@ -106,7 +130,7 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
         const half_t* cx = reinterpret_cast<const half_t*>(smem_raw + buf * WS_STAGE);
         // the tile's residual pieces, requested ahead of the MFMAs: there when the epilogue starts (gemm_epilogue.h)
         epi_u4v rres[(NF / 2 + NF % 2) * MF];
-        if (p.flags & VCX_GEMM_RESIDUAL) gemm_epilogue_fetch_residual<WsCfg>(p, t, 0, 0, wave, lane, rres);
+        if (MODE == 1 || (!LEAN && (p.flags & VCX_GEMM_RESIDUAL))) gemm_epilogue_fetch_residual<WsCfg>(p, t, 0, 0, wave, lane, rres);
         f4 acc[NF][MF];
 #pragma unroll
         for (int a = 0; a < NF; ++a)
@@ -115,8 +139,12 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
         h8 xf[MF], xn[MF];
 #pragma unroll
         for (int b = 0; b < MF; ++b) xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(b * 16 + lr, lg));
+#if defined(VCX_WS_ABL) && VCX_WS_ABL == 1        // tools/ws_ablate.py: no MFMA work (timing only)
+        for (int kk = 0; kk < 0; ++kk) {
+#else
 #pragma unroll
         for (int kk = 0; kk < WS_KS; ++kk) {
+#endif
             if (kk + 1 < WS_KS) {
 #pragma unroll
                 for (int b = 0; b < MF; ++b)
@@ -129,8 +157,76 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
 #pragma unroll
             for (int b = 0; b < MF; ++b) xf[b] = xn[b];
         }
-        // (the bias strip is the same for every tile of this kernel: written by the first epilogue, kept - unless a per-image addend rides in it)
-        gemm_epilogue<WsCfg, false, false, LNF, true>(p, acc, t, 0, 0, wave, lane, sB, sS, nullptr, nullptr, rres, i > 0 && !(p.flags & VCX_GEMM_ROWADD));
+#if defined(VCX_WS_ABL) && VCX_WS_ABL == 2        // tools/ws_ablate.py: no epilogue (timing only; one store keeps the MFMAs alive)
+        if (acc[0][0][0] == 12345.678f) *reinterpret_cast<float*>(p.C) = acc[1][1][1] + acc[4][3][2];
+#else
+        if constexpr (LEAN) {
+            // Same arithmetic, access units and store order as the plain path of gemm_epilogue (fma(acc, alpha, bias), + residual, one
+            // fp16 rounding; fragment pairs widened to dwordx4 with v_permlane16_swap, the fifth fragment as dwordx2) - the same bits -
+            // without its run-time variants: no branches, no LDS, no loads.
+            typedef unsigned u2v __attribute__((ext_vector_type(2)));
+            constexpr int UNITS = NF / 2 + NF % 2;
+            const unsigned odd = lg & 1, half = lg >> 1;
+            const unsigned coff0 = ((unsigned)(p.m_begin + t * WsCfg::TBM + lr) * (unsigned)p.ldc + (unsigned)(wave * (NF * 16))) * 2u;
+            const unsigned cstep = 32u * (unsigned)p.ldc;
+            const float alpha = p.alpha;
+#pragma unroll
+            for (int b = 0; b < MF; ++b) {
+#pragma unroll
+                for (int u = 0; u < UNITS; ++u) {
+                    const bool wide = u < NF / 2;
+                    const int a = 2 * u;
+                    float v0[4], v1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v0[r] = __builtin_fmaf(acc[a][b][r], alpha, bv[a][r]);
+                        if (wide) v1[r] = __builtin_fmaf(acc[a + 1][b][r], alpha, bv[a + 1][r]);
+                    }
+                    if (MODE == 1) {
+                        const epi_u4v raw = rres[b * UNITS + u];
+                        unsigned w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
+                        if (wide) {
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(w0, w2, false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(w1, w3, false, false);
+                            w0 = s0[0]; w2 = s0[1]; w1 = s1[0]; w3 = s1[1];
+                        }
+                        const h4 r0 = __builtin_bit_cast(h4, u2v{w0, w1});
+                        const h4 r1 = __builtin_bit_cast(h4, u2v{w2, w3});
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v0[r] += (float)r0[r]; v1[r] += (float)r1[r]; }
+                    }
+                    // fp32 results first, THEN one fp16 rounding, as the shared epilogue does it: left alone hipcc fuses multiply-add and
+                    // conversion into v_fma_mixlo_f16 here, which rounds once instead of twice and differs from the tiled engine in
+                    // ~3 results per 100 000 (found by the bit-identity test)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v0[r]), "+v"(v1[r]));
+                    const u2v p0 = __builtin_bit_cast(u2v, h4{(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]});
+                    if (wide) {
+                        const u2v p1 = __builtin_bit_cast(u2v, h4{(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]});
+                        const unsigned a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1];
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                        const unsigned col = (2 * u + odd) * 16 + half * 8;
+#if defined(VCX_WS_ABL) && VCX_WS_ABL == 3        // tools/ws_ablate.py: the epilogue's arithmetic without its stores (timing only)
+                        if (s0[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(epi_u4v{s0[0], s1[0], s0[1], s1[1]}, srd_c, coff0 + (unsigned)b * cstep + col * 2u, 0, 0);
+#else
+                        __builtin_amdgcn_raw_buffer_store_b128(epi_u4v{s0[0], s1[0], s0[1], s1[1]}, srd_c, coff0 + (unsigned)b * cstep + col * 2u, 0, 0);
+#endif
+                    } else {
+                        const unsigned col = (unsigned)a * 16 + (unsigned)lg * 4;
+#if defined(VCX_WS_ABL) && VCX_WS_ABL == 3
+                        if (p0[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b64(p0, srd_c, coff0 + (unsigned)b * cstep + col * 2u, 0, 0);
+#else
+                        __builtin_amdgcn_raw_buffer_store_b64(p0, srd_c, coff0 + (unsigned)b * cstep + col * 2u, 0, 0);
+#endif
+                    }
+                }
+            }
+        } else {
+            // (the bias strip is the same for every tile of this kernel: written by the first epilogue, kept - unless a per-image addend rides in it)
+            gemm_epilogue<WsCfg, false, false, LNF, true>(p, acc, t, 0, 0, wave, lane, sB, sS, nullptr, nullptr, rres, i > 0 && !(p.flags & VCX_GEMM_ROWADD));
+        }
+#endif
         // the tile after next goes into the stage that the PREVIOUS tile used: every wave has passed this iteration's barrier, i.e. has
         // finished reading it.  Issued behind the epilogue's stores, so that the counts above hold.
         __builtin_amdgcn_sched_barrier(0);
@@ -140,10 +236,10 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
 #endif
 }
 
-template <int LNF>
+template <int MODE>
 int launch_ws(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
-    auto kern = gemm_ws320_kernel<LNF>;
+    auto kern = gemm_ws320_kernel<MODE>;
     if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WS_SMEM, "vcx_gemm_f16(ws320)")) return VCX_ELAUNCH;
     const int nb = persistent_grid(a.tiles_m, 1);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(WsCfg::THREADS), WS_SMEM, s, a, a.a_bytes);
@@ -157,5 +253,7 @@ int launch_ws(const GemmArgs& a, hipStream_t s) {
 int vcxgemm::launch_ws320(GemmArgs& a, hipStream_t s) {
     a.tiles_m = (a.M - a.m_begin + WsCfg::TBM - 1) / WsCfg::TBM;
     a.tiles_n = 1;
-    return (a.flags & VCX_GEMM_COLSTATS) ? launch_ws<3>(a, s) : launch_ws<0>(a, s);
+    if (a.flags & VCX_GEMM_COLSTATS) return launch_ws<3>(a, s);
+    if (a.flags & VCX_GEMM_ROWADD) return launch_ws<2>(a, s);
+    return (a.flags & VCX_GEMM_RESIDUAL) ? launch_ws<1>(a, s) : launch_ws<0>(a, s);
 }
