@@ -165,6 +165,38 @@ def test_gemm_weight_stationary_320_matches_the_tiled_engine(M, variant):
     assert torch.equal(big[:M, :N], outs[1]) and bool((big[M:] == 3.0).all()) and bool((big[:, N:] == 3.0).all())
 
 
+@pytest.mark.parametrize("M,N,alpha", [(9216 * 2, 960, 1.0), (20000 + 13, 640, 0.35), (460800, 960, 1.0)])
+def test_gemm_weight_stationary_wide_and_lnfold(M, N, alpha):
+    """N = 640 / 960 (two / three 320-column blocks per row tile, one per block of the same XCD) on the weight-stationary kernel:
+    plain + residual, and the LayerNorm-folded projection (VCX_GEMM_LNFOLD: row statistics fetched ahead of the MFMAs, row sums of the
+    folded weight in registers) - the same bits as the tiled engine, and the folded form against fp64 LayerNorm -> Linear."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import fold_layernorm
+    K = 320
+    x = (rnd(M, K, seed=161) * 2 + 0.4).to(DEV).half()
+    w32 = (rnd(N, K, seed=162) / math.sqrt(K)).to(DEV)
+    b = (0.2 * rnd(N, seed=163)).to(DEV)
+    res = rnd(M, N, seed=164).to(DEV).half()
+    gamma = (1 + 0.3 * rnd(K, seed=165)).to(DEV)
+    beta = (0.2 * rnd(K, seed=166)).to(DEV)
+    wf, colsum, bias_f = fold_layernorm(w32, gamma, beta, None)
+    st = ops.row_stats(x, 1e-5)
+    got = {}
+    for ws in (1, 0):
+        prev = ops.tune_set("GEMM_WS", ws)
+        try:
+            got[ws] = (ops.linear(x, w32.half(), b, residual=res), ops.linear(x, wf, alpha * bias_f + b, alpha=alpha, ln_stats=st, ln_colsum=colsum))
+            torch.cuda.synchronize()
+        finally:
+            ops.tune_set("GEMM_WS", prev)
+    for k, what in enumerate(("plain + residual", "LNFOLD")):
+        assert torch.equal(got[1][k], got[0][k]), f"{what}: weight-stationary and tiled results differ in {int((got[1][k] != got[0][k]).sum())} elements"
+    if M <= 30000:
+        check(got[1][0], x.float() @ w32.half().float().t() + b + res.float(), name="ws wide")
+        ref = alpha * _ln_linear_ref(x, gamma, beta, w32, None) + b.double()
+        assert rel_l2(got[1][1], ref) <= 1e-3
+
+
 def test_gemm_weight_stationary_320_column_moments():
     """The COLSTATS epilogue on the weight-stationary kernel: data and (mean, M2) strips identical to the tiled engine's."""
     from viewcrafter_amd import ops

@@ -1,6 +1,7 @@
-// Weight-stationary linear layer for N = K = 320 (level 0 of the UNet: attention output projections, SpatialTransformer /
-// TemporalTransformer proj_in / proj_out; /root/reference lvdm/modules/attention.py:61,209,268,319,338 at 576x1024: M = 460800 token
-// rows through a 320 x 320 weight, 36 launches per DDIM step).
+// Weight-stationary linear layer for K = 320 and N = 320 j (level 0 of the UNet: attention output projections, SpatialTransformer /
+// TemporalTransformer proj_in / proj_out, the LayerNorm-folded q|k and q|k|v projections; /root/reference
+// lvdm/modules/attention.py:61-63,209,268,319,338 at 576x1024: M = 460800 token rows through 320 x 320 weight blocks, 50 launches per
+// DDIM step).
 //
 // These layers are memory-bound: 0.6 KB in + 0.6 KB out (+ 0.6 KB residual) per row against 205 kFLOP, i.e. 0.16 ms of HBM time and
 // 0.04 ms of matrix time per call.  The tiled engine (gemm_dma.hip) runs them at 4.0 TB/s (0.223 ms): per 256-row tile it streams the
@@ -14,6 +15,10 @@
 // 1 KB per 200 MFMAs) and owns a 64 x 80 output strip, which goes through the shared epilogue of gemm_epilogue.h (bias, per-image
 // addend, residual, column moments for the GroupNorm behind - same accumulator layout as the tiled engine, so the results are the same
 // bits).  No weight traffic after the first 200 KB per CU, 5.7 us of memory time per tile against 1.9 us of matrix time.
+//
+// N = 320 j (j = 2, 3): a block owns ONE 320-column block of the weight for its lifetime; the j blocks that work on the same row tiles
+// sit on the same XCD (block id = 8 slot + xcd, slot = j stream + column block), so the activation tile comes from HBM once and
+// from that XCD's L2 for the others.
 #include "gemm_epilogue.h"
 
 using namespace vcxgemm;
@@ -36,18 +41,23 @@ constexpr size_t WS_STRIP = (size_t)WsCfg::TBN * sizeof(float);
 constexpr size_t WS_SMEM = (size_t)WS_RING * WS_STAGE + 2 * WS_STRIP;
 
 // MODE 0 / 1: the lean epilogue below without / with a residual (bias at most);  MODE 2: the shared epilogue of gemm_epilogue.h
-// (per-image addend);  MODE 3: the shared epilogue with VCX_GEMM_COLSTATS
+// (per-image addend);  MODE 3: the shared epilogue with VCX_GEMM_COLSTATS;  MODE 4: lean epilogue with VCX_GEMM_LNFOLD (+ bias)
 template <int MODE>
 __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs p, unsigned a_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MF = WsCfg::MF, NF = WsCfg::NF;
     constexpr int LNF = MODE == 3 ? 3 : 0;
-    constexpr bool LEAN = MODE < 2;
+    constexpr bool LEAN = MODE < 2 || MODE == 4;
+    constexpr bool FOLD = MODE == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
 
     const int ntiles = p.tiles_m;
-    const int G = gridDim.x;
+    // block id = 8 slot + xcd (blocks are dealt round-robin over the 8 XCDs); slot = tiles_n * (row stream of the XCD) + column block
+    const int cb = (blockIdx.x >> 3) % p.tiles_n;
+    const int G = gridDim.x / p.tiles_n;                                          // row streams: stream s walks tiles s, s + G, ...
+    const int t_first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) / p.tiles_n;
+    const int ncol0 = cb * WsCfg::TBN;                                            // first output column of the block
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -56,7 +66,7 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
     // ---- the wave's weight slice: A fragments of its 80 output columns (rows of W) for all K, straight from global memory, once
     h8 wf[NF][WS_KS];
     {
-        const half_t* wrow = p.W + (size_t)(wave * (NF * 16) + lr) * p.ldw + lg * 8;
+        const half_t* wrow = p.W + (size_t)(ncol0 + wave * (NF * 16) + lr) * p.ldw + lg * 8;
 #pragma unroll
         for (int a = 0; a < NF; ++a)
 #pragma unroll
@@ -89,16 +99,19 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
     // ---- lean epilogue (MODE 0 / 1): the lane's bias pieces stay in registers for the whole kernel (the shared epilogue re-reads an LDS
     // strip per 16-row group - with an exposed LDS round trip per fragment, which a 256-register kernel with a partner wave on its
     // SIMD can afford and this one cannot: 3.9 us per tile, profiles/r05h_ws_ablate.txt)
-    [[maybe_unused]] f4 bv[NF];
+    [[maybe_unused]] f4 bv[NF], cv[FOLD ? NF : 1];        // bias; MODE 4: the folded weight's row sums (VCX_GEMM_LNFOLD)
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
     if (LEAN) {
 #pragma unroll
-        for (int a = 0; a < NF; ++a)
-            bv[a] = (p.flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + wave * (NF * 16) + a * 16 + lg * 4) : f4{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < NF; ++a) {
+            const int n = ncol0 + wave * (NF * 16) + a * 16 + lg * 4;
+            bv[a] = (p.flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + n) : f4{0.f, 0.f, 0.f, 0.f};
+            if (FOLD) cv[a] = *reinterpret_cast<const f4*>(p.ln_colsum + n);
+        }
         __builtin_amdgcn_s_waitcnt(0x0f70);
     }
 
-    int t = blockIdx.x;
+    int t = t_first;
     if (t < ntiles) issue_tile(t, 0);
     if (t + G < ntiles) issue_tile(t + G, 1);
     for (int i = 0; t < ntiles; t += G, ++i) {
@@ -130,7 +143,14 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
         const half_t* cx = reinterpret_cast<const half_t*>(smem_raw + buf * WS_STAGE);
         // the tile's residual pieces, requested ahead of the MFMAs: there when the epilogue starts (gemm_epilogue.h)
         epi_u4v rres[(NF / 2 + NF % 2) * MF];
-        if (MODE == 1 || (!LEAN && (p.flags & VCX_GEMM_RESIDUAL))) gemm_epilogue_fetch_residual<WsCfg>(p, t, 0, 0, wave, lane, rres);
+        if (MODE == 1 || (!LEAN && (p.flags & VCX_GEMM_RESIDUAL))) gemm_epilogue_fetch_residual<WsCfg>(p, t, cb, 0, wave, lane, rres);
+        // MODE 4: (mean, rstd) of the lane's four rows, likewise ahead of the MFMAs
+        [[maybe_unused]] float2 lnst[FOLD ? MF : 1];
+        if (FOLD) {
+#pragma unroll
+            for (int b = 0; b < MF; ++b) lnst[b] = reinterpret_cast<const float2*>(p.ln_stats)[min(p.m_begin + t * WsCfg::TBM + b * 16 + lr, p.M - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);       // requested HERE: left to itself hipcc sinks these loads to their first use, the tail of the MFMA stream
         f4 acc[NF][MF];
 #pragma unroll
         for (int a = 0; a < NF; ++a)
@@ -167,11 +187,22 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
             typedef unsigned u2v __attribute__((ext_vector_type(2)));
             constexpr int UNITS = NF / 2 + NF % 2;
             const unsigned odd = lg & 1, half = lg >> 1;
-            const unsigned coff0 = ((unsigned)(p.m_begin + t * WsCfg::TBM + lr) * (unsigned)p.ldc + (unsigned)(wave * (NF * 16))) * 2u;
+            const unsigned coff0 = ((unsigned)(p.m_begin + t * WsCfg::TBM + lr) * (unsigned)p.ldc + (unsigned)(ncol0 + wave * (NF * 16))) * 2u;
             const unsigned cstep = 32u * (unsigned)p.ldc;
             const float alpha = p.alpha;
 #pragma unroll
             for (int b = 0; b < MF; ++b) {
+                // MODE 4 (gemm_epilogue's LNF = 1): out = alpha rstd_m (acc - mean_m colsum_n) + bias'_n = fma(acc, la, fma(lb, colsum_n, bias'_n)).
+                // The row terms enter as explicit (x, x) pairs behind an optimisation barrier, as there: hipcc must not build the packed
+                // multiply-adds with an op_sel half swap (tools/isa_audit.py).
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                [[maybe_unused]] f2v la = {0.f, 0.f}, lb = {0.f, 0.f};
+                if (FOLD) {
+                    const float ra = alpha * lnst[b].y, rb = -ra * lnst[b].x;
+                    la = f2v{ra, ra};
+                    lb = f2v{rb, rb};
+                    asm volatile("" : "+v"(la), "+v"(lb));
+                }
 #pragma unroll
                 for (int u = 0; u < UNITS; ++u) {
                     const bool wide = u < NF / 2;
@@ -179,8 +210,13 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
                     float v0[4], v1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        v0[r] = __builtin_fmaf(acc[a][b][r], alpha, bv[a][r]);
-                        if (wide) v1[r] = __builtin_fmaf(acc[a + 1][b][r], alpha, bv[a + 1][r]);
+                        if (FOLD) {
+                            v0[r] = __builtin_fmaf(acc[a][b][r], la[r & 1], __builtin_fmaf(lb[r & 1], cv[a][r], bv[a][r]));
+                            if (wide) v1[r] = __builtin_fmaf(acc[a + 1][b][r], la[r & 1], __builtin_fmaf(lb[r & 1], cv[a + 1][r], bv[a + 1][r]));
+                        } else {
+                            v0[r] = __builtin_fmaf(acc[a][b][r], alpha, bv[a][r]);
+                            if (wide) v1[r] = __builtin_fmaf(acc[a + 1][b][r], alpha, bv[a + 1][r]);
+                        }
                     }
                     if (MODE == 1) {
                         const epi_u4v raw = rres[b * UNITS + u];
@@ -224,7 +260,7 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
             }
         } else {
             // (the bias strip is the same for every tile of this kernel: written by the first epilogue, kept - unless a per-image addend rides in it)
-            gemm_epilogue<WsCfg, false, false, LNF, true>(p, acc, t, 0, 0, wave, lane, sB, sS, nullptr, nullptr, rres, i > 0 && !(p.flags & VCX_GEMM_ROWADD));
+            gemm_epilogue<WsCfg, false, false, LNF, true>(p, acc, t, cb, 0, wave, lane, sB, sS, nullptr, nullptr, rres, i > 0 && !(p.flags & VCX_GEMM_ROWADD));
         }
 #endif
         // the tile after next goes into the stage that the PREVIOUS tile used: every wave has passed this iteration's barrier, i.e. has
@@ -241,18 +277,25 @@ int launch_ws(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
     auto kern = gemm_ws320_kernel<MODE>;
     if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WS_SMEM, "vcx_gemm_f16(ws320)")) return VCX_ELAUNCH;
-    const int nb = persistent_grid(a.tiles_m, 1);
+    // 8 XCDs x (slots per XCD) blocks; a slot group = the tiles_n column blocks of one row stream.  Fewer streams than the chip
+    // has room for when the problem has fewer row tiles.
+    const int per_xcd = persistent_grid(1 << 30, 1) / 8;
+    int streams_per_xcd = per_xcd / a.tiles_n;
+    const int needed = (a.tiles_m + 7) / 8;
+    if (streams_per_xcd > needed) streams_per_xcd = needed;
+    const int nb = 8 * streams_per_xcd * a.tiles_n;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(WsCfg::THREADS), WS_SMEM, s, a, a.a_bytes);
     return vcx_check_launch("vcx_gemm_f16(ws320)");
 }
 
 }  // namespace
 
-// Linear mode, N = K = 320, fp16 output, no GEGLU / LNFOLD / BIAS_M, 32-bit operand and output extents (the caller checks; it also fills
-// a_bytes / c_bytes / r_bytes).  Sets the 64-row tiling itself.
+// Linear mode, K = 320, N = 320 j (j <= 4), fp16 output, no GEGLU / LNFOLD_T / BIAS_M, LNFOLD only without residual / addend / moments,
+// 32-bit operand and output extents (the caller checks; it also fills a_bytes / c_bytes / r_bytes).  Sets the tiling itself.
 int vcxgemm::launch_ws320(GemmArgs& a, hipStream_t s) {
     a.tiles_m = (a.M - a.m_begin + WsCfg::TBM - 1) / WsCfg::TBM;
-    a.tiles_n = 1;
+    a.tiles_n = a.N / WsCfg::TBN;
+    if (a.flags & VCX_GEMM_LNFOLD) return launch_ws<4>(a, s);
     if (a.flags & VCX_GEMM_COLSTATS) return launch_ws<3>(a, s);
     if (a.flags & VCX_GEMM_ROWADD) return launch_ws<2>(a, s);
     return (a.flags & VCX_GEMM_RESIDUAL) ? launch_ws<1>(a, s) : launch_ws<0>(a, s);
