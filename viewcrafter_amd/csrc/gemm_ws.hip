@@ -111,17 +111,33 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
         __builtin_amdgcn_s_waitcnt(0x0f70);
     }
 
+    // Residual pieces (MODE 1) / row statistics (MODE 4) of a tile are requested ONE TILE AHEAD, into registers: a request made at the
+    // top of the tile that needs it has ~1.5 us of MFMAs to arrive in and comes up short by a microsecond per tile (first version of
+    // MODE 4: 0.42-0.47 ms against 0.35 ms for the same layer without the fold)
+    constexpr bool AHEAD = MODE == 1 || MODE == 4;
+    constexpr int P = MODE == 1 ? (NF / 2 + NF % 2) * MF : MODE == 4 ? MF : 0;       // vector-memory operations of one such request
+    epi_u4v rres[(NF / 2 + NF % 2) * MF];
+    [[maybe_unused]] epi_u4v rnxt[AHEAD ? (NF / 2 + NF % 2) * MF : 1];
+    [[maybe_unused]] float2 lnst[FOLD ? MF : 1], lnxt[FOLD ? MF : 1];
+    auto fetch_stats = [&](int tt, float2 (&l)[FOLD ? MF : 1]) {
+#pragma unroll
+        for (int b = 0; b < (FOLD ? MF : 0); ++b)
+            l[b] = reinterpret_cast<const float2*>(p.ln_stats)[min(p.m_begin + tt * WsCfg::TBM + b * 16 + lr, p.M - 1)];
+    };
+
     int t = t_first;
     if (t < ntiles) issue_tile(t, 0);
     if (t + G < ntiles) issue_tile(t + G, 1);
+    if (MODE == 1 && t < ntiles) gemm_epilogue_fetch_residual<WsCfg>(p, t, cb, 0, wave, lane, rres);
+    if (MODE == 4 && t < ntiles) fetch_stats(t, lnst);
     for (int i = 0; t < ntiles; t += G, ++i) {
         const int buf = i % WS_RING;
-        // The vector-memory counter retires in order.  Younger than this tile's ten pieces are: from the second iteration on the previous
-        // epilogue's output stores - EXACTLY 12 buffer stores (two dwordx4 + one dwordx2 per 16-row group), plus 10 column-moment stores
-        // with COLSTATS (the ISA listing has them behind an execz branch that is never taken: lanes with lr = 0 exist in every wave
-        // and every tile of a COLSTATS launch is a whole 64-row strip) - and, if there is a next tile, its ten pieces.  The wait must
-        // leave ALL of those stores in flight: forcing even the two oldest to be acknowledged here costs their full write latency in
-        // every iteration - 3.7 us per tile, 70 % of the kernel's time, in the first version (profiles/r05g_ws_ablate.txt).
+        // The vector-memory counter retires in order.  Younger than this tile's ten pieces are: its own residual / statistics request
+        // (P operations, MODE 1 / 4), from the second iteration on the previous epilogue's output stores - EXACTLY 12 buffer stores
+        // (two dwordx4 + one dwordx2 per 16-row group), plus 10 column-moment stores with COLSTATS (the ISA listing has them behind
+        // an execz branch that is never taken: lanes with lr = 0 exist in every wave and every tile of a COLSTATS launch is a whole
+        // 64-row strip) - and, if there is a next tile, its ten pieces.  The wait must leave ALL of those in flight: forcing even the
+        // two oldest stores to be acknowledged here costs their full write latency in every iteration.
         __builtin_amdgcn_sched_barrier(0);
         {
 #if defined(VCX_WS_ABL) && (VCX_WS_ABL == 2 || VCX_WS_ABL == 3)
@@ -131,24 +147,23 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
 #endif
             const bool next_in_flight = t + G < ntiles;        // (issued in the prologue or at the end of the previous iteration)
             if (i == 0) {
-                if (next_in_flight) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + 10) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
             } else {
-                if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S + 10) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
+                if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + S + 10) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + S) : "memory");
             }
         }
         __builtin_amdgcn_s_barrier();            // every wave's pieces have landed; every wave is done with the tile before last
         __builtin_amdgcn_sched_barrier(0);
         const half_t* cx = reinterpret_cast<const half_t*>(smem_raw + buf * WS_STAGE);
-        // the tile's residual pieces, requested ahead of the MFMAs: there when the epilogue starts (gemm_epilogue.h)
-        epi_u4v rres[(NF / 2 + NF % 2) * MF];
-        if (MODE == 1 || (!LEAN && (p.flags & VCX_GEMM_RESIDUAL))) gemm_epilogue_fetch_residual<WsCfg>(p, t, cb, 0, wave, lane, rres);
-        // MODE 4: (mean, rstd) of the lane's four rows, likewise ahead of the MFMAs
-        [[maybe_unused]] float2 lnst[FOLD ? MF : 1];
-        if (FOLD) {
-#pragma unroll
-            for (int b = 0; b < MF; ++b) lnst[b] = reinterpret_cast<const float2*>(p.ln_stats)[min(p.m_begin + t * WsCfg::TBM + b * 16 + lr, p.M - 1)];
+        if constexpr (MODE == 1) {
+            if (t + G < ntiles) gemm_epilogue_fetch_residual<WsCfg>(p, t + G, cb, 0, wave, lane, rnxt);
+        } else if constexpr (MODE == 4) {
+            if (t + G < ntiles) fetch_stats(t + G, lnxt);
+        } else if (p.flags & VCX_GEMM_RESIDUAL) {
+            // (shared-epilogue modes: this tile's pieces, ahead of its MFMAs)
+            gemm_epilogue_fetch_residual<WsCfg>(p, t, cb, 0, wave, lane, rres);
         }
         __builtin_amdgcn_sched_barrier(0);       // requested HERE: left to itself hipcc sinks these loads to their first use, the tail of the MFMA stream
         f4 acc[NF][MF];
@@ -268,6 +283,14 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
         if (t + 2 * G < ntiles) issue_tile(t + 2 * G, (i + 2) % WS_RING);
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < (NF / 2 + NF % 2) * MF; ++k) rres[k] = rnxt[k];
+        }
+        if constexpr (MODE == 4) {
+#pragma unroll
+            for (int b = 0; b < MF; ++b) lnst[b] = lnxt[b];
+        }
     }
 #endif
 }
