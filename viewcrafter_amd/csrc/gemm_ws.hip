@@ -19,6 +19,8 @@
 // N = 320 j (j = 2, 3): a block owns ONE 320-column block of the weight for its lifetime; the j blocks that work on the same row tiles
 // sit on the same XCD (block id = 8 slot + xcd, slot = j stream + column block), so the activation tile comes from HBM once and
 // from that XCD's L2 for the others.
+#include <type_traits>
+#include <utility>
 #include "gemm_epilogue.h"
 
 using namespace vcxgemm;
@@ -27,6 +29,11 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 [[maybe_unused]] constexpr unsigned OOB = 0xFFFFFFFFu;
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_ws_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for_ws(F&& f) { static_for_ws_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct WsCfg {                      // the shape gemm_epilogue.h is instantiated for: one 64-row tile, four waves side by side
     static constexpr int TBM = 64, TBN = 320, NWM = 1, NWN = 4;
@@ -295,6 +302,222 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
 #endif
 }
 
+
+// =============================================================================================================================
+// The lean modes (bias at most, optional residual) once more, with the epilogue of tile i UNDER the MFMAs of tile i + 1.
+//
+// One wave per SIMD executes its tile serially: wait, 200 MFMAs, ~300 epilogue instructions, 12 stores - 3.9 us per 64-row tile, of
+// which the matrix pipe works 1.5 (tools/ws_ablate.py).  Nothing else is resident on the SIMD to fill the rest, so the wave overlaps with
+// itself: 32-row tiles (half the accumulators: 40 registers, so TWO sets fit beside the 200 weight registers), and while the MFMAs of
+// tile i fill one set, the other set - tile i - 1, complete - is finished unit by unit (two fragments x 16 rows: multiply-add, residual,
+// fp16 rounding, v_permlane16_swap, one store) in the same instruction stream, six units over the ten K slices.  This kernel has what
+// the deferred GEGLU epilogue of section 1 of profiles/r05_experiments.md lacked: a matrix pipe that is two thirds idle and an issue
+// port with nothing else to do.  Ring of five 20 KB stages, three tiles ahead; residual pieces requested when a tile's MFMAs start and
+// used one tile later.  The vector-memory wait at the top of a tile is computed, not assumed: the wave counts the operations it
+// issues, remembers the count behind each tile's DMA pieces, and waits for all but (issued - mark) - exact whatever the mode, the
+// position in the stream and the tail.
+// =============================================================================================================================
+struct WpCfg {                      // 32-row tile, four waves side by side (the shape gemm_epilogue_fetch_residual is instantiated for)
+    static constexpr int TBM = 32, TBN = 320, NWM = 1, NWN = 4;
+    static constexpr int THREADS = 256;
+    static constexpr int MF = TBM / NWM / 16, NF = TBN / NWN / 16;        // 2 x 5 accumulator fragments per wave
+};
+constexpr int WP_STAGE = WpCfg::TBM * WS_K * (int)sizeof(half_t);          // 20 KB: five [32 rows][64] slabs
+constexpr int WP_RING = 5, WP_AHEAD = 3;
+[[maybe_unused]] constexpr int WP_PIECES = WP_STAGE / 1024 / 4;            // LDS-DMA instructions per wave and tile (5)
+constexpr size_t WP_SMEM = (size_t)WP_RING * WP_STAGE;
+
+__device__ __forceinline__ void ws_wait_vmcnt(int n) {        // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the count is an immediate)
+    switch (n < 63 ? n : 63) {
+#define VCX_WS_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define VCX_WS_W8(k) VCX_WS_W(k) VCX_WS_W(k + 1) VCX_WS_W(k + 2) VCX_WS_W(k + 3) VCX_WS_W(k + 4) VCX_WS_W(k + 5) VCX_WS_W(k + 6) VCX_WS_W(k + 7)
+        VCX_WS_W8(0) VCX_WS_W8(8) VCX_WS_W8(16) VCX_WS_W8(24) VCX_WS_W8(32) VCX_WS_W8(40) VCX_WS_W8(48) VCX_WS_W8(56)
+#undef VCX_WS_W8
+#undef VCX_WS_W
+    }
+}
+
+template <int I> using WInt = std::integral_constant<int, I>;
+
+template <bool RES>
+__global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(GemmArgs p, unsigned a_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int MF = WpCfg::MF, NF = WpCfg::NF, UNITS = NF / 2 + NF % 2, NUNIT = UNITS * MF;
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
+
+    const int ntiles = p.tiles_m;
+    const int cb = (blockIdx.x >> 3) % p.tiles_n;
+    const int G = gridDim.x / p.tiles_n;
+    const int t_first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) / p.tiles_n;
+    const int ncol0 = cb * WpCfg::TBN;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    h8 wf[NF][WS_KS];
+    f4 bv[NF];
+    {
+        const half_t* wrow = p.W + (size_t)(ncol0 + wave * (NF * 16) + lr) * p.ldw + lg * 8;
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+#pragma unroll
+            for (int kk = 0; kk < WS_KS; ++kk) wf[a][kk] = *reinterpret_cast<const h8*>(wrow + (size_t)a * 16 * p.ldw + kk * 32);
+            bv[a] = (p.flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + ncol0 + wave * (NF * 16) + a * 16 + lg * 4) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);       // (with the builtin: hipcc's wait-count bookkeeping must see it - see gemm_ws320_kernel)
+    }
+
+    // LDS-DMA of one 32-row tile: 20 instructions of 8 rows x 128 bytes; wave w issues slab i = 0..4, rows 8 w .. 8 w + 7
+    const int drow = wave * 8 + (lane >> 3);
+    const unsigned dsrc = (unsigned)((lane & 7) ^ ((drow >> 1) & 7)) * 16u;
+    int issued = 0;                           // vector-memory operations this wave has issued so far (program order = retirement order)
+    int mark[WP_RING];                        // ... as of the last DMA piece of the tile in each stage
+    auto issue_tile = [&](int t, int buf) {
+        const int m0 = p.m_begin + t * WpCfg::TBM + drow;
+        const unsigned v = m0 < p.M ? (unsigned)m0 * (unsigned)p.lda * 2u + dsrc : OOB;
+        unsigned char* dst = smem_raw + buf * WP_STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < WP_PIECES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dst + i * 4096), 16, v, (unsigned)i * (BK * 2), 0, 0);
+        issued += WP_PIECES;
+        mark[buf] = issued;
+    };
+
+    f4 acc[2][NF][MF];
+    [[maybe_unused]] epi_u4v rr[2][RES ? NUNIT : 1];
+    unsigned coff[2] = {0u, 0u};              // byte offset of (lane's row in group 0, wave's first column) of the tile in each accumulator set
+    const unsigned odd = lg & 1, half = lg >> 1;
+    const unsigned cstep = 32u * (unsigned)p.ldc;
+    const float alpha = p.alpha;
+
+    // unit J = b UNITS + u of the tile held in accumulator set PAR: the arithmetic, access units and store order of the plain path of
+    // gemm_epilogue (and of gemm_ws320_kernel's lean epilogue) - the same bits
+    auto unit = [&](auto PAR_, auto J_) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value, J = decltype(J_)::value, b = J / UNITS, u = J % UNITS;
+        constexpr bool wide = u < NF / 2;
+        constexpr int a = 2 * u;
+        float v0[4], v1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v0[r] = __builtin_fmaf(acc[PAR][a][b][r], alpha, bv[a][r]);
+            if (wide) v1[r] = __builtin_fmaf(acc[PAR][wide ? a + 1 : a][b][r], alpha, bv[wide ? a + 1 : a][r]);
+        }
+        if constexpr (RES) {
+            const epi_u4v raw = rr[PAR][J];
+            unsigned w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
+            if (wide) {
+                const auto s0 = __builtin_amdgcn_permlane16_swap(w0, w2, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(w1, w3, false, false);
+                w0 = s0[0]; w2 = s0[1]; w1 = s1[0]; w3 = s1[1];
+            }
+            const h4 r0 = __builtin_bit_cast(h4, u2v{w0, w1});
+            const h4 r1 = __builtin_bit_cast(h4, u2v{w2, w3});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v0[r] += (float)r0[r]; v1[r] += (float)r1[r]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v0[r]), "+v"(v1[r]));      // fp32 first, then ONE fp16 rounding (no v_fma_mixlo_f16)
+        const u2v p0 = __builtin_bit_cast(u2v, h4{(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]});
+        if constexpr (wide) {
+            const u2v p1 = __builtin_bit_cast(u2v, h4{(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]});
+            const unsigned a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1];
+            const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+            const unsigned col = (2 * u + odd) * 16 + half * 8;
+            __builtin_amdgcn_raw_buffer_store_b128(epi_u4v{s0[0], s1[0], s0[1], s1[1]}, srd_c, coff[PAR] + (unsigned)b * cstep + col * 2u, 0, 0);
+        } else {
+            const unsigned col = (unsigned)a * 16 + (unsigned)lg * 4;
+            __builtin_amdgcn_raw_buffer_store_b64(p0, srd_c, coff[PAR] + (unsigned)b * cstep + col * 2u, 0, 0);
+        }
+        issued += 1;
+    };
+
+    // one tile: its MFMAs into accumulator set PAR; PEND: the other set holds a finished tile - its units ride along
+    auto tile = [&](auto PAR_, auto PEND_, int t, int i) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value;
+        constexpr bool PEND = decltype(PEND_)::value != 0;
+        const int buf = i % WP_RING;
+        __builtin_amdgcn_sched_barrier(0);
+        ws_wait_vmcnt(issued - mark[buf]);           // everything up to this tile's last DMA piece has retired
+        __builtin_amdgcn_s_barrier();                // ... for every wave; and every wave is done with the tiles before
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + WP_AHEAD * G < ntiles) issue_tile(t + WP_AHEAD * G, (i + WP_AHEAD) % WP_RING);      // into the stage of tile i - 2: long consumed
+        if constexpr (RES) {
+            gemm_epilogue_fetch_residual<WpCfg>(p, t, cb, 0, wave, lane, rr[PAR]);
+            issued += NUNIT;
+        }
+        coff[PAR] = ((unsigned)(p.m_begin + t * WpCfg::TBM + lr) * (unsigned)p.ldc + (unsigned)(ncol0 + wave * (NF * 16))) * 2u;
+        __builtin_amdgcn_sched_barrier(0);
+        const half_t* cx = reinterpret_cast<const half_t*>(smem_raw + buf * WP_STAGE);
+        h8 xf[MF], xn[MF];
+#pragma unroll
+        for (int b = 0; b < MF; ++b) xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(b * 16 + lr, lg));
+        static_for_ws<WS_KS>([&](auto KK_) __attribute__((always_inline)) {
+            constexpr int kk = decltype(KK_)::value;
+            if constexpr (kk + 1 < WS_KS) {
+#pragma unroll
+                for (int b = 0; b < MF; ++b)
+                    xn[b] = *reinterpret_cast<const h8*>(cx + ((kk + 1) >> 1) * (WpCfg::TBM * BK) + lds_off(b * 16 + lr, ((kk + 1) & 1) * 4 + lg));
+            }
+#pragma unroll
+            for (int a = 0; a < NF; ++a)
+#pragma unroll
+                for (int b = 0; b < MF; ++b) {
+                    if constexpr (kk == 0) acc[PAR][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a][kk], xf[b], f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    else acc[PAR][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a][kk], xf[b], acc[PAR][a][b], 0, 0, 0);
+                }
+            if constexpr (kk + 1 < WS_KS) {
+#pragma unroll
+                for (int b = 0; b < MF; ++b) xf[b] = xn[b];
+            }
+            // six units over ten K slices: slices 1, 2, 4, 5, 7, 8 (the first leaves the residual request of the PREVIOUS tile one more
+            // slice; the last keeps the stores clear of the barrier)
+            if constexpr (PEND && kk % 3 != 0 && kk < 9) unit(WInt<PAR ^ 1>{}, WInt<(kk / 3) * 2 + (kk % 3) - 1>{});
+        });
+    };
+
+    int t = t_first, i = 0;
+#pragma unroll
+    for (int k = 0; k < WP_AHEAD; ++k)
+        if (t + k * G < ntiles) issue_tile(t + k * G, k);
+    if (t < ntiles) {
+        tile(WInt<0>{}, WInt<0>{}, t, i);
+        t += G; ++i;
+        for (;;) {
+            if (t >= ntiles) {
+                static_for_ws<NUNIT>([&](auto J_) __attribute__((always_inline)) { unit(WInt<0>{}, J_); });
+                break;
+            }
+            tile(WInt<1>{}, WInt<1>{}, t, i);
+            t += G; ++i;
+            if (t >= ntiles) {
+                static_for_ws<NUNIT>([&](auto J_) __attribute__((always_inline)) { unit(WInt<1>{}, J_); });
+                break;
+            }
+            tile(WInt<0>{}, WInt<1>{}, t, i);
+            t += G; ++i;
+        }
+    }
+#endif
+}
+
+template <bool RES>
+int launch_ws_pipe(const GemmArgs& a, hipStream_t s) {
+    static VcxLdsAttr lds;
+    auto kern = gemm_ws320_pipe_kernel<RES>;
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WP_SMEM, "vcx_gemm_f16(ws320 pipe)")) return VCX_ELAUNCH;
+    const int per_xcd = persistent_grid(1 << 30, 1) / 8;
+    int streams_per_xcd = per_xcd / a.tiles_n;
+    const int needed = (a.tiles_m + 7) / 8;
+    if (streams_per_xcd > needed) streams_per_xcd = needed;
+    hipLaunchKernelGGL(kern, dim3(8 * streams_per_xcd * a.tiles_n), dim3(WpCfg::THREADS), WP_SMEM, s, a, a.a_bytes);
+    return vcx_check_launch("vcx_gemm_f16(ws320 pipe)");
+}
+
 template <int MODE>
 int launch_ws(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
@@ -321,5 +544,8 @@ int vcxgemm::launch_ws320(GemmArgs& a, hipStream_t s) {
     if (a.flags & VCX_GEMM_LNFOLD) return launch_ws<4>(a, s);
     if (a.flags & VCX_GEMM_COLSTATS) return launch_ws<3>(a, s);
     if (a.flags & VCX_GEMM_ROWADD) return launch_ws<2>(a, s);
-    return (a.flags & VCX_GEMM_RESIDUAL) ? launch_ws<1>(a, s) : launch_ws<0>(a, s);
+    if (vcx_tune(VCX_TUNE_GEMM_WS) == 3)       // A/B: the serial form of the lean modes
+        return (a.flags & VCX_GEMM_RESIDUAL) ? launch_ws<1>(a, s) : launch_ws<0>(a, s);
+    a.tiles_m = (a.M - a.m_begin + WpCfg::TBM - 1) / WpCfg::TBM;
+    return (a.flags & VCX_GEMM_RESIDUAL) ? launch_ws_pipe<true>(a, s) : launch_ws_pipe<false>(a, s);
 }
