@@ -182,10 +182,10 @@ def test_gemm_weight_stationary_wide_and_lnfold(M, N, alpha):
     wf, colsum, bias_f = fold_layernorm(w32, gamma, beta, None)
     st = ops.row_stats(x, 1e-5)
     got = {}
-    for ws in (2, 0):           # 2: the folded projection on the weight-stationary kernel as well (1, the default, leaves it to the tiled engine)
+    for ws in (1, 0):           # (the folded projection stays on the tiled engine under both settings: its leg checks exactly that)
         prev = ops.tune_set("GEMM_WS", ws)
         try:
-            got[min(ws, 1)] = (ops.linear(x, w32.half(), b, residual=res), ops.linear(x, wf, alpha * bias_f + b, alpha=alpha, ln_stats=st, ln_colsum=colsum))
+            got[ws] = (ops.linear(x, w32.half(), b, residual=res), ops.linear(x, wf, alpha * bias_f + b, alpha=alpha, ln_stats=st, ln_colsum=colsum))
             torch.cuda.synchronize()
         finally:
             ops.tune_set("GEMM_WS", prev)

@@ -23,6 +23,9 @@ def conv(C, h, w, n=50, ups=0, name=None):
 def lin(M, N, K, res=False, name=None):
     x = rh(M, K); wt = rh(N, K, sc=1 / math.sqrt(K)); b = torch.randn(N, device=dev); r = rh(M, N) if res else None
     cases.append((name or f"linear {M}x{N}x{K}{' +res' if res else ''}", lambda: ops.linear(x, wt, b, residual=r), 2 * M * N * K))
+def lin_cs(M, N, K):
+    x = rh(M, K); wt = rh(N, K, sc=1 / math.sqrt(K)); b = torch.randn(N, device=dev); r = rh(M, N); cs = ops.colstats_buffer(M, N, dev)
+    cases.append((f"linear {M}x{N}x{K} +res +colstats", lambda: ops.linear(x, wt, b, residual=r, colstats=cs), 2 * M * N * K))
 def lnf(M, N, K):
     from viewcrafter_amd.packing import fold_layernorm
     x = rh(M, K, sc=2.0); wf, cs, bf = fold_layernorm(torch.randn(N, K, device=dev) / math.sqrt(K), 1 + 0.3 * torch.randn(K, device=dev), 0.2 * torch.randn(K, device=dev), torch.randn(N, device=dev))
@@ -41,7 +44,7 @@ lin(460800, 320, 320, res=True); lin(460800, 320, 320); lin(460800, 960, 320); l
 lin(115200, 640, 640, res=True); lin(28800, 1280, 5120, res=True); lin(28800, 3840, 1280)
 geglu(460800, 320); geglu(115200, 640); geglu(28800, 1280)
 lin(28800, 1280, 1280, res=True); lin(115200, 640, 2560, res=True); lin(460800, 640, 320)
-lnf(460800, 960, 320); lnf(460800, 640, 320)
+lnf(460800, 960, 320); lnf(460800, 640, 320); lin_cs(460800, 320, 320)
 conv(1280, 9, 16); tconv(640, 2304)
 # A/B of dispatcher settings given on the command line, interleaved rounds, median and min.  Arguments: "auto" (the product),
 # cfgN = force tile configuration N (knob GEMM_CFG), expN = knob EXP0 set to N (whatever experiment the library was built with)

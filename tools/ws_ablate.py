@@ -1,4 +1,6 @@
-"""Where does a tile's time go in the weight-stationary kernel (csrc/gemm_ws.hip)?  Timing-only builds with parts removed
+"""Where does a tile's time go in the SERIAL form of the weight-stationary kernel (csrc/gemm_ws.hip, gemm_ws320_kernel - since the
+pipelined form took over the plain modes this tool drives the COLSTATS mode; the recorded runs, profiles/r05g-r05j_ws_ablate.txt, are of the
+plain modes of the serial form as of the commits before)?  Timing-only builds with parts removed
 (-DVCX_WS_ABL=n into tools/_abl/, never libvcx.so):  1 = no MFMA loop,  2 = no epilogue,  3 = the epilogue's arithmetic without its stores.
 
     python tools/ws_ablate.py build      (CPU)          python tools/ws_ablate.py      (GPU box; interleaved, same process)
@@ -8,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ABL = os.path.join(ROOT, "tools", "_abl")
 CSRC = os.path.join(ROOT, "viewcrafter_amd", "csrc")
-VARIANTS = {1: "no MFMA loop", 2: "no epilogue", 3: "epilogue without its stores"}
+VARIANTS = {1: "no MFMA loop", 2: "no epilogue"}
 
 
 def build():

@@ -504,12 +504,10 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.r_bytes = (unsigned)r_ext;
     // Weight-stationary kernel (gemm_ws.hip) for the memory-bound K = 320 linear layers of level 0 (N = 320, 640, 960): the weight stays
     // in the register file, only the activation rows stream.  From 128 tiles of 64 rows on (below that the tiled engine's small
-    // configuration is as good).  Not the LayerNorm-folded projections: their lean epilogue was built and measured 2-14 % SLOWER
-    // than the tiled engine (profiles/r05_experiments.md section 3), so they stay there.
-    const int ws_knob = vcx_tune(VCX_TUNE_GEMM_WS);           // 2 (A/B tools): the LayerNorm-folded projections as well
-    const bool ws_fold_ok = lnf == 1 && ws_knob == 2 && !(flags & (VCX_GEMM_RESIDUAL | VCX_GEMM_ROWADD | VCX_GEMM_COLSTATS));
-    if (dma_ok && !conv && !geglu && !f32 && (!lnf || ws_fold_ok) && d->K == 320 && d->N % 320 == 0 && d->N <= 1280 && d->M >= 8192 &&
-        !(flags & VCX_GEMM_BIAS_M) && ws_knob != 0 && force_cfg_unset())
+    // configuration is as good).  Not the LayerNorm-folded projections: a lean folded epilogue was built and measured level with the
+    // tiled engine (0.407 vs 0.416 ms; profiles/r05_experiments.md section 3), so they stay there.
+    if (dma_ok && !conv && !geglu && !f32 && !lnf && d->K == 320 && d->N % 320 == 0 && d->N <= 1280 && d->M >= 8192 &&
+        !(flags & VCX_GEMM_BIAS_M) && vcx_tune(VCX_TUNE_GEMM_WS) != 0 && force_cfg_unset())
         return launch_ws320(a, s);
     if (dma_ok) {
         // tile choice: the large (256-row, 8-wave) tiles halve the LDS traffic per MFMA but need >= ~1.5 waves of 256 tiles

@@ -1,20 +1,24 @@
 // Weight-stationary linear layer for K = 320 and N = 320 j (level 0 of the UNet: attention output projections, SpatialTransformer /
-// TemporalTransformer proj_in / proj_out, the LayerNorm-folded q|k and q|k|v projections; /root/reference
-// lvdm/modules/attention.py:61-63,209,268,319,338 at 576x1024: M = 460800 token rows through 320 x 320 weight blocks, 50 launches per
-// DDIM step).
+// TemporalTransformer proj_in / proj_out; /root/reference lvdm/modules/attention.py:61-63,209,268,319,338 at 576x1024: M = 460800 token
+// rows through a 320 x 320 weight block, 36 launches per DDIM step).
 //
-// These layers are memory-bound: 0.6 KB in + 0.6 KB out (+ 0.6 KB residual) per row against 205 kFLOP, i.e. 0.16 ms of HBM time and
-// 0.04 ms of matrix time per call.  The tiled engine (gemm_dma.hip) runs them at 4.0 TB/s (0.223 ms): per 256-row tile it streams the
-// activation rows AND a 200 KB weight slice through LDS (55 % of its DMA bytes are weights it has fetched 1800 times before), its
-// K-steps are paced by the LDS-DMA stream, and all 256 CUs alternate in lock step between a read phase and a write burst.
+// These layers are memory-bound: 0.6 KB in + 0.6 KB out (+ 0.6 KB residual) per row against 205 kFLOP, i.e. 0.10-0.14 ms of HBM time and
+// 0.04 ms of matrix time per call.  The tiled engine (gemm_dma.hip) runs them in 0.152 / 0.226 ms (without / with residual): per 256-row
+// tile it streams the activation rows AND a 200 KB weight slice through LDS (55 % of its DMA bytes are weights it has fetched 1800 times
+// before), its K-steps are paced by the LDS-DMA stream, and all 256 CUs alternate in lock step between a read phase and a write burst.
 //
 // MI355X-first alternative: a CU's register file is 512 KB - the whole 320 x 320 fp16 weight (200 KB) fits in it.  One block of four
 // waves per CU (one per SIMD, 512 registers each); wave w keeps the MFMA A fragments of output columns 80 w .. 80 w + 79 for all ten
-// 32-deep K slices in 200 registers for the lifetime of the block.  Only the activation rows move: 64-row tiles (40 KB) through a
-// three-deep LDS ring by LDS-DMA, two tiles ahead, ONE barrier per tile; every wave reads the tile's B fragments from LDS (40 reads of
-// 1 KB per 200 MFMAs) and owns a 64 x 80 output strip, which goes through the shared epilogue of gemm_epilogue.h (bias, per-image
-// addend, residual, column moments for the GroupNorm behind - same accumulator layout as the tiled engine, so the results are the same
-// bits).  No weight traffic after the first 200 KB per CU, 5.7 us of memory time per tile against 1.9 us of matrix time.
+// 32-deep K slices in 200 registers for the lifetime of the block.  Only the activation rows move, as small tiles through an LDS ring
+// filled by LDS-DMA several tiles ahead, ONE barrier per tile; every wave reads the tile's B fragments from LDS and owns an 80-column
+// output strip.  Same MFMA shape, K order, epilogue arithmetic and access units as the tiled engine: the same bits
+// (tests/test_kernels_gpu.py::test_gemm_weight_stationary_*).  Measured (profiles/r05o_ws_pipe_ab.txt, r05m_ws_bench_ab.txt): 0.131 / 0.170 ms
+// in isolation, GEMM family -1.5 ms and step -1.35 ms in the benchmark.
+//
+//   gemm_ws320_pipe_kernel   bias / residual (32 launches per step): 32-row tiles, two accumulator sets - the finished tile's outputs are
+//                            formed and stored inside the next tile's MFMA stream
+//   gemm_ws320_kernel        per-image addend or column moments (VCX_GEMM_ROWADD / COLSTATS: the shared epilogue of gemm_epilogue.h),
+//                            64-row tiles, tile after tile
 //
 // N = 320 j (j = 2, 3): a block owns ONE 320-column block of the weight for its lifetime; the j blocks that work on the same row tiles
 // sit on the same XCD (block id = 8 slot + xcd, slot = j stream + column block), so the activation tile comes from HBM once and
@@ -38,7 +42,7 @@ __device__ __forceinline__ void static_for_ws(F&& f) { static_for_ws_impl(f, std
 struct WsCfg {                      // the shape gemm_epilogue.h is instantiated for: one 64-row tile, four waves side by side
     static constexpr int TBM = 64, TBN = 320, NWM = 1, NWN = 4;
     static constexpr int THREADS = 256;
-    static constexpr int MF = TBM / NWM / 16, NF = TBN / NWN / 16;        // 4 x 5 accumulator fragments per wave
+    [[maybe_unused]] static constexpr int MF = TBM / NWM / 16, NF = TBN / NWN / 16;        // 4 x 5 accumulator fragments per wave
 };
 [[maybe_unused]] constexpr int WS_K = 320, WS_KS = WS_K / 32;                               // ten 32-deep K slices
 constexpr int WS_STAGE = WsCfg::TBM * WS_K * (int)sizeof(half_t);          // 40 KB
@@ -47,15 +51,13 @@ constexpr int WS_RING = 3;
 constexpr size_t WS_STRIP = (size_t)WsCfg::TBN * sizeof(float);
 constexpr size_t WS_SMEM = (size_t)WS_RING * WS_STAGE + 2 * WS_STRIP;
 
-// MODE 0 / 1: the lean epilogue below without / with a residual (bias at most);  MODE 2: the shared epilogue of gemm_epilogue.h
-// (per-image addend);  MODE 3: the shared epilogue with VCX_GEMM_COLSTATS;  MODE 4: lean epilogue with VCX_GEMM_LNFOLD (+ bias)
+// Serial form, for the epilogues that only gemm_epilogue.h implements.  MODE 2: per-image addend (VCX_GEMM_ROWADD);  MODE 3: column
+// moments (VCX_GEMM_COLSTATS).  The plain modes (bias, residual) run on gemm_ws320_pipe_kernel below.
 template <int MODE>
 __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs p, unsigned a_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MF = WsCfg::MF, NF = WsCfg::NF;
     constexpr int LNF = MODE == 3 ? 3 : 0;
-    constexpr bool LEAN = MODE < 2 || MODE == 4;
-    constexpr bool FOLD = MODE == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
 
@@ -103,51 +105,23 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
     float* sB = reinterpret_cast<float*>(smem_raw + WS_RING * WS_STAGE) + wave * (NF * 16);      // the wave's strip of column addends
     float* sS = sB + WsCfg::TBN;
 
-    // ---- lean epilogue (MODE 0 / 1): the lane's bias pieces stay in registers for the whole kernel (the shared epilogue re-reads an LDS
-    // strip per 16-row group - with an exposed LDS round trip per fragment, which a 256-register kernel with a partner wave on its
-    // SIMD can afford and this one cannot: 3.9 us per tile, profiles/r05h_ws_ablate.txt)
-    [[maybe_unused]] f4 bv[NF], cv[FOLD ? NF : 1];        // bias; MODE 4: the folded weight's row sums (VCX_GEMM_LNFOLD)
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
-    if (LEAN) {
-#pragma unroll
-        for (int a = 0; a < NF; ++a) {
-            const int n = ncol0 + wave * (NF * 16) + a * 16 + lg * 4;
-            bv[a] = (p.flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + n) : f4{0.f, 0.f, 0.f, 0.f};
-            if (FOLD) cv[a] = *reinterpret_cast<const f4*>(p.ln_colsum + n);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-    }
-
-    // Residual pieces (MODE 1) / row statistics (MODE 4) of a tile are requested ONE TILE AHEAD, into registers: a request made at the
-    // top of the tile that needs it has ~1.5 us of MFMAs to arrive in and comes up short by a microsecond per tile (first version of
-    // MODE 4: 0.42-0.47 ms against 0.35 ms for the same layer without the fold)
-    constexpr bool AHEAD = MODE == 1 || MODE == 4;
-    constexpr int P = MODE == 1 ? (NF / 2 + NF % 2) * MF : MODE == 4 ? MF : 0;       // vector-memory operations of one such request
+    constexpr int P = 0;          // (no vector-memory request of this tile is older than the wait at its top: see the pipelined kernel for the general count)
     epi_u4v rres[(NF / 2 + NF % 2) * MF];
-    [[maybe_unused]] epi_u4v rnxt[AHEAD ? (NF / 2 + NF % 2) * MF : 1];
-    [[maybe_unused]] float2 lnst[FOLD ? MF : 1], lnxt[FOLD ? MF : 1];
-    auto fetch_stats = [&](int tt, float2 (&l)[FOLD ? MF : 1]) {
-#pragma unroll
-        for (int b = 0; b < (FOLD ? MF : 0); ++b)
-            l[b] = reinterpret_cast<const float2*>(p.ln_stats)[min(p.m_begin + tt * WsCfg::TBM + b * 16 + lr, p.M - 1)];
-    };
 
     int t = t_first;
     if (t < ntiles) issue_tile(t, 0);
     if (t + G < ntiles) issue_tile(t + G, 1);
-    if (MODE == 1 && t < ntiles) gemm_epilogue_fetch_residual<WsCfg>(p, t, cb, 0, wave, lane, rres);
-    if (MODE == 4 && t < ntiles) fetch_stats(t, lnst);
     for (int i = 0; t < ntiles; t += G, ++i) {
         const int buf = i % WS_RING;
-        // The vector-memory counter retires in order.  Younger than this tile's ten pieces are: its own residual / statistics request
-        // (P operations, MODE 1 / 4), from the second iteration on the previous epilogue's output stores - EXACTLY 12 buffer stores
+        // The vector-memory counter retires in order.  Younger than this tile's ten pieces are: from the second iteration on the previous
+        // epilogue's output stores - EXACTLY 12 buffer stores
         // (two dwordx4 + one dwordx2 per 16-row group), plus 10 column-moment stores with COLSTATS (the ISA listing has them behind
         // an execz branch that is never taken: lanes with lr = 0 exist in every wave and every tile of a COLSTATS launch is a whole
         // 64-row strip) - and, if there is a next tile, its ten pieces.  The wait must leave ALL of those in flight: forcing even the
         // two oldest stores to be acknowledged here costs their full write latency in every iteration.
         __builtin_amdgcn_sched_barrier(0);
         {
-#if defined(VCX_WS_ABL) && (VCX_WS_ABL == 2 || VCX_WS_ABL == 3)
+#if defined(VCX_WS_ABL) && VCX_WS_ABL == 2
             constexpr int S = 0;
 #else
             constexpr int S = LNF == 3 ? 22 : 12;
@@ -164,14 +138,8 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
         __builtin_amdgcn_s_barrier();            // every wave's pieces have landed; every wave is done with the tile before last
         __builtin_amdgcn_sched_barrier(0);
         const half_t* cx = reinterpret_cast<const half_t*>(smem_raw + buf * WS_STAGE);
-        if constexpr (MODE == 1) {
-            if (t + G < ntiles) gemm_epilogue_fetch_residual<WsCfg>(p, t + G, cb, 0, wave, lane, rnxt);
-        } else if constexpr (MODE == 4) {
-            if (t + G < ntiles) fetch_stats(t + G, lnxt);
-        } else if (p.flags & VCX_GEMM_RESIDUAL) {
-            // (shared-epilogue modes: this tile's pieces, ahead of its MFMAs)
-            gemm_epilogue_fetch_residual<WsCfg>(p, t, cb, 0, wave, lane, rres);
-        }
+        // this tile's residual pieces, requested ahead of its MFMAs: there when the epilogue starts (gemm_epilogue.h)
+        if (p.flags & VCX_GEMM_RESIDUAL) gemm_epilogue_fetch_residual<WsCfg>(p, t, cb, 0, wave, lane, rres);
         __builtin_amdgcn_sched_barrier(0);       // requested HERE: left to itself hipcc sinks these loads to their first use, the tail of the MFMA stream
         f4 acc[NF][MF];
 #pragma unroll
@@ -202,85 +170,7 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
 #if defined(VCX_WS_ABL) && VCX_WS_ABL == 2        // tools/ws_ablate.py: no epilogue (timing only; one store keeps the MFMAs alive)
         if (acc[0][0][0] == 12345.678f) *reinterpret_cast<float*>(p.C) = acc[1][1][1] + acc[4][3][2];
 #else
-        if constexpr (LEAN) {
-            // Same arithmetic, access units and store order as the plain path of gemm_epilogue (fma(acc, alpha, bias), + residual, one
-            // fp16 rounding; fragment pairs widened to dwordx4 with v_permlane16_swap, the fifth fragment as dwordx2) - the same bits -
-            // without its run-time variants: no branches, no LDS, no loads.
-            typedef unsigned u2v __attribute__((ext_vector_type(2)));
-            constexpr int UNITS = NF / 2 + NF % 2;
-            const unsigned odd = lg & 1, half = lg >> 1;
-            const unsigned coff0 = ((unsigned)(p.m_begin + t * WsCfg::TBM + lr) * (unsigned)p.ldc + (unsigned)(ncol0 + wave * (NF * 16))) * 2u;
-            const unsigned cstep = 32u * (unsigned)p.ldc;
-            const float alpha = p.alpha;
-#pragma unroll
-            for (int b = 0; b < MF; ++b) {
-                // MODE 4 (gemm_epilogue's LNF = 1): out = alpha rstd_m (acc - mean_m colsum_n) + bias'_n = fma(acc, la, fma(lb, colsum_n, bias'_n)).
-                // The row terms enter as explicit (x, x) pairs behind an optimisation barrier, as there: hipcc must not build the packed
-                // multiply-adds with an op_sel half swap (tools/isa_audit.py).
-                typedef float f2v __attribute__((ext_vector_type(2)));
-                [[maybe_unused]] f2v la = {0.f, 0.f}, lb = {0.f, 0.f};
-                if (FOLD) {
-                    const float ra = alpha * lnst[b].y, rb = -ra * lnst[b].x;
-                    la = f2v{ra, ra};
-                    lb = f2v{rb, rb};
-                    asm volatile("" : "+v"(la), "+v"(lb));
-                }
-#pragma unroll
-                for (int u = 0; u < UNITS; ++u) {
-                    const bool wide = u < NF / 2;
-                    const int a = 2 * u;
-                    float v0[4], v1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (FOLD) {
-                            v0[r] = __builtin_fmaf(acc[a][b][r], la[r & 1], __builtin_fmaf(lb[r & 1], cv[a][r], bv[a][r]));
-                            if (wide) v1[r] = __builtin_fmaf(acc[a + 1][b][r], la[r & 1], __builtin_fmaf(lb[r & 1], cv[a + 1][r], bv[a + 1][r]));
-                        } else {
-                            v0[r] = __builtin_fmaf(acc[a][b][r], alpha, bv[a][r]);
-                            if (wide) v1[r] = __builtin_fmaf(acc[a + 1][b][r], alpha, bv[a + 1][r]);
-                        }
-                    }
-                    if (MODE == 1) {
-                        const epi_u4v raw = rres[b * UNITS + u];
-                        unsigned w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
-                        if (wide) {
-                            const auto s0 = __builtin_amdgcn_permlane16_swap(w0, w2, false, false);
-                            const auto s1 = __builtin_amdgcn_permlane16_swap(w1, w3, false, false);
-                            w0 = s0[0]; w2 = s0[1]; w1 = s1[0]; w3 = s1[1];
-                        }
-                        const h4 r0 = __builtin_bit_cast(h4, u2v{w0, w1});
-                        const h4 r1 = __builtin_bit_cast(h4, u2v{w2, w3});
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { v0[r] += (float)r0[r]; v1[r] += (float)r1[r]; }
-                    }
-                    // fp32 results first, THEN one fp16 rounding, as the shared epilogue does it: left alone hipcc fuses multiply-add and
-                    // conversion into v_fma_mixlo_f16 here, which rounds once instead of twice and differs from the tiled engine in
-                    // ~3 results per 100 000 (found by the bit-identity test)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v0[r]), "+v"(v1[r]));
-                    const u2v p0 = __builtin_bit_cast(u2v, h4{(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]});
-                    if (wide) {
-                        const u2v p1 = __builtin_bit_cast(u2v, h4{(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]});
-                        const unsigned a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1];
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                        const unsigned col = (2 * u + odd) * 16 + half * 8;
-#if defined(VCX_WS_ABL) && VCX_WS_ABL == 3        // tools/ws_ablate.py: the epilogue's arithmetic without its stores (timing only)
-                        if (s0[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(epi_u4v{s0[0], s1[0], s0[1], s1[1]}, srd_c, coff0 + (unsigned)b * cstep + col * 2u, 0, 0);
-#else
-                        __builtin_amdgcn_raw_buffer_store_b128(epi_u4v{s0[0], s1[0], s0[1], s1[1]}, srd_c, coff0 + (unsigned)b * cstep + col * 2u, 0, 0);
-#endif
-                    } else {
-                        const unsigned col = (unsigned)a * 16 + (unsigned)lg * 4;
-#if defined(VCX_WS_ABL) && VCX_WS_ABL == 3
-                        if (p0[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b64(p0, srd_c, coff0 + (unsigned)b * cstep + col * 2u, 0, 0);
-#else
-                        __builtin_amdgcn_raw_buffer_store_b64(p0, srd_c, coff0 + (unsigned)b * cstep + col * 2u, 0, 0);
-#endif
-                    }
-                }
-            }
-        } else {
+        {
             // (the bias strip is the same for every tile of this kernel: written by the first epilogue, kept - unless a per-image addend rides in it)
             gemm_epilogue<WsCfg, false, false, LNF, true>(p, acc, t, cb, 0, wave, lane, sB, sS, nullptr, nullptr, rres, i > 0 && !(p.flags & VCX_GEMM_ROWADD));
         }
@@ -290,14 +180,6 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
         if (t + 2 * G < ntiles) issue_tile(t + 2 * G, (i + 2) % WS_RING);
-        if constexpr (MODE == 1) {
-#pragma unroll
-            for (int k = 0; k < (NF / 2 + NF % 2) * MF; ++k) rres[k] = rnxt[k];
-        }
-        if constexpr (MODE == 4) {
-#pragma unroll
-            for (int b = 0; b < MF; ++b) lnst[b] = lnxt[b];
-        }
     }
 #endif
 }
@@ -320,10 +202,10 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
 struct WpCfg {                      // 32-row tile, four waves side by side (the shape gemm_epilogue_fetch_residual is instantiated for)
     static constexpr int TBM = 32, TBN = 320, NWM = 1, NWN = 4;
     static constexpr int THREADS = 256;
-    static constexpr int MF = TBM / NWM / 16, NF = TBN / NWN / 16;        // 2 x 5 accumulator fragments per wave
+    [[maybe_unused]] static constexpr int MF = TBM / NWM / 16, NF = TBN / NWN / 16;        // 2 x 5 accumulator fragments per wave
 };
 constexpr int WP_STAGE = WpCfg::TBM * WS_K * (int)sizeof(half_t);          // 20 KB: five [32 rows][64] slabs
-constexpr int WP_RING = 5, WP_AHEAD = 3;
+[[maybe_unused]] constexpr int WP_RING = 5, WP_AHEAD = 3;
 [[maybe_unused]] constexpr int WP_PIECES = WP_STAGE / 1024 / 4;            // LDS-DMA instructions per wave and tile (5)
 constexpr size_t WP_SMEM = (size_t)WP_RING * WP_STAGE;
 
@@ -536,16 +418,13 @@ int launch_ws(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// Linear mode, K = 320, N = 320 j (j <= 4), fp16 output, no GEGLU / LNFOLD_T / BIAS_M, LNFOLD only without residual / addend / moments,
+// Linear mode, K = 320, N = 320 j (j <= 4), fp16 output, no GEGLU / LNFOLD / LNFOLD_T / BIAS_M,
 // 32-bit operand and output extents (the caller checks; it also fills a_bytes / c_bytes / r_bytes).  Sets the tiling itself.
 int vcxgemm::launch_ws320(GemmArgs& a, hipStream_t s) {
     a.tiles_m = (a.M - a.m_begin + WsCfg::TBM - 1) / WsCfg::TBM;
     a.tiles_n = a.N / WsCfg::TBN;
-    if (a.flags & VCX_GEMM_LNFOLD) return launch_ws<4>(a, s);
     if (a.flags & VCX_GEMM_COLSTATS) return launch_ws<3>(a, s);
     if (a.flags & VCX_GEMM_ROWADD) return launch_ws<2>(a, s);
-    if (vcx_tune(VCX_TUNE_GEMM_WS) == 3)       // A/B: the serial form of the lean modes
-        return (a.flags & VCX_GEMM_RESIDUAL) ? launch_ws<1>(a, s) : launch_ws<0>(a, s);
     a.tiles_m = (a.M - a.m_begin + WpCfg::TBM - 1) / WpCfg::TBM;
     return (a.flags & VCX_GEMM_RESIDUAL) ? launch_ws_pipe<true>(a, s) : launch_ws_pipe<false>(a, s);
 }
