@@ -36,7 +36,7 @@ extern "C" {
  * vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32.  5: vcx_gemm_desc starts with
  * struct_size - a descriptor of another layout is rejected instead of read past its end; ldcs; vcx_clip_preprocess_f32,
  * vcx_add_nchw_f32_to_nhwc_f16. */
-#define VCX_ABI_VERSION 5
+#define VCX_ABI_VERSION 6
 
 int vcx_abi_version(void);
 const char* vcx_last_error(void);
@@ -248,17 +248,20 @@ int vcx_nthwc_to_ncthw_f32(const void* src, float* dst, int B, int C, int T, int
  *   { sqrt_acp_t, sqrt_1m_acp_t, a_prev, sigma_t, scale_ratio(prev/t), cfg_scale,
  *     guidance_rescale, parameterization_is_v }.
  * v_uncond may be NULL (no guidance).  noise may be NULL when sigma_t == 0.
- * ws: device workspace of 8192*B bytes (per-block fp64 partial sums, reduced in fixed order), 8-byte aligned.
+ * ws / ws_bytes: device workspace (per-block fp64 partial sums, reduced in fixed order), 8-byte aligned, at least
+ * vcx_ddim_ws_bytes(B, n) bytes - the callee checks the size it is told (ABI 6; never more than 8192 * B).
  * ---------------------------------------------------------------------------------- */
+size_t vcx_ddim_ws_bytes(int B, int64_t n);
 int vcx_ddim_step_f32(const float* x, const float* v_cond, const float* v_uncond,
-                      const float* noise, float* x_prev, float* pred_x0, void* ws, int B,
-                      int64_t n, const float* coef_host, void* stream);
+                      const float* noise, float* x_prev, float* pred_x0, void* ws,
+                      size_t ws_bytes, int B, int64_t n, const float* coef_host, void* stream);
 /* Multi-condition guidance (lvdm/models/samplers/ddim_multiplecond.py:220-236, `--multiple_cond_cfg`): v_img is the
  * prediction under (empty text, image) conditioning and coef_host[8] = cfg_img:
  *   v = v_uncond + cfg_img (v_img - v_uncond) + cfg (v_cond - v_img).  v_img == NULL reduces to vcx_ddim_step_f32. */
 int vcx_ddim_step3_f32(const float* x, const float* v_cond, const float* v_uncond,
                        const float* v_img, const float* noise, float* x_prev, float* pred_x0,
-                       void* ws, int B, int64_t n, const float* coef_host, void* stream);
+                       void* ws, size_t ws_bytes, int B, int64_t n, const float* coef_host,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Lightweight per-kernel-family profiling with HIP events (used by bench.py to fill

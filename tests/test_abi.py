@@ -177,3 +177,19 @@ def test_product_build_reads_no_scratch_knob_on_a_launch_path():
             if re.search(r"vcx_tune\(\s*VCX_TUNE_EXP[01]\s*\)", t) and all(active for _, active in stack):
                 offenders.append(f"{name}:{ln}: {t}")
     assert not offenders, offenders
+
+
+def test_ddim_workspace_contract():
+    """ABI 6: every entry point that takes a workspace has a size query and is TOLD the size it gets.  The DDIM step
+    refuses a workspace smaller than vcx_ddim_ws_bytes(B, n) - checked ahead of any launch, so this runs without a GPU."""
+    import ctypes
+    from viewcrafter_amd import _lib
+    L = _lib.lib()
+    n = 4 * 25 * 72 * 128
+    need = L.vcx_ddim_ws_bytes(2, n)
+    assert 0 < need <= 8192 * 2 and need % 8 == 0 and L.vcx_ddim_ws_bytes(0, n) == 0
+    assert L.vcx_ddim_ws_bytes(1, 100) == 32            # one block, four fp64 partial sums
+    coef = (ctypes.c_float * 9)(*([0.5] * 9))
+    fake = 1 << 20                                      # never dereferenced: the size check comes first
+    rc = L.vcx_ddim_step3_f32(fake, fake, fake, None, None, fake, fake, fake, need - 8, 2, n, coef, None)
+    assert rc == -1 and b"vcx_ddim_ws_bytes" in L.vcx_last_error()          # VCX_EINVAL

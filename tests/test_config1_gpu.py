@@ -14,7 +14,8 @@
   * the same through the multi-condition sampler (`--multiple_cond_cfg --cfg_img 3`, ddim_multiplecond.py:220-236) at 25x40x64,
     BASELINE configs[1]'s latent (the shared image-token branch, 3 evaluations per step).
 
-Stated tolerance: forward rel-L2 <= 5e-3; decoded clip rel-L2 <= 3e-2 and PSNR >= 30 dB after 5 eta = 1 steps.
+Stated tolerance: forward rel-L2 <= 5e-3; decoded clip rel-L2 <= 3e-2 and PSNR >= 30 dB after 5 eta = 1 steps.  The ASSERTIONS sit at
+~2x the values measured on the MI355X (4.4e-3 / 58.7 dB, 3.6e-3 / 60.7 dB), not at the stated tolerance: a regression must fail them.
 """
 import os
 
@@ -147,7 +148,7 @@ def test_inference_main_five_steps_at_config1_vs_the_reference_driver(full_512, 
           f"image_guided_synthesis / DDIMSampler / UNetModel / AutoencoderKL (fp32, same draws): rel-L2 {e:.3e}, PSNR {p:.1f} dB; "
           f"{ref_calls} Gaussian draws on both sides")
     torch.cuda.empty_cache()
-    assert e <= 3e-2 and p >= 30.0
+    assert e <= 9e-3 and p >= 52.0        # measured 4.4e-3 / 58.7 dB (profiles/r04p_gpu_pytest.log): ~2x, so that a 2x regression fails
 
 
 def test_multicond_sampler_at_25x40x64_vs_the_reference_driver(full_512):
@@ -171,4 +172,4 @@ def test_multicond_sampler_at_25x40x64_vs_the_reference_driver(full_512):
     print(f"\n[multi-condition CFG, 320x512x25, 3 steps, cfg 7.5 / cfg_img 3, full width] decoded clip vs the reference's own driver + "
           f"ddim_multiplecond sampler (fp32, same draws): rel-L2 {e:.3e}, PSNR {p:.1f} dB")
     torch.cuda.empty_cache()
-    assert e <= 3e-2 and p >= 30.0
+    assert e <= 7.5e-3 and p >= 54.0      # measured 3.6e-3 / 60.7 dB: ~2x

@@ -62,7 +62,7 @@ def test_image_guided_synthesis_vs_reference_golden(igs_model, tag, kw, monkeypa
     sub = vid[..., ::4, ::4]
     e, p = rel_l2(sub, ref), psnr(sub, ref)
     print(f"image_guided_synthesis[{tag}]: decoded video rel-L2 vs the reference's own run = {e:.3e}, PSNR {p:.1f} dB")
-    assert e <= 3e-2 and p >= 30.0
+    assert e <= 1.5e-2 and p >= 46.5      # measured 7.4e-3 / 52.7 dB (cfg), 4.1e-3 / 57.9 dB (multicond): ~2x the larger
     if kw["n_samples"] == 2:
         assert not torch.equal(vid[:, 0], vid[:, 1])          # two variants, two noise streams
 

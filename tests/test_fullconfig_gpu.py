@@ -34,7 +34,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-FWD_TOL, DEC_TOL, TRAJ_TOL = 5e-3, 8e-3, 1e-2
+FWD_TOL, DEC_TOL, TRAJ_TOL = 5e-3, 8e-3, 7e-3      # trajectories: measured 2.3e-3 ... 3.5e-3 (stated tolerance 1e-2); ~2x the largest
+PSNR_MIN = 53.0                                     # decoded frames: measured 59.4 ... 62.1 dB (stated 30 dB); 6 dB = 2x the error
 _MODELS = {}
 
 
@@ -185,7 +186,7 @@ def test_ddim_trajectory_vs_fp32_oracle_on_gpu(tag, yaml_name, T, h, w, steps):
           f"(first pred_x0 {e_first:.3e}); decoded frames PSNR {p:.1f} dB")
     torch.cuda.empty_cache()
     assert e <= TRAJ_TOL
-    assert p >= 30.0
+    assert p >= PSNR_MIN
 
 
 def test_vae_encode_576x1024_vs_fp32_oracle_on_gpu():
@@ -437,4 +438,4 @@ def test_ddim_trajectory_vs_the_reference_sampler_itself_at_576x1024x25():
     del ref_model
     torch.cuda.empty_cache()
     assert e_oracle <= 1e-4
-    assert e_hip <= TRAJ_TOL and p >= 30.0
+    assert e_hip <= TRAJ_TOL and p >= PSNR_MIN

@@ -20,7 +20,7 @@ DEV = "cuda"
 
 UNET_TOL = 5e-3
 VAE_TOL = 8e-3
-DDIM_TOL = 3e-2
+DDIM_TOL = 1.6e-2      # measured 5.4e-3 (eta 0), 8.1e-3 (eta 1), 5.6e-3 (multi-cond): 2x the largest (stated tolerance 3e-2)
 
 
 @pytest.fixture(scope="module")
@@ -337,7 +337,7 @@ def test_ddim_trajectory_vs_reference_golden(model, eta):
             dec = model.decode_first_stage(samples)
         p = psnr(dec[..., ::4, ::4], g["decode_first_stage_sub4"])
         print(f"decoded frames PSNR vs reference = {p:.1f} dB")
-        assert p >= 30.0
+        assert p >= 48.0           # measured 54.8 dB
 
 
 def test_sampler_decode_walks_the_same_trajectory_as_ddim_sampling(model):

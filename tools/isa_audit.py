@@ -228,14 +228,32 @@ def store_data_hazards(listing):
 
 def audit_library_store_hazards():
     out = []
-    for name in LIB_SOURCES:
-        tmp = os.path.join(tempfile.mkdtemp(prefix="vcx_isa_"), name + ".s")
-        flags = FLAGS if name == "attention_v2.hip" else [f for f in FLAGS if f != "-fno-slp-vectorize"]
-        r = subprocess.run([HIPCC] + flags + ["-I", os.path.join(ROOT, "include"), "-o", tmp, os.path.join(CSRC, name)], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc failed on " + name + ":\n" + r.stderr[-2000:])
-        out += [(name,) + h for h in store_data_hazards(open(tmp).read())]
+    with tempfile.TemporaryDirectory(prefix="vcx_isa_") as tmpdir:
+        for name in LIB_SOURCES:
+            tmp = os.path.join(tmpdir, name + ".s")
+            flags = makefile_flags(name)
+            r = subprocess.run([HIPCC] + flags + ["-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", tmp, os.path.join(CSRC, name)],
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed on " + name + ":\n" + r.stderr[-2000:])
+            out += [(name,) + h for h in store_data_hazards(open(tmp).read())]
     return out
+
+
+def makefile_flags(name):
+    """The compile flags libvcx.so is built with, read from csrc/Makefile (CXXFLAGS plus the per-object additions), so that the audited
+    listing is the code that ships (a hand-copied flag list can drift)."""
+    flags, extra = None, []
+    for line in open(os.path.join(CSRC, "Makefile")):
+        m = re.match(r"CXXFLAGS\s*:=\s*(.*)", line)
+        if m:
+            flags = m.group(1).replace("$(ARCH)", "gfx950").split()
+        m = re.match(r"build/(\w+)\.o:\s*CXXFLAGS\s*\+=\s*(.*)", line)
+        if m and m.group(1) + ".hip" == name:
+            extra += m.group(2).split()
+    if flags is None:
+        raise RuntimeError("no CXXFLAGS in csrc/Makefile")
+    return [f for f in flags if f not in ("-Wall", "-Wno-unused-function")] + extra
 
 
 def main():

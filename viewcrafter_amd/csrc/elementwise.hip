@@ -367,9 +367,13 @@ extern "C" int vcx_nthwc_to_ncthw_f32(const void* src, float* dst, int B, int C,
     return vcx_check_launch("vcx_nthwc_to_ncthw_f32");
 }
 
+extern "C" size_t vcx_ddim_ws_bytes(int B, int64_t n) {        // four fp64 partial sums per block of the reduction grid
+    return B > 0 && n > 0 ? (size_t)32 * grid_for(n, 256) * (size_t)B : 0;
+}
+
 extern "C" int vcx_ddim_step_f32(const float* x, const float* v_cond, const float* v_uncond, const float* noise,
-                                 float* x_prev, float* pred_x0, void* ws, int B, int64_t n, const float* coef_host,
-                                 void* stream) {
+                                 float* x_prev, float* pred_x0, void* ws, size_t ws_bytes, int B, int64_t n,
+                                 const float* coef_host, void* stream) {
     float c9[9];
     if (!coef_host) {
         vcx_set_error("vcx_ddim_step_f32: null pointer");
@@ -377,16 +381,18 @@ extern "C" int vcx_ddim_step_f32(const float* x, const float* v_cond, const floa
     }
     for (int i = 0; i < 8; ++i) c9[i] = coef_host[i];
     c9[8] = 0.f;
-    return vcx_ddim_step3_f32(x, v_cond, v_uncond, nullptr, noise, x_prev, pred_x0, ws, B, n, c9, stream);
+    return vcx_ddim_step3_f32(x, v_cond, v_uncond, nullptr, noise, x_prev, pred_x0, ws, ws_bytes, B, n, c9, stream);
 }
 
 extern "C" int vcx_ddim_step3_f32(const float* x, const float* v_cond, const float* v_uncond, const float* v_img,
-                                  const float* noise, float* x_prev, float* pred_x0, void* ws, int B, int64_t n,
-                                  const float* coef_host, void* stream) {
+                                  const float* noise, float* x_prev, float* pred_x0, void* ws, size_t ws_bytes, int B,
+                                  int64_t n, const float* coef_host, void* stream) {
     VCX_REQUIRE(x && v_cond && x_prev && pred_x0 && ws && coef_host, "vcx_ddim_step_f32: null pointer");
     VCX_REQUIRE(!v_img || v_uncond, "vcx_ddim_step3_f32: v_img needs v_uncond");
     VCX_REQUIRE(B > 0 && B <= 65535 && n > 1, "vcx_ddim_step_f32: bad sizes");
     VCX_REQUIRE(((uintptr_t)ws & 7) == 0, "vcx_ddim_step_f32: ws must be 8-byte aligned");
+    VCX_REQUIRE(ws_bytes >= vcx_ddim_ws_bytes(B, n), "vcx_ddim_step_f32: workspace of %zu bytes, vcx_ddim_ws_bytes(%d, %lld) = %zu", ws_bytes, B,
+                (long long)n, vcx_ddim_ws_bytes(B, n));
     DdimCoef k;
     const float a_prev = coef_host[2], sigma = coef_host[3];
     k.sqrt_acp = coef_host[0];

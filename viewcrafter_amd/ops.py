@@ -169,7 +169,9 @@ def colstats_ok(M, pixels, cin, cout, in_rows=None):
     column moments for a GroupNorm whose statistics span `pixels` consecutive output rows?  (VCX_GEMM_COLSTATS: DMA kernel -
     cin % 64 == 0, cout % 8 == 0, 32-bit byte offsets - whole 64-row strips per statistics unit.)"""
     lim = 0xFFFF0000
-    return (pixels % 64 == 0 and M % 64 == 0 and cin % 64 == 0 and cout % 8 == 0 and 2 * (M + 256) * cout < lim
+    # (a mirror of the kernel-side test in vcx_gemm_f16, like lnfold_ok: with the DMA kernel switched off by the A/B knob the producers
+    # fall back to a statistics pass instead of asking for an epilogue that kernel does not have - ADVICE r4)
+    return (tune_get("GEMM_DMA") != 0 and pixels % 64 == 0 and M % 64 == 0 and cin % 64 == 0 and cout % 8 == 0 and 2 * (M + 256) * cout < lim
             and 2 * (in_rows if in_rows is not None else M) * cin < lim)
 
 
@@ -180,6 +182,10 @@ def colstats_buffer(M, cout, device):
 def group_norm_stats_from_colstats(colstats, n_outer, pixels, C, groups=32):
     """(mean, variance) per (n, group) from the column moments a colstats= convolution wrote: what group_norm(stats=) takes."""
     _dev32(colstats)
+    # the moments travel across module boundaries (flow.py, concat targets): a buffer that does not hold exactly the strips of this
+    # tensor would be read out of bounds or give silently wrong statistics (ADVICE r4)
+    if pixels % 64 != 0 or colstats.numel() != (n_outer * pixels // 64) * C * 2:
+        raise VcxError(f"colstats must hold [{n_outer} x {pixels} / 64, {C}, 2] floats with pixels % 64 == 0, got {tuple(colstats.shape)}")
     stats = torch.empty((n_outer, groups, 2), dtype=_f32, device=colstats.device)
     L = lib()
     ws = torch.empty((L.vcx_groupnorm_ws_bytes(n_outer, pixels, groups),), dtype=torch.uint8, device=colstats.device)
@@ -386,10 +392,11 @@ def ddim_step(x, v_cond, v_uncond, noise, coef, ws=None, v_img=None, cfg_img=0.0
     x_prev = torch.empty_like(x)
     pred_x0 = torch.empty_like(x)
     if ws is None:
-        ws = torch.empty((1024 * B,), dtype=torch.float64, device=x.device)
+        ws = torch.empty((lib().vcx_ddim_ws_bytes(B, n) // 8,), dtype=torch.float64, device=x.device)
     c = (ctypes.c_float * 9)(*([float(v) for v in coef[:8]] + [float(cfg_img)]))
     check(lib().vcx_ddim_step3_f32(x.data_ptr(), v_cond.data_ptr(), _ptr(v_uncond), _ptr(v_img), _ptr(noise),
-                                   x_prev.data_ptr(), pred_x0.data_ptr(), ws.data_ptr(), B, n, c, _stream()), "ddim_step")
+                                   x_prev.data_ptr(), pred_x0.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(), B, n, c,
+                                   _stream()), "ddim_step")
     return x_prev, pred_x0
 
 
