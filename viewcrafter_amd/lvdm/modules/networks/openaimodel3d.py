@@ -78,6 +78,19 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
         return x
 
 
+def _adapter_rows(feat, frames):
+    """Adapter maps for a tensor of `frames` frames under the shared guidance prefix: the caller may hand maps for the
+    un-replicated batch (b t frames: repeated where the r evaluations already flow as one batch) or for the replicated batch the
+    reference's forward sees (r b t frames, r identical copies: the first b t are taken while the prefix still runs un-replicated)."""
+    if feat.shape[0] == frames:
+        return feat
+    if frames % feat.shape[0] == 0:
+        return feat.repeat(frames // feat.shape[0], 1, 1, 1)
+    if feat.shape[0] % frames == 0:
+        return feat[:frames]
+    raise ValueError(f"features_adapter map of {feat.shape[0]} frames for a tensor of {frames} frames")
+
+
 def _out_channels_of(block):
     """channels of the tensor a TimestepEmbedSequential returns"""
     last = list(block)[-1]
@@ -550,10 +563,7 @@ class UNetModel(PackedModule):
                 h = module(h, emb, context=ckv, batch_size=cur_b, flow=flow)
             cs = flow.colstats
             if features_adapter is not None and (i + 1) % 3 == 0:      # plug-in adapter features (openaimodel3d.py:582-585)
-                feat = features_adapter[adapter_idx]
-                if feat.shape[0] * r == h.shape[0] and r > 1:           # given per un-replicated batch: the r evaluations share it
-                    feat = feat.repeat(r, 1, 1, 1)
-                h = ops.add_nchw_(h.contiguous(), feat)
+                h = ops.add_nchw_(h.contiguous(), _adapter_rows(features_adapter[adapter_idx], h.shape[0]))
                 adapter_idx, cs = adapter_idx + 1, None                 # the moments of h no longer describe it
             hs.append((h, cs))
         if features_adapter is not None and len(features_adapter) != adapter_idx:
