@@ -544,6 +544,41 @@ def main():
                                       "sec_per_50_steps": 50 * dt, "reference_published_sec_per_video_a100": published[name]}
                 del x2, cond2, uc2
             sampler._cfg_cache = None
+            # Two clips per GPU on two HIP streams (viewcrafter_amd/interleave.py; what ViewCrafter.run_diffusion_many does with a rank's
+            # clips): 2 x 3 DDIM steps of the headline workload one clip after the other, then interleaved step by step - aggregate rate
+            # of both clips.  A throughput mode for several trajectories per GPU; `value` above is ONE trajectory per GPU.
+            from viewcrafter_amd.interleave import run_interleaved, step_yield
+            xa, conda, uca = synth_conditioning(T, h, w, device, seed=123)
+            xb = torch.randn_like(xa)
+
+            def clip(xx, index, nsteps=3):
+                smp = DDIMSampler(model)
+                smp.make_schedule(ddim_num_steps=50, ddim_discretize="uniform_trailing", ddim_eta=1.0, verbose=False)
+                smp.share_cfg_prefix = not args.no_shared_prefix
+                for i in range(nsteps):
+                    idx = n_sched - 1 - i
+                    ts = torch.full((1,), int(smp.ddim_timesteps[idx]), device=device, dtype=torch.long)
+                    xx, _ = smp.p_sample_ddim(xx, conda, ts, index=idx, unconditional_guidance_scale=7.5, unconditional_conditioning=uca, fs=fs,
+                                              guidance_rescale=0.7, cfg_img=None, unconditional_conditioning_img_nonetext=None)
+                    step_yield()
+                return xx
+            with torch.no_grad():
+                res = {}
+                for lanes in (1, 2, 1, 2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    outs2 = run_interleaved(clip, [(0, xa), (1, xb)], n_lanes=lanes)
+                    torch.cuda.synchronize()
+                    res.setdefault(lanes, []).append(time.perf_counter() - t0)
+                    assert all(torch.isfinite(o).all() for o in outs2)
+            seq, two = min(res[1]), min(res[2])
+            out["extra"]["two_clips_per_gpu"] = {
+                "workload": args.workload, "ddim_steps_per_clip": 3, "clips": 2,
+                "one_after_the_other_steps_per_s": 6 / seq, "two_streams_steps_per_s": 6 / two, "gain": seq / two,
+                "note": "aggregate DDIM steps/s of two independent trajectories on one GPU; interleaved step by step on two HIP streams "
+                        "(bit-identical outputs: tests/test_entry_gpu.py::test_two_clips_per_gpu_on_two_streams_equal_the_plain_loop); "
+                        "the headline `value` stays one trajectory per GPU"}
+            del xa, xb
         from viewcrafter_amd.config import load_yaml
         mp_ = load_yaml(os.path.join(ROOT, "configs", cfg_name))["model"]["params"]
         hp = dict(mp_["unet_config"]["params"])

@@ -67,6 +67,34 @@ def test_image_guided_synthesis_vs_reference_golden(igs_model, tag, kw, monkeypa
         assert not torch.equal(vid[:, 0], vid[:, 1])          # two variants, two noise streams
 
 
+def test_two_clips_per_gpu_on_two_streams_equal_the_plain_loop(igs_model):
+    """viewcrafter_amd/interleave.py through parallel.run_sharded: three clips, two in flight at a time on their own HIP streams with the
+    baton handed on after every DDIM step (eta = 1: a Gaussian draw per step and clip), against the same clips one after the other -
+    bit-identical videos, the same generator state afterwards."""
+    from tests.tiny_config import IGS_H, IGS_T, IGS_W
+    from viewcrafter_amd import parallel
+    from viewcrafter_amd.utils.diffusion_utils import image_guided_synthesis
+    noise_shape = [1, 4, IGS_T, IGS_H // 8, IGS_W // 8]
+    clips = [torch.tanh(synth_input(f"lanes_videos{i}", (1, 3, IGS_T, IGS_H, IGS_W))).to(DEV) for i in range(3)]
+
+    def one(videos, index):
+        torch.manual_seed(1234 + index)
+        with torch.no_grad():
+            return image_guided_synthesis(igs_model, [""], videos, noise_shape, ddim_steps=4, ddim_eta=1.0, unconditional_guidance_scale=7.5,
+                                          fs=10, text_input=False, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                                          condition_index=[0])
+    got = {}
+    for lanes in (1, 2):
+        torch.manual_seed(5)
+        got[lanes] = parallel.run_sharded(one, clips, gather=False, lanes=lanes)
+        torch.cuda.synchronize()
+        got[lanes] = ([got[lanes][i].clone() for i in range(3)], torch.cuda.get_rng_state().clone(), torch.random.get_rng_state().clone())
+    for a, b in zip(got[1][0], got[2][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(got[1][1], got[2][1]) and torch.equal(got[1][2], got[2][2])
+    assert not torch.equal(got[1][0][0], got[1][0][1])
+
+
 def test_inference_cli_end_to_end(tmp_path):
     from viewcrafter_amd.utils.video_io import read_avi
     ypath, cpath, rpath, (T, H, W) = write_tiny_entry_files(tmp_path)

@@ -131,3 +131,40 @@ def test_broadcast_tensor_list_two_ranks_and_a_failing_source(fail):
         assert all(isinstance(v, str) and "DUSt3R went wrong" in v for v in outs.values()), outs
     else:
         assert outs[0] == outs[1] and len(outs[0]) == 4 and outs[0][3] == ((5,), "torch.float64", 5.0)
+
+
+def test_interleaved_clips_draw_the_same_numbers_as_a_plain_loop():
+    """viewcrafter_amd/interleave.py: two clips in flight at a time, taking turns at every sampler step, each with the global generator as
+    part of its context - every clip must draw exactly what it draws running alone after manual_seed(seed + index), whatever the
+    interleaving, and the generator must be left as a plain loop leaves it."""
+    import torch
+    from viewcrafter_amd.interleave import run_interleaved, step_yield
+
+    def clip(item, index):
+        if index > 0:
+            torch.manual_seed(100 + index)
+        acc = torch.zeros(3)
+        for _ in range(item):                     # `item` sampler steps, one draw each, baton handed on after every step
+            acc = acc * 0.5 + torch.randn(3)
+            step_yield()
+        return acc + torch.rand(3)                # (the decode-side draw behind the loop)
+
+    items = [(0, 5), (1, 3), (2, 7), (3, 1), (4, 4)]
+    torch.manual_seed(7)
+    want = [clip(item, index) for index, item in items]
+    end_state = torch.random.get_rng_state()
+    for lanes in (2, 3):
+        torch.manual_seed(7)
+        got = run_interleaved(clip, items, n_lanes=lanes)
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), f"{lanes} lanes"
+        assert torch.equal(torch.random.get_rng_state(), end_state)
+
+    def boom(item, index):
+        step_yield()
+        if index == 1:
+            raise RuntimeError("clip 1 failed")
+        step_yield()
+        return torch.zeros(1)
+    import pytest
+    with pytest.raises(RuntimeError, match="clip 1 failed"):
+        run_interleaved(boom, [(0, 0), (1, 0)], n_lanes=2)

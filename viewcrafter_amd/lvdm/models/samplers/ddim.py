@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from .... import ops
+from ....interleave import step_yield
 from ...common import noise_like
 from ..utils_diffusion import make_ddim_sampling_parameters, make_ddim_timesteps
 
@@ -124,6 +125,7 @@ class DDIMSampler(object):
                 callback(i)
             if img_callback:
                 img_callback(pred_x0, i)
+            step_yield()           # two clips per GPU (viewcrafter_amd/interleave.py): the other clip's step is queued next; a no-op otherwise
             if index % log_every_t == 0 or index == total_steps - 1:
                 intermediates["x_inter"].append(img)
                 intermediates["pred_x0"].append(pred_x0)

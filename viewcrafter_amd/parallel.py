@@ -160,10 +160,16 @@ def gather_results(local, n_items, dst=0, _force=False):
     return [out[owner_of(i, world)][i // world] for i in range(n_items)]
 
 
-def run_sharded(fn, items, gather=True):
-    """Apply fn(item, index) to the items this rank owns; optionally gather the tensor results on rank 0."""
+def run_sharded(fn, items, gather=True, lanes=1):
+    """Apply fn(item, index) to the items this rank owns; optionally gather the tensor results on rank 0.  lanes > 1: that many of the
+    rank's items in flight at a time, interleaved step by step on their own HIP streams (interleave.run_interleaved)."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
-    local = {i: fn(items[i], i) for i in shard_indices(len(items), rank, world)}
+    mine = list(shard_indices(len(items), rank, world))
+    if lanes > 1 and len(mine) > 1:
+        from .interleave import run_interleaved
+        local = dict(zip(mine, run_interleaved(fn, [(i, items[i]) for i in mine], n_lanes=lanes)))
+    else:
+        local = {i: fn(items[i], i) for i in mine}
     return gather_results(local, len(items)) if gather else local
 
 
