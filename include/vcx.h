@@ -35,8 +35,8 @@ extern "C" {
 /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*.  3: vcx_gemm_desc grows ln_stats / ln_colsum (VCX_GEMM_LNFOLD*),
  * vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32.  5: vcx_gemm_desc starts with
  * struct_size - a descriptor of another layout is rejected instead of read past its end; ldcs; vcx_clip_preprocess_f32,
- * vcx_add_nchw_f32_to_nhwc_f16. */
-#define VCX_ABI_VERSION 6
+ * vcx_add_nchw_f32_to_nhwc_f16.  6: vcx_ddim_ws_bytes, ws_bytes argument of the DDIM steps.  7: vcx_groupnorm_fold_linear_f16. */
+#define VCX_ABI_VERSION 7
 
 int vcx_abi_version(void);
 const char* vcx_last_error(void);
@@ -144,6 +144,17 @@ int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stats, const fl
  * independent of the batch size); ws as for vcx_groupnorm_stats_f16 (vcx_groupnorm_ws_bytes). */
 int vcx_groupnorm_stats_from_colstats_f32(const float* colstats, float* stats, void* ws, int n_outer, int64_t pixels, int C,
                                           int groups, void* stream);
+
+/* GroupNorm folded into the nn.Linear / 1x1 Conv1d behind it - TemporalTransformer.norm -> proj_in (attention.py:331-336,369-372; the
+ * same pair in SpatialTransformer, attention.py:265-269,299): no SiLU sits between them, so GroupNorm-apply is an affine map per
+ * (statistics unit n, channel) and  Linear(GroupNorm(x_n)) = x_n Wn[n]^T + bn[n]  with
+ *   Wn[n][o][c] = fp16(W[o][c] gamma[c] rstd[n, g(c)]),   bn[n][o] = bias[o] + sum_c (W[o][c] beta[c] - float(Wn[n][o][c]) mean[n, g(c)])
+ * (the mean term on the ROUNDED weight: a common offset of a group's channels cancels exactly).  The caller then runs vcx_gemm_f16 on
+ * the un-normalised rows of unit n with (Wn[n], bn[n]): the normalised copy of the tensor is neither written nor re-read.
+ * W fp32 [N][C] (master weights), bias fp32 [N] or NULL, stats [n_outer][groups][2] = (mean, variance) as vcx_groupnorm_apply_f16
+ * takes them; out: Wn fp16 [n_outer][N][C], bn fp32 [n_outer][N].  C % 4 == 0. */
+int vcx_groupnorm_fold_linear_f16(const float* W, const float* bias, const float* gamma, const float* beta, const float* stats,
+                                  void* Wn, float* bn, int n_outer, int N, int C, int groups, float eps, void* stream);
 
 /* LayerNorm over the last dim (nn.LayerNorm, attention.py:226-228), fp32 statistics. */
 /* (mean, rstd) of every row, stats[rows][2] fp32: the read-only half of LayerNorm in front of a VCX_GEMM_LNFOLD projection
@@ -284,7 +295,7 @@ int vcx_profile_end(double* out_host);
 #define VCX_TUNE_GEMM_CFG 0        /* -1 auto | 0..3 force tile config 128x128 / 128x160 / 256x256 / 256x320 */
 #define VCX_TUNE_GEMM_DMA 1        /* 1 | 0 = register-staged kernel everywhere                              */
 #define VCX_TUNE_FLASH_QB 2        /* 0 auto | 1 | 2 query blocks of 32 rows per wave (v1 kernel)            */
-#define VCX_TUNE_XATTN_RESIDENT 3  /* 1 | 0 = never use the LDS-resident cross-attention kernel              */
+#define VCX_TUNE_XATTN_RESIDENT 3  /* 1 | 0 = never use the LDS-resident cross-attention kernel | 2 = its first form */
 #define VCX_TUNE_FLASH_IMPL 4      /* 0 auto | 1 phased v1 kernel | 2 software-pipelined v2 kernel           */
 #define VCX_TUNE_EXP0 5            /* free for one-off experiments (0)                                       */
 #define VCX_TUNE_EXP1 6

@@ -97,6 +97,25 @@ def group_norm_stats_from_colstats(colstats, n_outer, pixels, C, groups=32):
     return torch.stack([mean_g, m2_g / (pixels * cpg)], dim=-1).float()
 
 
+def group_norm_stats(x, groups=32):
+    n, pixels, C = x.shape
+    xf = x.float().view(n, pixels, groups, C // groups)
+    return torch.stack([xf.mean(dim=(1, 3)), xf.var(dim=(1, 3), unbiased=False)], dim=-1)
+
+
+def group_norm_fold_linear(w32, bias, gamma, beta, stats, eps, groups=32):
+    """include/vcx.h vcx_groupnorm_fold_linear_f16: the mean term on the fp16-ROUNDED scaled weight."""
+    N, C = w32.shape
+    cpg = C // groups
+    mean = stats[..., 0].float().repeat_interleave(cpg, dim=1)                          # [n, C]
+    a = torch.rsqrt(stats[..., 1].float() + eps).repeat_interleave(cpg, dim=1) * gamma.float()
+    wn = (w32.float()[None] * a[:, None, :]).to(_f16)                                   # [n, N, C]
+    bn = (w32.float() @ beta.float())[None] - (wn.float() * mean[:, None, :]).sum(-1)
+    if bias is not None:
+        bn = bn + bias.float()[None]
+    return wn, bn.float().contiguous()
+
+
 def group_norm(x, gamma, beta, eps, silu, groups=32, out=None, stats=None):
     n, pixels, C = x.shape
     xf = x.float().view(n, pixels, groups, C // groups)
@@ -213,6 +232,7 @@ def install(monkeypatch):
     from viewcrafter_amd import _lib, ops
     _TUNE.clear()
     table = dict(require_gpu=lambda: None, gemm=gemm, group_norm_stats_from_colstats=group_norm_stats_from_colstats, group_norm=group_norm,
+                 group_norm_stats=group_norm_stats, group_norm_fold_linear=group_norm_fold_linear,
                  row_stats=row_stats, layer_norm=layer_norm, flash_attn=flash_attn, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn,
                  softmax_rows_=softmax_rows_, copy2d=copy2d, add_nchw_=add_nchw_, ncthw_to_nthwc=ncthw_to_nthwc, nthwc_to_ncthw=nthwc_to_ncthw,
                  timestep_embedding=timestep_embedding, silu_f32=lambda x: F.silu(x.float()), gelu_=lambda x: x.copy_(F.gelu(x.float()).to(_f16)),

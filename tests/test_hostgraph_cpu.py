@@ -49,6 +49,39 @@ def test_host_graph_of_the_unet_vs_reference_golden(monkeypatch, level, tag, sha
     assert y.shape == g[f"unet_out_{tag}"].shape and e <= UNET_TOL
 
 
+@pytest.mark.parametrize("level", [2, 0])
+@pytest.mark.parametrize("tag,shape,L", [("perframe", (1, 4, 32, 16), 77 + 64), ("shared", (2, 3, 16, 32), 77 + 40)])
+def test_host_graph_with_the_temporal_groupnorm_folded_into_proj_in(monkeypatch, level, tag, shape, L):
+    """TemporalTransformer.norm as per-video weights / bias of proj_in (vcx_groupnorm_fold_linear_f16 + one GEMM per video) at EVERY
+    level of the tiny graph (the product folds from 16 MB per video up): statistics from the producer's moments (level 2) or from
+    a statistics pass (level 0), two videos with different statistics ("shared": b = 2), against the reference golden."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.lvdm.modules import attention
+    m, _ = _unet(monkeypatch, level)
+    monkeypatch.setattr(attention, "GN_FOLD", True)
+    monkeypatch.setattr(attention, "GN_FOLD_MIN_BYTES", 0)
+    calls = dict(fold=0, videos=0)
+    fold = ops.group_norm_fold_linear
+
+    def counted(w32, bias, gamma, beta, stats, eps, **k):
+        calls["fold"] += 1
+        calls["videos"] += stats.shape[0]
+        return fold(w32, bias, gamma, beta, stats, eps, **k)
+    monkeypatch.setattr(ops, "group_norm_fold_linear", counted)
+    g = golden("unet_tiny")
+    b, t, h, w = shape
+    x = synth_input(f"unet_x_{tag}", (b, 8, t, h, w))
+    ctx = synth_input(f"unet_ctx_{tag}", (b, L, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = m(x, torch.tensor([999, 399][:b]), context=ctx, fs=torch.tensor([10, 3][:b]))
+    e = rel_l2(y, g[f"unet_out_{tag}"])
+    n_tt = sum(isinstance(mod, attention.TemporalTransformer) for mod in m.modules())
+    print(f"temporal GroupNorm folded into proj_in ({calls['fold']} of {n_tt} temporal transformers, {calls['videos']} weight sets), GN statistics level "
+          f"{level}, {tag}: rel-L2 vs the reference golden = {e:.3e}")
+    assert calls["fold"] == n_tt and calls["videos"] == n_tt * b
+    assert y.shape == g[f"unet_out_{tag}"].shape and e <= UNET_TOL
+
+
 def test_moments_travel_with_the_activations_and_the_concat_is_written_in_place(monkeypatch):
     """Level 2 (round 4): count what the graph asks of the kernels at a latent where every level but the deepest has whole 64-row
     strips - statistics passes only where no producer could supply moments, one copy per concat instead of two - and check the

@@ -362,6 +362,42 @@ def test_groupnorm_large_common_offset(n, pix, C, offset, std):
     check(out, ref.float(), tol=3e-3, name="groupnorm offset")
 
 
+@pytest.mark.parametrize("n,pix,C,N,offset,std", [(2, 9216, 320, 320, 0.0, 1.0), (2, 2304, 640, 640, 0.0, 1.0), (3, 640, 1280, 1280, 0.0, 1.0),
+                                                  (2, 9216, 320, 320, 100.0, 0.1), (1, 5000, 640, 320, -300.0, 0.25), (2, 1000, 64, 72, 3.0, 1.0)])
+def test_groupnorm_folded_into_the_linear_layer_behind_it(n, pix, C, N, offset, std):
+    """vcx_groupnorm_fold_linear_f16 + one GEMM per statistics unit on the UN-normalised rows = Linear(GroupNorm(x)) (reference
+    TemporalTransformer.norm -> proj_in, attention.py:331-336,369-372), against fp64 on the same fp16 input - with different statistics
+    per unit and with a common offset 1000x the spread (the gate of test_groupnorm_large_common_offset: the mean term is taken on the
+    ROUNDED folded weight, so the offset cancels exactly) - and next to the unfolded pair of kernels it replaces; the weight / bias
+    sets themselves against the restatement of the contract (tests/cpu_kernels.py); bit-reproducible."""
+    from viewcrafter_amd import ops
+    from tests import cpu_kernels
+    x = (offset + std * rnd(n, pix, C, seed=461) * (1 + torch.arange(n).view(n, 1, 1))).half()      # unit i: spread (i + 1) std
+    g = 1 + 0.2 * rnd(C, seed=462)
+    b = 0.1 * rnd(C, seed=463)
+    w = rnd(N, C, seed=464) / math.sqrt(C)
+    bias = 0.3 * rnd(N, seed=465)
+    xd, gd, bd, wd, biasd = x.to(DEV), g.to(DEV), b.to(DEV), w.to(DEV), bias.to(DEV)
+    stats = ops.group_norm_stats(xd)
+    wn, bn = ops.group_norm_fold_linear(wd, biasd, gd, bd, stats, 1e-6)
+    wn_ref, bn_ref = cpu_kernels.group_norm_fold_linear(w, bias, g, b, stats.cpu(), 1e-6)
+    assert (wn.cpu().float() - wn_ref.float()).abs().max() <= 2e-3 * wn_ref.float().abs().max()      # (rsqrt: hardware approximation vs torch)
+    out = torch.empty(n * pix, N, device=DEV, dtype=torch.float16)
+    for i in range(n):
+        ops.gemm(xd.view(n * pix, C)[i * pix:], wn[i], M=pix, N=N, K=C, lda=C, out=out[i * pix:], ldc=N, bias=bn[i])
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, g.double(), b.double(), 1e-6).permute(0, 2, 1) @ w.double().t() + bias.double()
+    check(out.view(n, pix, N), ref.float(), tol=3e-3, name="groupnorm folded into linear")
+    unfolded = ops.linear(ops.group_norm(xd, gd, bd, 1e-6, False).view(n * pix, C), wd.half(), biasd)
+    e_f, e_u = rel_l2(out.view(n, pix, N), ref.float()), rel_l2(unfolded.view(n, pix, N), ref.float())
+    print(f"Linear(GroupNorm(x)) n={n} pix={pix} C={C} offset={offset}: folded {e_f:.2e}, GroupNorm kernel + linear {e_u:.2e} (vs fp64)")
+    assert e_f <= 1.5 * e_u + 2e-4
+    wn2, bn2 = ops.group_norm_fold_linear(wd, biasd, gd, bd, stats, 1e-6)
+    assert torch.equal(wn, wn2) and torch.equal(bn, bn2)
+    if n > 1:       # a unit's weights do not depend on how many units ride in the call
+        w1, b1 = ops.group_norm_fold_linear(wd, biasd, gd, bd, stats[1:2].contiguous(), 1e-6)
+        assert torch.equal(w1[0], wn[1]) and torch.equal(b1[0], bn[1])
+
+
 @pytest.mark.parametrize("kind,n,H,W,cin,cout,offset", [
     ("3x3", 3, 16, 32, 64, 320, 0.0),            # group width 10: a lane's 4-column piece straddles two groups
     ("3x3", 2, 8, 8, 128, 640, 0.0),             # one 64-row strip per frame
@@ -896,6 +932,58 @@ def test_flash_dual_text_plus_image(T, shared, nq, log2):
     ref = attn_ref(qh, kth, vth, sc) + attn_ref(qh, kih, vih, sc)
     ref = ref.view(G, heads, nq, 64).permute(0, 2, 1, 3).reshape(G * nq, C)
     check(out, ref, tol=3e-3, name="dual cross-attn")
+
+
+# The LDS-resident kernel exists in two forms (csrc/attention.hip: xattn_resident2_d64_kernel walks half tiles with prefetched
+# fragments and query rows; knob XATTN_RESIDENT = 2 selects the first form).  Key counts that end inside / on the edge of a half
+# tile, query counts that leave ragged 64-row wave iterations and ragged 512-row block shares, and logits large enough that the
+# deferred running max has to move several times (gain: the rescale branch is otherwise never taken by unit-variance data).
+@pytest.mark.parametrize("T,nq,nk1,nk2,gain", [(5, 144, 77, 256, 1.0), (3, 1000, 77, 256, 1.0), (2, 200, 33, 100, 1.0), (4, 576, 128, 16, 1.0),
+                                               (2, 77, 20, 250, 1.0), (25, 2304, 77, 256, 1.0), (3, 333, 77, 256, 6.0), (2, 64, 96, 64, 3.0)])
+def test_resident_cross_attention_second_form(T, nq, nk1, nk2, gain):
+    from viewcrafter_amd import ops
+    B, heads = 2, 3
+    C = heads * 64
+    G = B * T
+    r1, r2 = (nk1 + 7) // 8 * 8, (nk2 + 7) // 8 * 8
+    q = rnd(G * nq, C, seed=255) * gain
+    kt = torch.zeros(B, r1, C); vtx = torch.zeros(B, r1, C)
+    kt[:, :nk1] = rnd(B, nk1, C, seed=256); vtx[:, :nk1] = rnd(B, nk1, C, seed=257)
+    ki = torch.zeros(B, r2, C); vi = torch.zeros(B, r2, C)
+    ki[:, :nk2] = rnd(B, nk2, C, seed=258); vi[:, :nk2] = rnd(B, nk2, C, seed=259)
+    scale = 0.125
+    qd = _log2_q(q, scale).to(DEV)
+    kt, vtx, ki, vi = [t.to(DEV).half() for t in (kt, vtx, ki, vi)]
+    vt_t = vtx.reshape(B * r1, C).t().contiguous()
+    vi_t = vi.reshape(B * r2, C).t().contiguous()
+    outs = {}
+    for form in (1, 2):
+        prev = ops.tune_set("XATTN_RESIDENT", form)
+        try:
+            out = torch.full((G * nq + 64, C), 7.0, device=DEV, dtype=torch.float16)      # 64 guard rows behind the result
+            ops.flash_attn_dual(qd, kt.view(B * r1, C), vt_t, ki.view(B * r2, C), vi_t, out, n_groups=G, heads=heads, nq=nq, nk1=nk1, kv_rows1=r1,
+                                kv_div1=T, ldk1=C, ldvt1=B * r1, nk2=nk2, kv_rows2=r2, kv_div2=T, ldk2=C, ldvt2=B * r2, ldq=C, ldo=C,
+                                scale=scale, log2_logits=True)
+            outs[form] = out
+        finally:
+            ops.tune_set("XATTN_RESIDENT", prev)
+
+    def split(t, n):
+        return t.view(-1, n, heads, 64).permute(0, 2, 1, 3).reshape(-1, n, 64)
+    qh = split(qd.view(G, nq, C), nq)
+    ref = (attn_ref(qh, split(kt[:, :nk1].repeat_interleave(T, 0), nk1), split(vtx[:, :nk1].repeat_interleave(T, 0), nk1), LN2)
+           + attn_ref(qh, split(ki[:, :nk2].repeat_interleave(T, 0), nk2), split(vi[:, :nk2].repeat_interleave(T, 0), nk2), LN2))
+    ref = ref.view(G, heads, nq, 64).permute(0, 2, 1, 3).reshape(G * nq, C)
+    for form, out in outs.items():
+        check(out[:G * nq], ref, tol=3e-3, name=f"resident cross-attn form {form}")
+        assert (out[G * nq:] == 7.0).all(), f"form {form} wrote behind its last row"
+    check(outs[1][:G * nq], outs[2][:G * nq].float(), tol=2e-3, name="resident form 2 (new) vs form 1")
+    # the second form once more: bit-reproducible
+    again = torch.empty_like(outs[1])
+    ops.flash_attn_dual(qd, kt.view(B * r1, C), vt_t, ki.view(B * r2, C), vi_t, again, n_groups=G, heads=heads, nq=nq, nk1=nk1, kv_rows1=r1,
+                        kv_div1=T, ldk1=C, ldvt1=B * r1, nk2=nk2, kv_rows2=r2, kv_div2=T, ldk2=C, ldvt2=B * r2, ldq=C, ldo=C,
+                        scale=scale, log2_logits=True)
+    assert torch.equal(again[:G * nq], outs[1][:G * nq])
 
 
 @pytest.mark.parametrize("B,T,P,heads", [(1, 16, 40, 2), (2, 25, 37, 5), (1, 4, 8, 1)])

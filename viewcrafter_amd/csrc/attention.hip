@@ -530,6 +530,263 @@ __global__ void __launch_bounds__(512, 1) xattn_resident_d64_kernel(XAttnArgs p)
 }
 
 // =======================================================================================
+// Resident cross-attention, second form (round 5).  Same residency, same arithmetic per score as xattn_resident_d64_kernel; what
+// changes is everything around the MFMAs, which ran at 0.2 of either roof (0.338 ms at level 0 for 116 us of matrix work):
+//   * the loop walks HALF tiles (32 keys): one score accumulator per query block instead of two, and the 32 registers that frees
+//     hold the K fragments of the NEXT half tile and the V^T fragments of this one, requested a whole MFMA / softmax phase ahead
+//     (v1: ds_read -> lgkmcnt(0) -> two MFMAs, eight times per tile);
+//   * the Q rows of the wave's NEXT 64 queries are requested (branch-free buffer loads, rows past the end arrive as zeros without
+//     traffic) when an iteration starts and used when the next one does - v1 waited vmcnt(0) for them at the top of every iteration;
+//   * the first key set's normalised result waits in a wave-private LDS patch (8 KB x 8 waves = the 64 KB the K / V^T image leaves
+//     free) instead of 32 registers;
+//   * the deferred-max test is a ballot over the per-lane PARTIAL maxima (a row exceeds the threshold iff one of its two lanes
+//     does); the exact row maximum - v_permlane32_swap, not an LDS round trip - is only formed inside the rare rescale;
+//   * output as 16-byte buffer stores (lane pairs exchange halves with v_permlane32_swap), rows past the end dropped by the range
+//     check: no exec-mask branches, so hipcc's vector-memory counts stay exact and the Q wait does not drain the stores.
+// A text half tile that holds no key (77 keys: 3 of 4) is never visited, so nothing is special-cased for it.
+// =======================================================================================
+__global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p, unsigned q_bytes, unsigned o_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int T1 = 2, T2 = 4, NT = T1 + T2;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsmem[];
+    half_t* sK = reinterpret_cast<half_t*>(xsmem);           // [NT][64 keys][64] swizzled
+    half_t* sV = sK + NT * 64 * 64;                          // [NT][64 d][64 keys] swizzled
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int unit = blockIdx.x / p.split, part = blockIdx.x % p.split;
+    const int gb = unit / p.heads, h = unit % p.heads;
+    u4v* sKeep = reinterpret_cast<u4v*>(xsmem + 2 * NT * 8192 + wave * 8192) + lane;      // piece i of this lane: sKeep[64 i], i < 8
+
+    // ---- K / V^T of both sets -> LDS (as in xattn_resident_d64_kernel)
+    {
+        const int srow8 = lane >> 3, spos = lane & 7;
+        for (int idx = wave; idx < NT * 16; idx += 8) {
+            const int t = idx >> 4, j = idx & 15;
+            const bool second = t >= T1;
+            const int kt = second ? t - T1 : t;
+            const int nk = second ? p.nk2 : p.nk1;
+            const int64_t ldk = second ? p.ldk2 : p.ldk1, ldvt = second ? p.ldvt2 : p.ldvt1;
+            const int64_t kvrow0 = (int64_t)gb * (second ? p.kv_rows2 : p.kv_rows1);
+            const half_t* kbase = (second ? p.k2 : p.k1) + kvrow0 * ldk + h * 64;
+            const half_t* vbase = (second ? p.vt2 : p.vt1) + (int64_t)(h * 64) * ldvt + kvrow0;
+            const int r = (j & 7) * 8 + srow8;
+            const int csrc = spos ^ ((r >> 1) & 7);
+            if (j < 8) {
+                const unsigned bytes = (unsigned)(((int64_t)(nk - 1) * ldk + 64) * 2);
+                const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kbase), 0, (int)bytes, 0x00020000);
+                const int key = kt * 64 + r;
+                const unsigned v = key < nk ? (unsigned)((int64_t)key * ldk * 2) + csrc * 16 : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(sK + t * 4096 + (j & 7) * 512), 16, v, 0, 0, 0);
+            } else {
+                const unsigned bytes = (unsigned)((63ll * ldvt + ((nk + 7) & ~7)) * 2);
+                const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vbase), 0, (int)bytes, 0x00020000);
+                const int key0 = kt * 64 + csrc * 8;
+                const unsigned v = key0 < nk ? (unsigned)((int64_t)r * ldvt * 2) + (unsigned)(kt * 128) + csrc * 16 : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(sV + t * 4096 + (j & 7) * 512), 16, v, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
+
+    const int64_t row_begin = (int64_t)part * p.rows_per_block;
+    const int64_t row_end = row_begin + p.rows_per_block < p.rows_per_unit ? row_begin + p.rows_per_block : p.rows_per_unit;
+    const half_t* qbase = p.q + ((int64_t)gb * p.rows_per_unit) * p.ldq + h * 64;
+    half_t* obase = p.o + ((int64_t)gb * p.rows_per_unit) * p.ldo + h * 64;
+    const __amdgpu_buffer_rsrc_t srd_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(qbase), 0, (int)q_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)o_bytes, 0x00020000);
+    const unsigned ldq2 = (unsigned)p.ldq * 2u, ldo2 = (unsigned)p.ldo * 2u;
+    const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float scale = p.scale_log2;
+    const int nh1 = (p.nk1 + 31) >> 5, nh = nh1 + ((p.nk2 + 31) >> 5);          // half tiles of the first set, of both
+
+    // fragment offsets (elements) inside a tile for key half 0: K fragment of k-step s = row lq, chunk 2 s + hi; V^T fragment
+    // piece (s, e) = row lq (+ 32 db), chunk 2 s + e, halves 4 hi .. + 3.  Key half 1: K 32 rows on, V^T chunk + 4 = offset ^ 32.
+    int ko[4], vo[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        ko[s] = tile_off(lq, 2 * s + hi);
+        vo[s] = tile_off(lq, s) + 4 * hi;
+    }
+    auto read_k = [&](int j, h8 (&kf)[4]) {                 // half tile j of the flat sequence (both sets)
+        const int jj = j >= nh1 ? j - nh1 : j;
+        const half_t* base = sK + ((j >= nh1 ? T1 : 0) + (jj >> 1)) * 4096 + (jj & 1) * 2048;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const h8*>(base + ko[s]);
+    };
+    auto load_q = [&](int64_t r0, u4v (&dst)[8]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t qrow = r0 + b * 32 + lq;
+            const unsigned v = qrow < row_end ? (unsigned)qrow * ldq2 + (unsigned)hi * 16u : OOB;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dst[b * 4 + s] = __builtin_amdgcn_raw_buffer_load_b128(srd_q, v, s * 32, 0);
+        }
+    };
+
+    u4v qn[8];
+    h8 kf[4];
+    load_q(row_begin + wave * 64, qn);
+    read_k(0, kf);
+    for (int64_t r0 = row_begin + wave * 64; r0 < row_end; r0 += 512) {       // this wave's two 32-row query blocks
+        h8 qf[2][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qf[i >> 2][i & 3] = __builtin_bit_cast(h8, qn[i]);
+        load_q(r0 + 512, qn);                                                 // the next iteration's rows (zeros past the end)
+        f16v oacc[2][2];
+        float m_run[2], l_run[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            m_run[b] = -1e30f;
+            l_run[b] = 0.f;
+            oacc[b][0] = zero16;
+            oacc[b][1] = zero16;
+        }
+#pragma unroll 1
+        for (int j = 0; j < nh; ++j) {
+            if (j == nh1) {
+                // ---- first set complete: normalise, park in LDS as fp16, start over for the second set
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, l_run[b]), __builtin_bit_cast(unsigned, l_run[b]), false, false);
+                    const float inv = 1.0f / (__builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]));
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        h8 lo8, hi8;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            lo8[i] = (half_t)(oacc[b][db][i] * inv);
+                            hi8[i] = (half_t)(oacc[b][db][8 + i] * inv);
+                        }
+                        const u4v w0 = __builtin_bit_cast(u4v, lo8), w1 = __builtin_bit_cast(u4v, hi8);
+                        sKeep[64 * (4 * b + 2 * db)] = w0;
+                        sKeep[64 * (4 * b + 2 * db + 1)] = w1;
+                        // a wide store still reads its data registers one or two slots on (tools/isa_audit.py, the library-wide rule of
+                        // round 3): the data stay live, and untouched, across two wait states
+                        asm volatile("s_nop 1" : : "v"(w0), "v"(w1));
+                        oacc[b][db] = zero16;
+                    }
+                    m_run[b] = -1e30f;
+                    l_run[b] = 0.f;
+                }
+            }
+            const bool second = j >= nh1;
+            const int jj = second ? j - nh1 : j;
+            const int kb = jj & 1, key_base = jj * 32, nk = second ? p.nk2 : p.nk1;
+            const half_t* cV = sV + ((second ? T1 : 0) + (jj >> 1)) * 4096;
+            // ---- V^T fragments of this half tile (used behind the softmax), then the scores
+            h8 vf[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const h4 lo = *reinterpret_cast<const h4*>(cV + db * 2048 + (vo[2 * s] ^ (kb * 32)));
+                    const h4 hi4 = *reinterpret_cast<const h4*>(cV + db * 2048 + (vo[2 * s + 1] ^ (kb * 32)));
+                    vf[s][db] = h8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                }
+            f16v sacc[2];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[b][s], s == 0 ? zero16 : sacc[b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- K fragments of the next half tile (of the next iteration's first one behind the last): a softmax ahead of their use
+            read_k(j + 1 < nh ? j + 1 : 0, kf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (key_base + 32 > nk) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key_base + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (key >= nk) sacc[b][r] = -1e30f;
+                    }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float mx = sacc[b][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
+                const float cand = mx * scale;                                           // this lane's 16 of the row's 32 keys
+                if (__builtin_amdgcn_ballot_w64(cand > m_run[b] + FLASH_DEFER) != 0) {   // deferred max, as in flash_d64_kernel
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, cand), __builtin_bit_cast(unsigned, cand), false, false);
+                    const float m_new = fmaxf(m_run[b], fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])));
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+                    m_run[b] = m_new;
+                    l_run[b] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { oacc[b][0][i] *= alpha; oacc[b][1][i] *= alpha; }
+                }
+                const float m_use = m_run[b];
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][r], scale, -m_use));
+                    sacc[b][r] = pv;
+                    psum += pv;
+                }
+                l_run[b] += psum;
+            }
+            // ---- O^T += V^T P^T
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                h8 pf[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pf[b][i] = (half_t)sacc[b][8 * s + i];
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) oacc[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s][db], pf[b], oacc[b][db], 0, 0, 0);
+            }
+        }
+        // ---- second set complete: normalise, add the first set's result, store
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, l_run[b]), __builtin_bit_cast(unsigned, l_run[b]), false, false);
+            const float inv = 1.0f / (__builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]));
+            const int64_t qrow = r0 + b * 32 + lq;
+            const unsigned ov = qrow < row_end ? (unsigned)qrow * ldo2 + (unsigned)hi * 16u : OOB;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const h8 k0 = __builtin_bit_cast(h8, sKeep[64 * (4 * b + 2 * db)]);
+                const h8 k1 = __builtin_bit_cast(h8, sKeep[64 * (4 * b + 2 * db + 1)]);
+                u2v pk[4];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    h4 o4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = gq * 4 + r;
+                        o4[r] = (half_t)(oacc[b][db][i] * inv + (float)(i < 8 ? k0[i] : k1[i - 8]));
+                    }
+                    pk[gq] = __builtin_bit_cast(u2v, o4);
+                }
+                // column group k = 4 db + gq holds columns 8 k + 4 hi .. + 3 of this lane's row: after the half swap lanes 0-31 own
+                // columns 8 k .. 8 k + 7 and lanes 32-63 columns 8 k + 8 .. 8 k + 15 (as tattn_d64_kernel)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq += 2) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[gq][0], pk[gq + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[gq][1], pk[gq + 1][1], false, false);
+                    const u4v w = {s0[0], s1[0], s0[1], s1[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(w, srd_o, ov, (db * 32 + gq * 8) * 2, 0);
+                    asm volatile("s_nop 1" : : "v"(w));          // (the wide-store rule again)
+                }
+            }
+        }
+    }
+#endif
+}
+
+// =======================================================================================
 // Temporal attention: T <= 32 frames, d = 64.
 // =======================================================================================
 struct TAttnArgs {
@@ -824,6 +1081,16 @@ extern "C" int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const 
         x.rows_per_block = ((iters + split - 1) / split) * 512;
         x.split = (int)((x.rows_per_unit + x.rows_per_block - 1) / x.rows_per_block);
         constexpr int XSMEM = 6 * 64 * 64 * 2 * 2;
+        // second form (half tiles, prefetched fragments and query rows, first result parked in the other 64 KB of LDS): needs 32-bit
+        // byte offsets inside a unit's Q / O rows and 16-byte output stores; knob XATTN_RESIDENT = 2 keeps the first form (A/B runs)
+        const int64_t q_ext = ((x.rows_per_unit - 1) * ldq + 64) * 2, o_ext = ((x.rows_per_unit - 1) * ldo + 64) * 2;
+        if (vcx_tune(VCX_TUNE_XATTN_RESIDENT) != 2 && q_ext < 0xFFFF0000ll && o_ext < 0xFFFF0000ll && ldo % 8 == 0 && ((uintptr_t)o & 15) == 0) {
+            constexpr int XSMEM2 = XSMEM + 8 * 8192;
+            static VcxLdsAttr lds2;
+            if (!lds2.ensure(reinterpret_cast<const void*>(xattn_resident2_d64_kernel), XSMEM2, "vcx_attn_flash_dual_d64_f16(resident2)")) return VCX_ELAUNCH;
+            hipLaunchKernelGGL(xattn_resident2_d64_kernel, dim3(x.nunits * x.split), dim3(512), XSMEM2, s, x, (unsigned)q_ext, (unsigned)o_ext);
+            return vcx_check_launch("vcx_attn_flash_dual_d64_f16(resident2)");
+        }
         static VcxLdsAttr lds;
         if (!lds.ensure(reinterpret_cast<const void*>(xattn_resident_d64_kernel), XSMEM, "vcx_attn_flash_dual_d64_f16")) return VCX_ELAUNCH;
         hipLaunchKernelGGL(xattn_resident_d64_kernel, dim3(x.nunits * x.split), dim3(512), XSMEM, s, x);

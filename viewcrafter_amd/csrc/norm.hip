@@ -371,6 +371,41 @@ __global__ void __launch_bounds__(256) gn_colstats_partials_kernel(const float2*
     }
 }
 
+// GroupNorm folded into the linear layer behind it (vcx_groupnorm_fold_linear_f16): one wave per (output row o, statistics unit n).
+//   Wn[n][o][c] = fp16(W[o][c] a[c]),  a[c] = gamma[c] rstd[n, g(c)]
+//   bn[n][o]    = bias[o] + sum_c (W[o][c] beta[c] - float(Wn[n][o][c]) mean[n, g(c)])
+// The mean term uses the ROUNDED weight - what the GEMM will multiply the un-normalised rows with - so a common offset of a group's
+// channels cancels exactly, as in the folded LayerNorm (colsum of the rounded W').  Lane l owns the 4-channel pieces l, l + 64, ...;
+// the row sum is a fixed butterfly: bit-reproducible and the same bits whatever the number of units.
+__global__ void __launch_bounds__(64) gn_fold_linear_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ stats, half_t* __restrict__ Wn,
+                                                            float* __restrict__ bn, int N, int C, int groups, float eps) {
+    const int o = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+    const int cpg = C / groups;
+    const float* wrow = W + (int64_t)o * C;
+    half_t* orow = Wn + ((int64_t)n * N + o) * C;
+    const float* st = stats + (int64_t)n * groups * 2;
+    float acc = 0.f;
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        const f4 w = *reinterpret_cast<const f4*>(wrow + c0);
+        const f4 ga = *reinterpret_cast<const f4*>(gamma + c0);
+        const f4 be = *reinterpret_cast<const f4*>(beta + c0);
+        h4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c0 + e) / cpg;
+            const float mean = st[2 * g], a = rsqrtf(st[2 * g + 1] + eps) * ga[e];
+            const half_t wh = (half_t)(w[e] * a);
+            out[e] = wh;
+            acc += w[e] * be[e] - (float)wh * mean;
+        }
+        *reinterpret_cast<h4*>(orow + c0) = out;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) bn[(int64_t)n * N + o] = (bias ? bias[o] : 0.f) + acc;
+}
+
 }  // namespace
 
 extern "C" int vcx_groupnorm_stats_from_colstats_f32(const float* colstats, float* stats, void* ws, int n_outer, int64_t pixels, int C,
@@ -453,6 +488,20 @@ extern "C" int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stat
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(cw * pl), 0, s, (const half_t*)x, (half_t*)y, stats, gamma, beta, pixels, C,
                        groups, eps, silu, ppb, cw, pl);
     return vcx_check_launch("vcx_groupnorm_apply_f16");
+}
+
+extern "C" int vcx_groupnorm_fold_linear_f16(const float* W, const float* bias, const float* gamma, const float* beta, const float* stats,
+                                             void* Wn, float* bn, int n_outer, int N, int C, int groups, float eps, void* stream) {
+    VCX_REQUIRE(W && gamma && beta && stats && Wn && bn, "vcx_groupnorm_fold_linear_f16: null pointer");
+    VCX_REQUIRE(n_outer > 0 && n_outer <= 65535 && N > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0,
+                "vcx_groupnorm_fold_linear_f16: need C %% 4 == 0, C %% groups == 0, n_outer <= 65535 (C=%d groups=%d n_outer=%d)", C, groups, n_outer);
+    VCX_REQUIRE((((uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && ((uintptr_t)Wn & 7) == 0,
+                "vcx_groupnorm_fold_linear_f16: W / gamma / beta must be 16-byte, Wn 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_GN, s, 0.0, (double)N * C * (4.0 + 2.0 * n_outer));
+    hipLaunchKernelGGL(gn_fold_linear_kernel, dim3((unsigned)N, (unsigned)n_outer), dim3(64), 0, s, W, bias, gamma, beta, stats, (half_t*)Wn, bn, N, C,
+                       groups, eps);
+    return vcx_check_launch("vcx_groupnorm_fold_linear_f16");
 }
 
 extern "C" int vcx_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C,

@@ -39,6 +39,15 @@ FOLD_LAYERNORM = os.environ.get("VCX_LN_FOLD", "1") != "0"
 FOLD_LAYERNORM_FF = os.environ.get("VCX_LN_FOLD_FF", "0") == "1"
 
 
+# TemporalTransformer.norm -> proj_in (reference attention.py:331-336,369-372): a GroupNorm without SiLU in front of a linear layer
+# is an affine map per (video, channel), so it runs as per-video scaled weights and bias of the projection
+# (vcx_groupnorm_fold_linear_f16 + one GEMM per video on the UN-normalised rows) and the normalised copy of the tensor is neither
+# written nor re-read.  Where a video's tensor is smaller than GN_FOLD_MIN_BYTES the apply pass is cheaper than a second launch.
+# VCX_GN_FOLD=0: the separate apply pass everywhere (A/B runs, tools/step_ab.py).
+GN_FOLD = os.environ.get("VCX_GN_FOLD", "1") != "0"
+GN_FOLD_MIN_BYTES = int(os.environ.get("VCX_GN_FOLD_MIN_BYTES", str(16 << 20)))
+
+
 def _ln_projection(w, ln, alpha=1.0, bias=None):
     """Packed form of `Linear(w, bias)(LayerNorm(.)) * alpha` (alpha scales the product, not the layer's own bias): folded
     (w', colsum, bias') when `ln` is given, plain fp16 weights otherwise (colsum None: the caller normalises first).  A folded
@@ -440,7 +449,7 @@ class TemporalTransformer(PackedModule):
     def _pack(self):
         win = self.proj_in.weight.detach().reshape(self.proj_in.weight.shape[0], -1)
         wout = self.proj_out.weight.detach().reshape(self.proj_out.weight.shape[0], -1)
-        return dict(gn_w=_f32(self.norm.weight), gn_b=_f32(self.norm.bias), win=_f16(win), bin=_f32(self.proj_in.bias),
+        return dict(gn_w=_f32(self.norm.weight), gn_b=_f32(self.norm.bias), win=_f16(win), win32=_f32(win), bin=_f32(self.proj_in.bias),
                     wout=_f16(wout), bout=_f32(self.proj_out.bias))
 
     def forward(self, x, context=None, colstats=None, want_colstats=False, target=None):
@@ -452,9 +461,19 @@ class TemporalTransformer(PackedModule):
         tokens = B * T * P
         xin = x.reshape(tokens, C)
         stats = None if (colstats is None or GN_STATS_LEVEL < 2) else ops.group_norm_stats_from_colstats(colstats, B, T * P, C)
-        a = ops.group_norm(x.view(B, T * P, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False, stats=stats)
-        t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
-        D, heads = t.shape[1], self.n_heads
+        D, heads = pk["win"].shape[0], self.n_heads
+        rows = T * P
+        if GN_FOLD and C % 64 == 0 and 2 * rows * C >= GN_FOLD_MIN_BYTES and 2 * rows * max(C, D) < 0xFFFF0000 and ops.tune_get("GEMM_DMA") != 0:
+            # the norm as per-video weights / bias of proj_in; the projection reads the un-normalised rows of each video
+            if stats is None:
+                stats = ops.group_norm_stats(x.view(B, rows, C))
+            wn, bn = ops.group_norm_fold_linear(pk["win32"], pk["bin"], pk["gn_w"], pk["gn_b"], stats, self.norm.eps)
+            t = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
+            for b in range(B):
+                ops.gemm(xin[b * rows:], wn[b], M=rows, N=D, K=C, lda=C, out=t[b * rows:], ldc=D, bias=bn[b])
+        else:
+            a = ops.group_norm(x.view(B, rows, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False, stats=stats)
+            t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
         for blk in self.transformer_blocks:
             ln = blk.ln_params()
             for attn, lnp in ((blk.attn1, ln[0]), (blk.attn2, ln[1])):

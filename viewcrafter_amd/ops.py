@@ -194,6 +194,32 @@ def group_norm_stats_from_colstats(colstats, n_outer, pixels, C, groups=32):
     return stats
 
 
+def group_norm_stats(x, groups=32):
+    """(mean, variance) per (n, group) of x [n_outer, pixels, C] fp16: the statistics pass of group_norm on its own."""
+    n_outer, pixels, C = x.shape
+    _dev16(x)
+    L = lib()
+    stats = torch.empty((n_outer, groups, 2), dtype=_f32, device=x.device)
+    ws = torch.empty((L.vcx_groupnorm_ws_bytes(n_outer, pixels, groups),), dtype=torch.uint8, device=x.device)
+    check(L.vcx_groupnorm_stats_f16(x.data_ptr(), stats.data_ptr(), ws.data_ptr(), n_outer, pixels, C, groups, _stream()), "groupnorm_stats")
+    return stats
+
+
+def group_norm_fold_linear(w32, bias, gamma, beta, stats, eps, groups=32):
+    """GroupNorm (no SiLU) folded into the linear layer behind it: w32 [N, C] fp32 master weights, stats [n, groups, 2] ->
+    (Wn [n, N, C] fp16, bn [n, N] fp32) with Linear(GroupNorm(x_n)) = x_n Wn[n]^T + bn[n] (include/vcx.h)."""
+    _dev32(w32, bias, gamma, beta, stats)
+    N, C = w32.shape
+    n = stats.shape[0]
+    if not w32.is_contiguous() or tuple(stats.shape) != (n, groups, 2):
+        raise VcxError(f"group_norm_fold_linear: contiguous [N, C] weights and [n, {groups}, 2] statistics expected, got {tuple(w32.shape)} / {tuple(stats.shape)}")
+    wn = torch.empty((n, N, C), dtype=_f16, device=w32.device)
+    bn = torch.empty((n, N), dtype=_f32, device=w32.device)
+    check(lib().vcx_groupnorm_fold_linear_f16(w32.data_ptr(), _ptr(bias), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), wn.data_ptr(),
+                                              bn.data_ptr(), n, N, C, groups, eps, _stream()), "groupnorm_fold_linear")
+    return wn, bn
+
+
 def group_norm(x, gamma, beta, eps, silu, groups=32, out=None, stats=None):
     """x [n_outer, pixels, C] fp16 (contiguous).  Statistics over (pixels, C/groups) - computed here, or handed in (`stats`
     [n_outer, groups, 2] = (mean, variance), from group_norm_stats_from_colstats)."""
