@@ -545,6 +545,21 @@ __global__ void __launch_bounds__(512, 1) xattn_resident_d64_kernel(XAttnArgs p)
 //     check: no exec-mask branches, so hipcc's vector-memory counts stay exact and the Q wait does not drain the stores.
 // A text half tile that holds no key (77 keys: 3 of 4) is never visited, so nothing is special-cased for it.
 // =======================================================================================
+// Both halves of a query row: lanes l and l ^ 32 each hold a partial value x; returns (x of lanes 0-31, x of lanes 32-63) in every
+// lane.  The two results are copied into scalars BEFORE the bit cast: __builtin_bit_cast(float, sw[1]) on the element of the
+// builtin's vector result reads element 0 with this hipcc (the IR holds a single extractvalue 0; seen in the listing as
+// "rcp(x) * 0.5" for 1 / (lo + hi)) - the first GPU run of this kernel normalised every row with twice one half's sum.
+__device__ __forceinline__ void row_halves(float x, float& lo, float& hi) {
+    const unsigned a = __builtin_bit_cast(unsigned, x);
+    const auto sw = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const unsigned r0 = sw[0], r1 = sw[1];
+    lo = __builtin_bit_cast(float, r0);
+    hi = __builtin_bit_cast(float, r1);
+}
+
+#ifndef XDBG
+#define XDBG 0        // debug builds (tools/xattn_debug.py): 1 K fragments read where used, 4 exact row maximum ahead of the ballot, 8 Q rows loaded where used, 16 scalar 8-byte stores
+#endif
 __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p, unsigned q_bytes, unsigned o_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int T1 = 2, T2 = 4, NT = T1 + T2;
@@ -636,9 +651,14 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
     read_k(0, kf);
     for (int64_t r0 = row_begin + wave * 64; r0 < row_end; r0 += 512) {       // this wave's two 32-row query blocks
         h8 qf[2][4];
+#if XDBG & 8
+        load_q(r0, qn);
+#endif
 #pragma unroll
         for (int i = 0; i < 8; ++i) qf[i >> 2][i & 3] = __builtin_bit_cast(h8, qn[i]);
+#if !(XDBG & 8)
         load_q(r0 + 512, qn);                                                 // the next iteration's rows (zeros past the end)
+#endif
         f16v oacc[2][2];
         float m_run[2], l_run[2];
 #pragma unroll
@@ -654,8 +674,9 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
                 // ---- first set complete: normalise, park in LDS as fp16, start over for the second set
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, l_run[b]), __builtin_bit_cast(unsigned, l_run[b]), false, false);
-                    const float inv = 1.0f / (__builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]));
+                    float l_lo, l_hi;
+                    row_halves(l_run[b], l_lo, l_hi);
+                    const float inv = 1.0f / (l_lo + l_hi);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
                         h8 lo8, hi8;
@@ -691,6 +712,9 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
                     vf[s][db] = h8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
                 }
             f16v sacc[2];
+#if XDBG & 1
+            read_k(j, kf);
+#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -698,7 +722,9 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
                     sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[b][s], s == 0 ? zero16 : sacc[b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             // ---- K fragments of the next half tile (of the next iteration's first one behind the last): a softmax ahead of their use
+#if !(XDBG & 1)
             read_k(j + 1 < nh ? j + 1 : 0, kf);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (key_base + 32 > nk) {
 #pragma unroll
@@ -714,10 +740,14 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
                 float mx = sacc[b][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
+#if XDBG & 4
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+#endif
                 const float cand = mx * scale;                                           // this lane's 16 of the row's 32 keys
                 if (__builtin_amdgcn_ballot_w64(cand > m_run[b] + FLASH_DEFER) != 0) {   // deferred max, as in flash_d64_kernel
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, cand), __builtin_bit_cast(unsigned, cand), false, false);
-                    const float m_new = fmaxf(m_run[b], fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])));
+                    float c_lo, c_hi;
+                    row_halves(cand, c_lo, c_hi);
+                    const float m_new = fmaxf(m_run[b], fmaxf(c_lo, c_hi));
                     const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
                     m_run[b] = m_new;
                     l_run[b] *= alpha;
@@ -751,8 +781,9 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
         // ---- second set complete: normalise, add the first set's result, store
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, l_run[b]), __builtin_bit_cast(unsigned, l_run[b]), false, false);
-            const float inv = 1.0f / (__builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]));
+            float l_lo, l_hi;
+            row_halves(l_run[b], l_lo, l_hi);
+            const float inv = 1.0f / (l_lo + l_hi);
             const int64_t qrow = r0 + b * 32 + lq;
             const unsigned ov = qrow < row_end ? (unsigned)qrow * ldo2 + (unsigned)hi * 16u : OOB;
 #pragma unroll
@@ -776,9 +807,17 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
                 for (int gq = 0; gq < 4; gq += 2) {
                     const auto s0 = __builtin_amdgcn_permlane32_swap(pk[gq][0], pk[gq + 1][0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(pk[gq][1], pk[gq + 1][1], false, false);
+#if XDBG & 16
+                    if (qrow < row_end) {
+                        *reinterpret_cast<u2v*>(obase + qrow * p.ldo + db * 32 + 8 * gq + 4 * hi) = pk[gq];
+                        *reinterpret_cast<u2v*>(obase + qrow * p.ldo + db * 32 + 8 * (gq + 1) + 4 * hi) = pk[gq + 1];
+                    }
+                    (void)s0; (void)s1;
+#else
                     const u4v w = {s0[0], s1[0], s0[1], s1[1]};
                     __builtin_amdgcn_raw_buffer_store_b128(w, srd_o, ov, (db * 32 + gq * 8) * 2, 0);
                     asm volatile("s_nop 1" : : "v"(w));          // (the wide-store rule again)
+#endif
                 }
             }
         }
