@@ -35,7 +35,8 @@ extern "C" {
 /* 2: groupnorm stats are (mean, biased variance); vcx_tune_*.  3: vcx_gemm_desc grows ln_stats / ln_colsum (VCX_GEMM_LNFOLD*),
  * vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32.  5: vcx_gemm_desc starts with
  * struct_size - a descriptor of another layout is rejected instead of read past its end; ldcs; vcx_clip_preprocess_f32,
- * vcx_add_nchw_f32_to_nhwc_f16.  6: vcx_ddim_ws_bytes, ws_bytes argument of the DDIM steps.  7: vcx_groupnorm_fold_linear_f16. */
+ * vcx_add_nchw_f32_to_nhwc_f16.  6: vcx_ddim_ws_bytes, ws_bytes argument of the DDIM steps.  7: vcx_groupnorm_fold_linear_f16,
+ * vcx_gemm_units_f16. */
 #define VCX_ABI_VERSION 7
 
 int vcx_abi_version(void);
@@ -119,6 +120,12 @@ typedef struct vcx_gemm_desc {
 } vcx_gemm_desc;
 
 int vcx_gemm_f16(const vcx_gemm_desc* desc_host, void* stream);
+/* The same linear layer with ONE weight / bias set per `unit_rows` consecutive rows: rows [u unit_rows, (u + 1) unit_rows) use
+ * W + u w_unit_stride and bias + u bias_unit_stride (element strides) - the (Wn, bn) sets of vcx_groupnorm_fold_linear_f16, one per
+ * frame (SpatialTransformer.norm -> proj_in, attention.py:265-269,299) or per video (TemporalTransformer, attention.py:331-336,369-372).
+ * Linear mode, VCX_GEMM_BIAS_N at most, M a whole number of units.  N = K = 320 with unit_rows % 32 == 0 runs as ONE launch of the
+ * weight-stationary kernel (a block keeps its unit's weights in registers); every other shape unit by unit through vcx_gemm_f16. */
+int vcx_gemm_units_f16(const vcx_gemm_desc* desc_host, int unit_rows, int64_t w_unit_stride, int64_t bias_unit_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * GroupNorm(32 groups) on channels-last fp16 with fp32 statistics.

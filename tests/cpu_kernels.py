@@ -85,6 +85,16 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
     return out
 
 
+def gemm_units(a, wn, bn, *, unit_rows, out=None):
+    M, K = a.shape
+    units, N, _ = wn.shape
+    if out is None:
+        out = torch.empty((M, N), dtype=_f16)
+    for u in range(units):
+        gemm(a[u * unit_rows:], wn[u], M=unit_rows, N=N, K=K, lda=a.stride(0), out=out[u * unit_rows:], ldc=out.stride(0), bias=bn[u])
+    return out
+
+
 def group_norm_stats_from_colstats(colstats, n_outer, pixels, C, groups=32):
     strips = pixels // 64
     cs = colstats.view(n_outer, strips, -1, 2)[:, :, :C].double()
@@ -232,7 +242,7 @@ def install(monkeypatch):
     from viewcrafter_amd import _lib, ops
     _TUNE.clear()
     table = dict(require_gpu=lambda: None, gemm=gemm, group_norm_stats_from_colstats=group_norm_stats_from_colstats, group_norm=group_norm,
-                 group_norm_stats=group_norm_stats, group_norm_fold_linear=group_norm_fold_linear,
+                 group_norm_stats=group_norm_stats, group_norm_fold_linear=group_norm_fold_linear, gemm_units=gemm_units,
                  row_stats=row_stats, layer_norm=layer_norm, flash_attn=flash_attn, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn,
                  softmax_rows_=softmax_rows_, copy2d=copy2d, add_nchw_=add_nchw_, ncthw_to_nthwc=ncthw_to_nthwc, nthwc_to_ncthw=nthwc_to_ncthw,
                  timestep_embedding=timestep_embedding, silu_f32=lambda x: F.silu(x.float()), gelu_=lambda x: x.copy_(F.gelu(x.float()).to(_f16)),

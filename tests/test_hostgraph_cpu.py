@@ -51,7 +51,7 @@ def test_host_graph_of_the_unet_vs_reference_golden(monkeypatch, level, tag, sha
 
 @pytest.mark.parametrize("level", [2, 0])
 @pytest.mark.parametrize("tag,shape,L", [("perframe", (1, 4, 32, 16), 77 + 64), ("shared", (2, 3, 16, 32), 77 + 40)])
-def test_host_graph_with_the_temporal_groupnorm_folded_into_proj_in(monkeypatch, level, tag, shape, L):
+def test_host_graph_with_the_transformer_groupnorms_folded_into_proj_in(monkeypatch, level, tag, shape, L):
     """TemporalTransformer.norm as per-video weights / bias of proj_in (vcx_groupnorm_fold_linear_f16 + one GEMM per video) at EVERY
     level of the tiny graph (the product folds from 16 MB per video up): statistics from the producer's moments (level 2) or from
     a statistics pass (level 0), two videos with different statistics ("shared": b = 2), against the reference golden."""
@@ -60,6 +60,8 @@ def test_host_graph_with_the_temporal_groupnorm_folded_into_proj_in(monkeypatch,
     m, _ = _unet(monkeypatch, level)
     monkeypatch.setattr(attention, "GN_FOLD", True)
     monkeypatch.setattr(attention, "GN_FOLD_MIN_BYTES", 0)
+    # ... and SpatialTransformer.norm as per-FRAME weights (the product: only where vcx_gemm_units_f16 takes all frames in one launch)
+    monkeypatch.setattr(attention, "spatial_fold_ok", lambda n, pixels, C, D: pixels % 8 == 0)
     calls = dict(fold=0, videos=0)
     fold = ops.group_norm_fold_linear
 
@@ -76,9 +78,10 @@ def test_host_graph_with_the_temporal_groupnorm_folded_into_proj_in(monkeypatch,
         y = m(x, torch.tensor([999, 399][:b]), context=ctx, fs=torch.tensor([10, 3][:b]))
     e = rel_l2(y, g[f"unet_out_{tag}"])
     n_tt = sum(isinstance(mod, attention.TemporalTransformer) for mod in m.modules())
-    print(f"temporal GroupNorm folded into proj_in ({calls['fold']} of {n_tt} temporal transformers, {calls['videos']} weight sets), GN statistics level "
-          f"{level}, {tag}: rel-L2 vs the reference golden = {e:.3e}")
-    assert calls["fold"] == n_tt and calls["videos"] == n_tt * b
+    n_st = sum(isinstance(mod, attention.SpatialTransformer) for mod in m.modules())
+    print(f"GroupNorm folded into proj_in ({calls['fold']} of {n_tt} temporal + {n_st} spatial transformers, {calls['videos']} weight sets), GN statistics "
+          f"level {level}, {tag}: rel-L2 vs the reference golden = {e:.3e}")
+    assert calls["fold"] == n_tt + n_st and calls["videos"] == n_tt * b + n_st * b * t
     assert y.shape == g[f"unet_out_{tag}"].shape and e <= UNET_TOL
 
 

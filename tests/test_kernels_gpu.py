@@ -398,6 +398,29 @@ def test_groupnorm_folded_into_the_linear_layer_behind_it(n, pix, C, N, offset, 
         assert torch.equal(w1[0], wn[1]) and torch.equal(b1[0], bn[1])
 
 
+@pytest.mark.parametrize("units,unit_rows,C,N", [(50, 9216, 320, 320), (2, 230400, 320, 320), (25, 9216, 320, 320), (3, 1056, 320, 320), (7, 4096, 320, 320),
+                                                 (300, 1024, 320, 320), (2, 2304, 640, 640), (4, 1000, 320, 320), (3, 640, 320, 960)])
+def test_gemm_with_one_weight_set_per_unit_of_rows(units, unit_rows, C, N):
+    """vcx_gemm_units_f16: one (weights, bias) set per unit of rows - a folded GroupNorm's per-frame / per-video sets.  N = K = 320 with
+    whole 32-row tiles per unit is ONE launch of the weight-stationary kernel (blocks share out the units; more units than CUs, a
+    single 32-row tile stream per block, 25 / 50 frames of the benchmark); everything else runs unit by unit.  Bit-identical to one
+    vcx_gemm_f16 per unit either way; guard rows behind the output stay untouched."""
+    from viewcrafter_amd import ops
+    M = units * unit_rows
+    x = rnd(M, C, seed=471).to(DEV).half()
+    wn = (rnd(units, N, C, seed=472) / math.sqrt(C)).to(DEV).half()
+    bn = rnd(units, N, seed=473).to(DEV)
+    out = torch.full((M + 64, N), 7.0, device=DEV, dtype=torch.float16)
+    ops.gemm_units(x, wn, bn, unit_rows=unit_rows, out=out[:M])
+    ref = torch.empty(M, N, device=DEV, dtype=torch.float16)
+    for u in range(units):
+        ops.gemm(x[u * unit_rows:], wn[u], M=unit_rows, N=N, K=C, lda=C, out=ref[u * unit_rows:], ldc=N, bias=bn[u])
+    assert torch.equal(out[:M], ref)
+    assert (out[M:] == 7.0).all()
+    u = units - 1
+    check(out[u * unit_rows:M], x[u * unit_rows:].float() @ wn[u].float().t() + bn[u], tol=2e-3, name="gemm_units last unit")
+
+
 @pytest.mark.parametrize("kind,n,H,W,cin,cout,offset", [
     ("3x3", 3, 16, 32, 64, 320, 0.0),            # group width 10: a lane's 4-column piece straddles two groups
     ("3x3", 2, 8, 8, 128, 640, 0.0),             # one 64-row strip per frame

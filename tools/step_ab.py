@@ -5,6 +5,7 @@ knobs, variants interleaved round by round.  Prints ms per step and the per-fami
 
 A variant is  name:key=value,key=value  with keys
     gnfold   0 | 1   TemporalTransformer.norm folded into proj_in (viewcrafter_amd/lvdm/modules/attention.py GN_FOLD)
+    gnspatial 0 | 1  ... and SpatialTransformer.norm at level 0 (GN_FOLD_SPATIAL)
     lnff     0 | 1   LayerNorm folded into the GEGLU projection (FOLD_LAYERNORM_FF)
     xattn    1 | 2   resident cross-attention kernel: second form | first form (knob XATTN_RESIDENT)
     ws       1 | 0   weight-stationary K = 320 kernel (knob GEMM_WS)
@@ -65,6 +66,7 @@ def main():
 
     def apply(settings):
         attention.GN_FOLD = settings.get("gnfold", "1") != "0"
+        attention.GN_FOLD_SPATIAL = settings.get("gnspatial", "1") != "0"
         lnff = settings.get("lnff", "0") == "1"
         if lnff != attention.FOLD_LAYERNORM_FF:
             attention.FOLD_LAYERNORM_FF = lnff
@@ -76,6 +78,7 @@ def main():
 
     def run(settings, steps, profile):
         apply(settings)
+        torch.manual_seed(7)                         # the eta = 1 noise of every run is the same draw
         x = x0.clone()
         with torch.no_grad():
             x = one_step(x, 0)                       # packs / caches of this variant

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvcx.so")
 
 # every symbol include/vcx.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
-    "vcx_abi_version", "vcx_last_error", "vcx_device_arch", "vcx_gemm_f16",
+    "vcx_abi_version", "vcx_last_error", "vcx_device_arch", "vcx_gemm_f16", "vcx_gemm_units_f16",
     "vcx_groupnorm_ws_bytes", "vcx_groupnorm_stats_f16", "vcx_groupnorm_apply_f16", "vcx_groupnorm_stats_from_colstats_f32", "vcx_groupnorm_fold_linear_f16", "vcx_layernorm_f16", "vcx_rowstats_f16",
     "vcx_attn_flash_d64_f16", "vcx_attn_flash_dual_d64_f16", "vcx_attn_temporal_d64_f16", "vcx_softmax_rows_f16",
     "vcx_silu_f32", "vcx_gelu_f16", "vcx_clip_preprocess_f32", "vcx_add_nchw_f32_to_nhwc_f16", "vcx_timestep_embedding_f32", "vcx_cast_f32_to_f16", "vcx_cast_f16_to_f32",
@@ -74,6 +74,7 @@ def lib():
     L.vcx_last_error.restype = c_char_p
     L.vcx_device_arch.argtypes = [c_char_p, c_int]
     L.vcx_gemm_f16.argtypes = [POINTER(GemmDesc), c_void_p]
+    L.vcx_gemm_units_f16.argtypes = [POINTER(GemmDesc), c_int, c_int64, c_int64, c_void_p]
     L.vcx_groupnorm_ws_bytes.argtypes = [c_int, c_int64, c_int]
     L.vcx_groupnorm_stats_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]
     L.vcx_groupnorm_apply_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,

@@ -557,8 +557,8 @@ __device__ __forceinline__ void row_halves(float x, float& lo, float& hi) {
     hi = __builtin_bit_cast(float, r1);
 }
 
-#ifndef XDBG
-#define XDBG 0        // debug builds (tools/xattn_debug.py): 1 K fragments read where used, 4 exact row maximum ahead of the ballot, 8 Q rows loaded where used, 16 scalar 8-byte stores
+#ifndef XABL
+#define XABL 0        // timing-only ablations (tools/xattn_ablate.py; garbage results): 1 no exp2, 2 no softmax arithmetic at all, 4 no MFMAs, 8 no Q loads / O stores, 16 no fragment reads in the loop, 32 no max / rescale branch
 #endif
 __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p, unsigned q_bytes, unsigned o_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -651,12 +651,9 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
     read_k(0, kf);
     for (int64_t r0 = row_begin + wave * 64; r0 < row_end; r0 += 512) {       // this wave's two 32-row query blocks
         h8 qf[2][4];
-#if XDBG & 8
-        load_q(r0, qn);
-#endif
 #pragma unroll
         for (int i = 0; i < 8; ++i) qf[i >> 2][i & 3] = __builtin_bit_cast(h8, qn[i]);
-#if !(XDBG & 8)
+#if !(XABL & 8)
         load_q(r0 + 512, qn);                                                 // the next iteration's rows (zeros past the end)
 #endif
         f16v oacc[2][2];
@@ -703,6 +700,11 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
             const half_t* cV = sV + ((second ? T1 : 0) + (jj >> 1)) * 4096;
             // ---- V^T fragments of this half tile (used behind the softmax), then the scores
             h8 vf[2][2];
+#if XABL & 16
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { vf[s][0] = qf[0][s]; vf[s][1] = qf[1][s]; }
+            if (0)
+#endif
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -712,17 +714,21 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
                     vf[s][db] = h8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
                 }
             f16v sacc[2];
-#if XDBG & 1
-            read_k(j, kf);
-#endif
+#if XABL & 4
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[b][r] = (float)kf[r & 3][r >> 2] + (float)qf[b][r & 3][r >> 2];
+#else
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[b][s], s == 0 ? zero16 : sacc[b], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             // ---- K fragments of the next half tile (of the next iteration's first one behind the last): a softmax ahead of their use
-#if !(XDBG & 1)
+#if !(XABL & 16)
             read_k(j + 1 < nh ? j + 1 : 0, kf);
 #endif
             __builtin_amdgcn_sched_barrier(0);
@@ -735,16 +741,20 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
                         if (key >= nk) sacc[b][r] = -1e30f;
                     }
             }
+#if XABL & 2
+            if (0)
+#endif
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 float mx = sacc[b][0];
+#if XABL & 32
+                mx = 0.f;
+                if (0)
+#endif
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
-#if XDBG & 4
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-#endif
                 const float cand = mx * scale;                                           // this lane's 16 of the row's 32 keys
-                if (__builtin_amdgcn_ballot_w64(cand > m_run[b] + FLASH_DEFER) != 0) {   // deferred max, as in flash_d64_kernel
+                if (!(XABL & 32) && __builtin_amdgcn_ballot_w64(cand > m_run[b] + FLASH_DEFER) != 0) {   // deferred max, as in flash_d64_kernel
                     float c_lo, c_hi;
                     row_halves(cand, c_lo, c_hi);
                     const float m_new = fmaxf(m_run[b], fmaxf(c_lo, c_hi));
@@ -758,13 +768,24 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
                 float psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#if XABL & 1
+                    const float pv = __builtin_fmaf(sacc[b][r], scale, -m_use);
+#else
                     const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][r], scale, -m_use));
+#endif
                     sacc[b][r] = pv;
                     psum += pv;
                 }
                 l_run[b] += psum;
             }
             // ---- O^T += V^T P^T
+#if XABL & 4
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[b][0][r] += sacc[b][r] * (float)vf[0][0][r & 7]; oacc[b][1][r] += sacc[b][r] * (float)vf[1][1][r & 7]; }
+            if (0)
+#endif
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 h8 pf[2];
@@ -807,17 +828,12 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
                 for (int gq = 0; gq < 4; gq += 2) {
                     const auto s0 = __builtin_amdgcn_permlane32_swap(pk[gq][0], pk[gq + 1][0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(pk[gq][1], pk[gq + 1][1], false, false);
-#if XDBG & 16
-                    if (qrow < row_end) {
-                        *reinterpret_cast<u2v*>(obase + qrow * p.ldo + db * 32 + 8 * gq + 4 * hi) = pk[gq];
-                        *reinterpret_cast<u2v*>(obase + qrow * p.ldo + db * 32 + 8 * (gq + 1) + 4 * hi) = pk[gq + 1];
-                    }
-                    (void)s0; (void)s1;
-#else
                     const u4v w = {s0[0], s1[0], s0[1], s1[1]};
+#if XABL & 8
+                    if (w[0] == 0x12345678u)
+#endif
                     __builtin_amdgcn_raw_buffer_store_b128(w, srd_o, ov, (db * 32 + gq * 8) * 2, 0);
                     asm volatile("s_nop 1" : : "v"(w));          // (the wide-store rule again)
-#endif
                 }
             }
         }

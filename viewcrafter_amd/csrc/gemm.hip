@@ -480,6 +480,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.ln_colsum = d->ln_colsum;
     a.colstats = d->colstats;
     a.ldcs = d->ldcs > 0 ? d->ldcs : d->N;
+    a.unit_rows = 0; a.units = 1; a.w_unit_stride = 0; a.bias_unit_stride = 0;
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * (double)d->N * d->K;
     const double bytes = 2.0 * ((double)d->M * d->K / (conv ? d->kh * d->kw : 1) + (double)d->N * d->K + (double)d->M * d->N);
@@ -553,4 +554,45 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     VCX_REQUIRE(!(flags & VCX_GEMM_COLSTATS), "vcx_gemm_f16: COLSTATS needs the DMA kernel (K / cin %% 64 == 0, extents < 4 GiB); K=%d cin=%d", d->K, d->cin);
     VCX_REQUIRE(!lnf, "vcx_gemm_f16: LNFOLD needs the DMA kernel (K %% 64 == 0, N %% 8 == 0, extents < 4 GiB); K=%d N=%d", d->K, d->N);
     return use160 ? dispatch<160>(a, conv, geglu, f32, s) : dispatch<128>(a, conv, geglu, f32, s);
+}
+
+// One weight / bias set per unit of rows (include/vcx.h): the weight-stationary kernel in ONE launch where it applies (N = K = 320, the
+// level-0 projections: a block keeps its unit's weights in registers anyway), otherwise unit by unit through vcx_gemm_f16.
+extern "C" int vcx_gemm_units_f16(const vcx_gemm_desc* d, int unit_rows, int64_t w_unit_stride, int64_t bias_unit_stride, void* stream) {
+    VCX_REQUIRE(d != nullptr && d->struct_size == sizeof(vcx_gemm_desc), "vcx_gemm_units_f16: null descriptor or wrong struct_size");
+    VCX_REQUIRE(d->A && d->W && d->C && d->M > 0 && d->N > 0 && d->K > 0, "vcx_gemm_units_f16: null A/W/C or empty problem");
+    VCX_REQUIRE(d->mode == 0 && !(d->flags & ~VCX_GEMM_BIAS_N), "vcx_gemm_units_f16: linear layers with a per-column bias at most (mode %d flags 0x%x)", d->mode, d->flags);
+    VCX_REQUIRE(unit_rows > 0 && d->M % unit_rows == 0, "vcx_gemm_units_f16: M (%d) must be a whole number of units of %d rows", d->M, unit_rows);
+    VCX_REQUIRE(w_unit_stride % 8 == 0 && bias_unit_stride % 4 == 0, "vcx_gemm_units_f16: unit strides must keep W 16-byte and bias 16-byte aligned");
+    VCX_REQUIRE(!(d->flags & VCX_GEMM_BIAS_N) || d->bias, "vcx_gemm_units_f16: bias flag without bias");
+    VCX_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldc % 8 == 0 && (((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C) & 15) == 0 && ((uintptr_t)d->bias & 15) == 0,
+                "vcx_gemm_units_f16: strides must be multiples of 8, pointers 16-byte aligned");
+    const int units = d->M / unit_rows;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned long long lim = 0xFFFF0000ull;
+    const unsigned long long a_ext = 2ull * ((unsigned long long)(d->M - 1) * d->lda + d->K), c_ext = 2ull * ((unsigned long long)(d->M - 1) * d->ldc + d->N);
+    if (units > 1 && d->K == 320 && d->N == 320 && unit_rows % 32 == 0 && unit_rows >= 1024 && d->M >= 8192 && a_ext < lim &&
+        2ull * (unsigned long long)(d->M + 256) * d->ldc < lim && units <= 65535 && vcx_tune(VCX_TUNE_GEMM_DMA) != 0 && vcx_tune(VCX_TUNE_GEMM_WS) != 0 &&
+        force_cfg_unset()) {
+        GemmArgs a{};
+        a.A = (const half_t*)d->A; a.W = (const half_t*)d->W; a.C = d->C; a.bias = d->bias;
+        a.lda = d->lda; a.M = d->M; a.N = d->N; a.K = d->K; a.ldw = d->ldw; a.ldc = d->ldc; a.ldr = 0;
+        a.rowadd_div = 1; a.flags = d->flags; a.alpha = d->alpha; a.m_begin = 0;
+        a.ldcs = d->N;
+        a.a_bytes = (unsigned)a_ext; a.c_bytes = (unsigned)c_ext; a.w_bytes = 0; a.r_bytes = 0;
+        a.unit_rows = unit_rows; a.units = units; a.w_unit_stride = w_unit_stride; a.bias_unit_stride = bias_unit_stride;
+        VcxProfScope prof(VCX_FAM_GEMM, s, 2.0 * d->M * (double)d->N * d->K, 2.0 * ((double)d->M * d->K + (double)units * d->N * d->K + (double)d->M * d->N));
+        return launch_ws320_units(a, s);
+    }
+    for (int u = 0; u < units; ++u) {
+        vcx_gemm_desc du = *d;
+        du.A = (const half_t*)d->A + (int64_t)u * unit_rows * d->lda;
+        du.C = (half_t*)d->C + (int64_t)u * unit_rows * d->ldc;
+        du.W = (const half_t*)d->W + (int64_t)u * w_unit_stride;
+        if (d->bias) du.bias = d->bias + (int64_t)u * bias_unit_stride;
+        du.M = unit_rows;
+        const int rc = vcx_gemm_f16(&du, stream);
+        if (rc) return rc;
+    }
+    return VCX_OK;
 }

@@ -30,6 +30,9 @@ struct GemmArgs {
     const float* ln_colsum;   // VCX_GEMM_LNFOLD[_T]: row sums of the folded weight
     float* colstats;          // VCX_GEMM_COLSTATS: (mean, M2) per 64-row strip and output column
     int64_t ldcs;             // columns per strip of colstats (>= N: the buffer may hold a concatenated partner's columns too)
+    // vcx_gemm_units_f16 (weight-stationary kernel only): one weight / bias set per unit_rows consecutive rows; 0 = one set for all
+    int unit_rows, units;
+    int64_t w_unit_stride, bias_unit_stride;      // elements between consecutive units' weights / biases
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -118,6 +121,7 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
 
 int persistent_grid(int ntiles, int blocks_per_cu = 2);
 int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);
+int launch_ws320_units(GemmArgs& a, hipStream_t s);  // ... with one weight / bias set per unit of rows (vcx_gemm_units_f16)
 int launch_ws320(GemmArgs& a, hipStream_t s);        // gemm_ws.hip: weight-stationary linear layer, N = K = 320 (plain / COLSTATS epilogues)   // a.flags & VCX_GEMM_LNFOLD[_T] selects the folded-LayerNorm epilogue
 
 }  // namespace vcxgemm

@@ -230,10 +230,25 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
 
-    const int ntiles = p.tiles_m;
+    int ntiles = p.tiles_m;
     const int cb = (blockIdx.x >> 3) % p.tiles_n;
-    const int G = gridDim.x / p.tiles_n;
-    const int t_first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) / p.tiles_n;
+    int G = gridDim.x / p.tiles_n;
+    int t_first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) / p.tiles_n;
+    if constexpr (!RES) {
+        // vcx_gemm_units_f16: one weight / bias set per unit of unit_rows rows (a GroupNorm folded into this projection has one per
+        // frame or per video).  gridDim.x / units consecutive blocks share a unit; a block keeps that unit's weights for its
+        // lifetime and walks the unit's row tiles only (N = 320: one column block; unit_rows % 32 == 0: no tile straddles two units).
+        if (p.unit_rows > 0) {
+            const int bpu = gridDim.x / p.units, unit = blockIdx.x / bpu;
+            p.m_begin += unit * p.unit_rows;
+            p.M = p.m_begin + p.unit_rows;
+            p.W += (int64_t)unit * p.w_unit_stride;
+            if (p.flags & VCX_GEMM_BIAS_N) p.bias += (int64_t)unit * p.bias_unit_stride;
+            ntiles = p.unit_rows / WpCfg::TBM;
+            G = bpu;
+            t_first = blockIdx.x % bpu;
+        }
+    }
     const int ncol0 = cb * WpCfg::TBN;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -420,6 +435,21 @@ int launch_ws(const GemmArgs& a, hipStream_t s) {
 
 // Linear mode, K = 320, N = 320 j (j <= 4), fp16 output, no GEGLU / LNFOLD / LNFOLD_T / BIAS_M,
 // 32-bit operand and output extents (the caller checks; it also fills a_bytes / c_bytes / r_bytes).  Sets the tiling itself.
+// One launch, `units` weight / bias sets (vcx_gemm_units_f16): N = K = 320, bias at most, unit_rows % 32 == 0 (the caller checks).
+int vcxgemm::launch_ws320_units(GemmArgs& a, hipStream_t s) {
+    static VcxLdsAttr lds;
+    auto kern = gemm_ws320_pipe_kernel<false>;
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WP_SMEM, "vcx_gemm_units_f16(ws320 pipe)")) return VCX_ELAUNCH;
+    a.tiles_n = 1;
+    a.tiles_m = a.unit_rows / WpCfg::TBM;
+    const int cus = persistent_grid(1 << 30, 1);
+    int bpu = cus / a.units;                        // blocks per unit: the chip's CUs shared out, at least one, at most one per row tile
+    if (bpu < 1) bpu = 1;
+    if (bpu > a.tiles_m) bpu = a.tiles_m;
+    hipLaunchKernelGGL(kern, dim3(bpu * a.units), dim3(WpCfg::THREADS), WP_SMEM, s, a, a.a_bytes);
+    return vcx_check_launch("vcx_gemm_units_f16(ws320 pipe)");
+}
+
 int vcxgemm::launch_ws320(GemmArgs& a, hipStream_t s) {
     a.tiles_m = (a.M - a.m_begin + WsCfg::TBM - 1) / WsCfg::TBM;
     a.tiles_n = a.N / WsCfg::TBN;

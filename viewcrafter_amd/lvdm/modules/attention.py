@@ -39,13 +39,23 @@ FOLD_LAYERNORM = os.environ.get("VCX_LN_FOLD", "1") != "0"
 FOLD_LAYERNORM_FF = os.environ.get("VCX_LN_FOLD_FF", "0") == "1"
 
 
-# TemporalTransformer.norm -> proj_in (reference attention.py:331-336,369-372): a GroupNorm without SiLU in front of a linear layer
-# is an affine map per (video, channel), so it runs as per-video scaled weights and bias of the projection
-# (vcx_groupnorm_fold_linear_f16 + one GEMM per video on the UN-normalised rows) and the normalised copy of the tensor is neither
-# written nor re-read.  Where a video's tensor is smaller than GN_FOLD_MIN_BYTES the apply pass is cheaper than a second launch.
-# VCX_GN_FOLD=0: the separate apply pass everywhere (A/B runs, tools/step_ab.py).
+# TemporalTransformer.norm -> proj_in (reference attention.py:331-336,369-372) and SpatialTransformer.norm -> proj_in (:265-269,299):
+# a GroupNorm without SiLU in front of a linear layer is an affine map per (statistics unit, channel), so it runs as per-unit scaled
+# weights and bias of the projection (vcx_groupnorm_fold_linear_f16 + vcx_gemm_units_f16 on the UN-normalised rows) and the normalised
+# copy of the tensor is neither written nor re-read.  Temporal norms (unit = video): wherever a video's tensor is at least
+# GN_FOLD_MIN_BYTES (below that the apply pass is cheaper than a launch per video).  Spatial norms (unit = frame, 50 of them): only
+# where all frames go through ONE launch - the weight-stationary kernel at C = 320, level 0 of the UNet, whose blocks keep a weight
+# set in registers anyway.  VCX_GN_FOLD=0: the separate apply pass everywhere (A/B runs, tools/step_ab.py).
 GN_FOLD = os.environ.get("VCX_GN_FOLD", "1") != "0"
 GN_FOLD_MIN_BYTES = int(os.environ.get("VCX_GN_FOLD_MIN_BYTES", str(16 << 20)))
+GN_FOLD_SPATIAL = os.environ.get("VCX_GN_FOLD_SPATIAL", "1") != "0"
+
+
+def spatial_fold_ok(n, pixels, C, D):
+    """Does vcx_gemm_units_f16 take n frames of `pixels` rows in ONE weight-stationary launch (csrc/gemm.hip)?"""
+    return (GN_FOLD and GN_FOLD_SPATIAL and n > 1 and C == 320 and D == 320 and pixels % 32 == 0 and pixels >= 1024 and n * pixels >= 8192
+            and 2 * n * pixels * C >= GN_FOLD_MIN_BYTES and 2 * (n * pixels + 256) * C < 0xFFFF0000 and ops.tune_get("GEMM_DMA") != 0
+            and ops.tune_get("GEMM_WS") != 0)
 
 
 def _ln_projection(w, ln, alpha=1.0, bias=None):
@@ -333,7 +343,7 @@ class SpatialTransformer(PackedModule):
         self.use_linear = use_linear
 
     def _pack(self):
-        return dict(gn_w=_f32(self.norm.weight), gn_b=_f32(self.norm.bias), win=_f16(self.proj_in.weight),
+        return dict(gn_w=_f32(self.norm.weight), gn_b=_f32(self.norm.bias), win=_f16(self.proj_in.weight), win32=_f32(self.proj_in.weight),
                     bin=_f32(self.proj_in.bias), wout=_f16(self.proj_out.weight), bout=_f32(self.proj_out.bias))
 
     def project_context(self, ctx):
@@ -353,7 +363,9 @@ class SpatialTransformer(PackedModule):
         pk = self.packed()
         # colstats: column moments of x from the convolution that produced it (ResBlock): the norm then needs no statistics pass
         stats = None if colstats is None else ops.group_norm_stats_from_colstats(colstats, n, N_img, C)
-        a = ops.group_norm(x.view(n, N_img, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False, stats=stats)
+        D_in = pk["win"].shape[0]
+        fold = N_img % 8 == 0 and spatial_fold_ok(n, N_img, C, D_in)      # the norm as per-frame weights / bias of proj_in
+        a = None if fold else ops.group_norm(x.view(n, N_img, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False, stats=stats)
         # The attention kernels address a frame's keys / values at 16-byte granularity: h*w must be a multiple of 8.  It is at every
         # level of 576x1024 and 320x512; for other --height / --width (e.g. 384x640: 6x10 = 60 tokens at the deepest level) each
         # frame's token rows are padded with zero rows up to the next multiple of 8 for the length of this block - all its layers
@@ -367,7 +379,13 @@ class SpatialTransformer(PackedModule):
                 return dst
             xin, a = pad_frames(xin), pad_frames(a.view(n * N_img, C))
         tokens = n * N
-        t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
+        if fold:
+            if stats is None:
+                stats = ops.group_norm_stats(x.view(n, N_img, C))
+            wn, bn = ops.group_norm_fold_linear(pk["win32"], pk["bin"], pk["gn_w"], pk["gn_b"], stats, self.norm.eps)
+            t = ops.gemm_units(xin, wn, bn, unit_rows=N_img)
+        else:
+            t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
         D, heads = t.shape[1], self.n_heads
         for bi, (blk, kv) in enumerate(zip(self.transformer_blocks, context_kv)):
             ln = blk.ln_params()
@@ -468,9 +486,7 @@ class TemporalTransformer(PackedModule):
             if stats is None:
                 stats = ops.group_norm_stats(x.view(B, rows, C))
             wn, bn = ops.group_norm_fold_linear(pk["win32"], pk["bin"], pk["gn_w"], pk["gn_b"], stats, self.norm.eps)
-            t = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
-            for b in range(B):
-                ops.gemm(xin[b * rows:], wn[b], M=rows, N=D, K=C, lda=C, out=t[b * rows:], ldc=D, bias=bn[b])
+            t = ops.gemm_units(xin, wn, bn, unit_rows=rows)
         else:
             a = ops.group_norm(x.view(B, rows, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False, stats=stats)
             t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])

@@ -114,6 +114,25 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
     return out
 
 
+def gemm_units(a, wn, bn, *, unit_rows, out=None):
+    """out[M, N] = a[M, K] Wn[u]^T + bn[u] for the rows of unit u = m // unit_rows: wn [units, N, K] fp16, bn [units, N] fp32 (the
+    sets of group_norm_fold_linear).  One launch of the weight-stationary kernel where it applies, else unit by unit (include/vcx.h)."""
+    M, K = a.shape
+    units, N, K2 = wn.shape
+    _dev16(a, wn, out)
+    _dev32(bn)
+    if K2 != K or M != units * unit_rows or tuple(bn.shape) != (units, N) or not wn.is_contiguous() or not bn.is_contiguous():
+        raise VcxError(f"gemm_units: a {tuple(a.shape)} / wn {tuple(wn.shape)} / bn {tuple(bn.shape)} do not describe {units} units of {unit_rows} rows")
+    if out is None:
+        out = torch.empty((M, N), dtype=_f16, device=a.device)
+    d = GemmDesc()
+    d.A, d.W, d.C, d.bias = a.data_ptr(), wn.data_ptr(), out.data_ptr(), bn.data_ptr()
+    d.lda, d.M, d.N, d.K, d.ldw, d.ldc = a.stride(0), M, N, K, K, out.stride(0)
+    d.flags, d.alpha = GEMM_BIAS_N, 1.0
+    check(lib().vcx_gemm_units_f16(ctypes.byref(d), int(unit_rows), N * K, N, _stream()), "vcx_gemm_units_f16")
+    return out
+
+
 def lnfold_ok(rows, n_out, K, *, lda=None, ldc=None, transposed=False):
     """Will vcx_gemm_f16 take a folded-LayerNorm projection (VCX_GEMM_LNFOLD / _T) of `rows` token rows x K channels onto n_out
     outputs?  The epilogue exists in the DMA kernel only; this mirrors its preconditions in csrc/gemm.hip (`dma_ok`: knob
