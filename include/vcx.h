@@ -36,7 +36,7 @@ extern "C" {
  * vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32.  5: vcx_gemm_desc starts with
  * struct_size - a descriptor of another layout is rejected instead of read past its end; ldcs; vcx_clip_preprocess_f32,
  * vcx_add_nchw_f32_to_nhwc_f16.  6: vcx_ddim_ws_bytes, ws_bytes argument of the DDIM steps.  7: vcx_groupnorm_fold_linear_f16,
- * vcx_gemm_units_f16. */
+ * vcx_gemm_units_f16, vcx_attn_flash_d512_f16. */
 #define VCX_ABI_VERSION 7
 
 int vcx_abi_version(void);
@@ -207,6 +207,13 @@ int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const void* vt1, 
                                 int nk1, int kv_rows1, int kv_div1, int64_t ldk1, int64_t ldvt1,
                                 int nk2, int kv_rows2, int kv_div2, int64_t ldk2, int64_t ldvt2,
                                 int64_t ldq, int64_t ldo, float scale, int flags, void* stream);
+
+/* Flash attention with ONE head of dim 512, no mask: O = softmax(scale * Q K^T) V - the AttnBlock of the VAE
+ * (lvdm/modules/networks/ae_modules.py:26-78 at 9216 tokens per 576x1024 frame); the score matrix is never materialised.
+ * Group g (a frame): Q rows q + (g*nq)*ldq (512 columns), K rows k + (g*kv_rows)*ldk (nk valid), V^T rows vt + d*ldvt + g*kv_rows
+ * (512 rows d x nk columns), O rows o + (g*nq)*ldo.  kv_rows >= nk, multiple of 8 (rows [nk, kv_rows) must be readable). */
+int vcx_attn_flash_d512_f16(const void* q, const void* k, const void* vt, void* o, int n_groups, int nq, int nk, int kv_rows,
+                            int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, float scale, void* stream);
 
 /* Temporal self-attention over T <= 32 frames per pixel, head dim 64
  * (TemporalTransformer -> CrossAttention.forward, attention.py:365-412, 81-126).

@@ -175,6 +175,15 @@ def flash_attn(q, k, vt, out, *, n_groups, heads, nq, nk, kv_rows, kv_div, ldq, 
     return out
 
 
+def flash_attn_d512(q, k, vt, out, *, n_groups, nq, nk, kv_rows, ldq, ldk, ldvt, ldo, scale):
+    for g in range(n_groups):
+        qm = _view2d(q, nq, 512, ldq, g * nq * ldq).float()
+        km = _view2d(k, nk, 512, ldk, g * kv_rows * ldk).float()
+        vtm = _view2d(vt, 512, nk, ldvt, g * kv_rows).float()
+        _view2d(out, nq, 512, ldo, g * nq * ldo).copy_(((qm @ km.t() * scale).softmax(-1) @ vtm.t()).to(_f16))
+    return out
+
+
 def flash_attn_dual(q, k1, vt1, k2, vt2, out, *, n_groups, heads, nq, nk1, kv_rows1, kv_div1, ldk1, ldvt1, nk2, kv_rows2, kv_div2, ldk2, ldvt2,
                     ldq, ldo, scale, log2_logits=False):
     for g in range(n_groups):
@@ -243,7 +252,7 @@ def install(monkeypatch):
     _TUNE.clear()
     table = dict(require_gpu=lambda: None, gemm=gemm, group_norm_stats_from_colstats=group_norm_stats_from_colstats, group_norm=group_norm,
                  group_norm_stats=group_norm_stats, group_norm_fold_linear=group_norm_fold_linear, gemm_units=gemm_units,
-                 row_stats=row_stats, layer_norm=layer_norm, flash_attn=flash_attn, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn,
+                 row_stats=row_stats, layer_norm=layer_norm, flash_attn=flash_attn, flash_attn_d512=flash_attn_d512, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn,
                  softmax_rows_=softmax_rows_, copy2d=copy2d, add_nchw_=add_nchw_, ncthw_to_nthwc=ncthw_to_nthwc, nthwc_to_ncthw=nthwc_to_ncthw,
                  timestep_embedding=timestep_embedding, silu_f32=lambda x: F.silu(x.float()), gelu_=lambda x: x.copy_(F.gelu(x.float()).to(_f16)),
                  to_f16=lambda x: x.to(_f16).contiguous(), to_f32=lambda x: x.float().contiguous(),

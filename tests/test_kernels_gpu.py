@@ -1009,6 +1009,32 @@ def test_resident_cross_attention_second_form(T, nq, nk1, nk2, gain):
     assert torch.equal(again[:G * nq], outs[1][:G * nq])
 
 
+@pytest.mark.parametrize("n,nq,nk,gain", [(2, 256, 256, 1.0), (3, 136, 135, 1.0), (2, 1000, 1000, 1.0), (1, 2304, 2304, 1.0), (1, 9216, 9216, 1.0),
+                                          (5, 40, 35, 1.0), (2, 512, 512, 8.0), (9, 128, 64, 1.0)])
+def test_flash_attention_one_head_of_512(n, nq, nk, gain):
+    """vcx_attn_flash_d512_f16 - the VAE AttnBlock (reference ae_modules.py:26-78) without a materialised score matrix: frames as
+    groups, key counts that end inside a 32-key tile (135 keys in 136 padded rows: what AttnBlock passes for a 9x15 latent), query
+    counts that leave ragged 16-row waves and 128-row blocks, more groups than XCDs, logits large enough to move the deferred
+    running max (gain), and the 9216-token frame of the 576x1024 decode; bit-reproducible."""
+    from viewcrafter_amd import ops
+    C = 512
+    kv_rows = (nk + 7) // 8 * 8
+    q = (rnd(n * nq, C, seed=661) * gain).to(DEV).half()
+    k = torch.zeros(n, kv_rows, C); v = torch.zeros(n, kv_rows, C)
+    k[:, :nk] = rnd(n, nk, C, seed=662); v[:, :nk] = rnd(n, nk, C, seed=663)
+    k, v = k.to(DEV).half(), v.to(DEV).half()
+    vt = v.reshape(n * kv_rows, C).t().contiguous()                                  # [C, n * kv_rows]
+    out = torch.full((n * nq + 16, C), 7.0, device=DEV, dtype=torch.float16)
+    scale = C ** -0.5
+    ops.flash_attn_d512(q, k.view(n * kv_rows, C), vt, out, n_groups=n, nq=nq, nk=nk, kv_rows=kv_rows, ldq=C, ldk=C, ldvt=n * kv_rows, ldo=C, scale=scale)
+    ref = attn_ref(q.view(n, nq, C), k[:, :nk], v[:, :nk], scale).reshape(n * nq, C)
+    check(out[:n * nq], ref, tol=3e-3, name="flash d512")
+    assert (out[n * nq:] == 7.0).all()
+    again = torch.empty_like(out)
+    ops.flash_attn_d512(q, k.view(n * kv_rows, C), vt, again, n_groups=n, nq=nq, nk=nk, kv_rows=kv_rows, ldq=C, ldk=C, ldvt=n * kv_rows, ldo=C, scale=scale)
+    assert torch.equal(again[:n * nq], out[:n * nq])
+
+
 @pytest.mark.parametrize("B,T,P,heads", [(1, 16, 40, 2), (2, 25, 37, 5), (1, 4, 8, 1)])
 def test_temporal_attention(B, T, P, heads):
     from viewcrafter_amd import ops

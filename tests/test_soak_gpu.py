@@ -149,6 +149,54 @@ def test_attention_and_norm_kernels_are_bit_reproducible_at_the_benchmark_shapes
     _soak(lambda: ops.row_stats(xr, 1e-5), calls, "row statistics")
 
 
+def test_round5_kernels_are_bit_reproducible_at_the_benchmark_shapes():
+    """The kernels of round 5 at the shapes the benchmark gives them, under a full chip: the weight-stationary K = 320 kernel in its plain,
+    residual and one-weight-set-per-frame / per-video forms, the folded-GroupNorm weight builder, both forms of the resident
+    cross-attention kernel (level 0: 9216 queries x 5 heads per frame, 77 + 256 keys per video) and the d = 512 flash kernel of the
+    VAE."""
+    from viewcrafter_amd import ops
+    calls = max(CALLS // 4, 10)
+    M, C = 25 * 9216, 320
+    x = rnd(M, C, seed=31).to(DEV).half()
+    w = (rnd(C, C, seed=32) / math.sqrt(C)).to(DEV).half()
+    bias = rnd(C, seed=33).to(DEV)
+    res = rnd(M, C, seed=34).to(DEV).half()
+    _soak(lambda: ops.linear(x, w, bias), calls, "weight-stationary linear")
+    _soak(lambda: ops.linear(x, w, bias, residual=res), calls, "weight-stationary linear + residual")
+    stats = ops.group_norm_stats(x.view(25, 9216, C))
+    g, b = (1 + 0.2 * rnd(C, seed=35)).to(DEV), (0.1 * rnd(C, seed=36)).to(DEV)
+    w32 = (rnd(C, C, seed=37) / math.sqrt(C)).to(DEV)
+    _soak(lambda: ops.group_norm_fold_linear(w32, bias, g, b, stats, 1e-6), calls, "GroupNorm fold: weight / bias sets")
+    wn, bn = ops.group_norm_fold_linear(w32, bias, g, b, stats, 1e-6)
+    _soak(lambda: ops.gemm_units(x, wn, bn, unit_rows=9216), calls, "one weight set per frame (25 x 9216 rows)")
+    _soak(lambda: ops.gemm_units(x, wn[:5].contiguous(), bn[:5].contiguous(), unit_rows=5 * 9216), calls, "one weight set per 5 frames")
+    # resident cross-attention, level 0 of one video
+    T, nq, heads = 25, 9216, 5
+    q = (rnd(T * nq, C, seed=41) * 0.18).to(DEV).half()
+    kt = torch.zeros(80, C); kt[:77] = rnd(77, C, seed=42); kt = kt.to(DEV).half()
+    vt = torch.zeros(80, C); vt[:77] = rnd(77, C, seed=43); vt_t = vt.to(DEV).half().t().contiguous()
+    ki = rnd(256, C, seed=44).to(DEV).half(); vi_t = rnd(256, C, seed=45).to(DEV).half().t().contiguous()
+    for form in (1, 2):
+        prev = ops.tune_set("XATTN_RESIDENT", form)
+        try:
+            def xattn():
+                o = torch.empty((T * nq, C), dtype=torch.float16, device=DEV)
+                return ops.flash_attn_dual(q, kt, vt_t, ki, vi_t, o, n_groups=T, heads=heads, nq=nq, nk1=77, kv_rows1=80, kv_div1=T, ldk1=C, ldvt1=80,
+                                           nk2=256, kv_rows2=256, kv_div2=T, ldk2=C, ldvt2=256, ldq=C, ldo=C, scale=0.125, log2_logits=True)
+            _soak(xattn, calls, f"resident cross-attention, form {'second' if form == 1 else 'first'}")
+        finally:
+            ops.tune_set("XATTN_RESIDENT", prev)
+    # VAE AttnBlock: 4 frames x 9216 tokens x 512
+    n, N, Cv = 4, 9216, 512
+    qv, kv = rnd(n * N, Cv, seed=51).to(DEV).half(), rnd(n * N, Cv, seed=52).to(DEV).half()
+    vvt = rnd(Cv, n * N, seed=53).to(DEV).half()
+
+    def vae_attn():
+        o = torch.empty((n * N, Cv), dtype=torch.float16, device=DEV)
+        return ops.flash_attn_d512(qv, kv, vvt, o, n_groups=n, nq=N, nk=N, kv_rows=N, ldq=Cv, ldk=Cv, ldvt=n * N, ldo=Cv, scale=Cv ** -0.5)
+    _soak(vae_attn, max(calls // 5, 5), "flash attention, one head of 512")
+
+
 @pytest.mark.parametrize("share_prefix", [True, False])
 def test_b2_unet_forward_at_25x72x128_is_bit_reproducible_over_20_runs(share_prefix):
     """The cond + uncond evaluation of one DDIM step at the headline latent, as the sampler launches it (B = 2, with the shared

@@ -842,6 +842,190 @@ __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p
 }
 
 // =======================================================================================
+// Flash attention, ONE head of d = 512: the AttnBlock of the VAE (reference lvdm/modules/networks/ae_modules.py:26-78: 9216 tokens
+// per 576x1024 frame, softmax(q k^T / sqrt(512)) v).  The score matrix is never written: 170 MB per frame as fp16, which the
+// GEMM -> row softmax -> GEMM sequence of rounds 1-4 wrote, read, rewrote and read again, frame by frame.
+//
+// Swapped formulation as in flash_d64_kernel (S^T = K Q^T, O^T += V^T P^T: the softmax statistics of a query live in the four lanes
+// q, q + 16, q + 32, q + 48 and P feeds the second product without cross-lane movement), on v_mfma_f32_16x16x32_f16 so that a wave's
+// state fits 256 registers: a wave owns 16 queries with Q (16 x 512 fp16 = 64 registers) and O^T (512 x 16 fp32 = 128 registers)
+// resident.  Eight waves per block (128 queries), two per SIMD; K / V^T tiles of 32 keys go HBM -> LDS by DMA, two stages of 64 KB:
+// K as eight [32 keys][64 d] slabs, V^T as eight [64 d][32 keys] slabs with two d rows per 128-byte line, both in the XOR-swizzled
+// line layout of tile_off().  Per tile a wave issues 32 score MFMAs and 32 PV MFMAs around ~70 VALU instructions of softmax: the
+// contraction is eight times as long as at d = 64, the phased order costs little, and the kernel is plain HIP.  LDS traffic is the
+// bound (1 KB fragment per MFMA).
+// =======================================================================================
+struct Flash512Args {
+    const half_t* q;
+    const half_t* k;
+    const half_t* vt;
+    half_t* o;
+    int nq, nk, kv_rows, nqb, nprob;
+    int64_t ldq, ldk, ldvt, ldo;
+    float scale_log2;
+};
+
+// the four lanes q + 16 g of a 16-lane row: all-reduce by two butterfly steps (DPP row_shr is confined to 16 lanes: permute through LDS hardware)
+__device__ __forceinline__ float quad_rows_max(float x) {
+    x = fmaxf(x, __shfl_xor(x, 16));
+    return fmaxf(x, __shfl_xor(x, 32));
+}
+__device__ __forceinline__ float quad_rows_sum(float x) {
+    x += __shfl_xor(x, 16);
+    return x + __shfl_xor(x, 32);
+}
+
+__global__ void __launch_bounds__(512, 1) flash_d512_kernel(Flash512Args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int D = 512, TK = 32, STAGE = 2 * TK * D;           // elements per stage: K tile + V^T tile
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsmem[];
+    half_t* smem = reinterpret_cast<half_t*>(fsmem);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lr = lane & 15, lg = lane >> 4;
+    // all query blocks of one frame on ONE XCD (ids of the same residue mod 8): its K / V^T stream is shared through that L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = (slot / p.nqb) * 8 + xcd;
+    if (g >= p.nprob) return;
+    const int q0 = ((slot % p.nqb) * 8 + wave) * 16;
+
+    // ---- Q fragments (B operand of the score MFMAs): lane (q = lr, lg) holds Q[q][32 s + 8 lg .. + 7], s = 0..15
+    const half_t* qbase = p.q + ((int64_t)g * p.nq) * p.ldq;
+    const int qrow = q0 + lr;
+    const bool qvalid = qrow < p.nq;
+    const half_t* qptr = qbase + (int64_t)(qvalid ? qrow : p.nq - 1) * p.ldq + lg * 8;
+    h8 qf[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qf[s] = *reinterpret_cast<const h8*>(qptr + s * 32);
+
+    // ---- K / V^T streams
+    const half_t* kbase = p.k + ((int64_t)g * p.kv_rows) * p.ldk;
+    const half_t* vbase = p.vt + (int64_t)g * p.kv_rows;
+    const unsigned k_bytes = (unsigned)(((int64_t)(p.nk - 1) * p.ldk + D) * 2);
+    const unsigned v_bytes = (unsigned)(((int64_t)(D - 1) * p.ldvt + ((p.nk + 7) & ~7)) * 2);
+    const __amdgpu_buffer_rsrc_t srd_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kbase), 0, (int)k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vbase), 0, (int)v_bytes, 0x00020000);
+    // DMA map: a slab is 32 lines of 128 bytes = 256 chunks of 16 bytes; thread t takes chunk t & 255 of slabs (t >> 8) + 2 c, c < 4.
+    // LDS line L = (t & 255) >> 3, position t & 7 (lane-linear image), source chunk j = position ^ ((L >> 1) & 7).
+    // K slab: line = key, j = d / 8 inside the slab.  V^T slab: line = two d rows, j = 4 (d & 1) + keys / 8.
+    const int dt = tid & 255, dh = tid >> 8;
+    const int dl = dt >> 3, dc = (dt & 7) ^ ((dl >> 1) & 7);
+    const unsigned koff = (unsigned)((int64_t)dl * p.ldk * 2) + dc * 16 + dh * 128;                                          // + tile * 32 rows; + 256 bytes per c
+    const unsigned voff = (unsigned)((int64_t)(2 * dl + (dc >> 2) + 64 * dh) * p.ldvt * 2) + (dc & 3) * 16;                  // + tile * 64 bytes; + 128 d rows per c
+    const unsigned ktile_bytes = (unsigned)(TK * p.ldk * 2), vslab2_bytes = (unsigned)(128 * p.ldvt * 2);
+    const int wl = (dt >> 6) * 512;                                 // this wave's 8 lines inside a slab (elements)
+    auto load_tile = [&](int kt, int buf) {
+        half_t* dk = smem + buf * STAGE + dh * 2048 + wl;
+        half_t* dv = dk + TK * D;
+        const bool kin = kt * TK + dl < p.nk;                       // key row exists
+        const bool vin = kt * TK + (dc & 3) * 8 < p.nk;             // first key of the V^T chunk exists (nk rounded up to 8 in the extent)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_k, (lds_ptr_t)(dk + c * 4096), 16, kin ? koff + (unsigned)kt * ktile_bytes : 0xFFFFFFFFu, c * 256, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_v, (lds_ptr_t)(dv + c * 4096), 16, vin ? voff + (unsigned)kt * 64u + (unsigned)c * vslab2_bytes : 0xFFFFFFFFu, 0, 0, 0);
+        }
+    };
+
+    // fragment offsets (elements) inside a slab.  K (A operand, 16 keys x 32 d): line = key 16 kb + lr, chunk 4 (s & 1) + lg of slab
+    // s >> 1.  V^T (A operand, 16 d rows x 32 keys): d row 16 i + lr inside the slab (i < 4): line 8 i + (lr >> 1), chunk
+    // 4 (lr & 1) + c; this lane's eight keys are 4 lg .. + 3 (chunk lg >> 1, halves 4 (lg & 1) ..) and 16 + 4 lg .. + 3 (chunk 2 + (lg >> 1)).
+    int ko[2], vo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ko[i] = tile_off(lr, 4 * i + lg);
+        vo[i] = tile_off(lr >> 1, 4 * (lr & 1) + 2 * i + (lg >> 1)) + 4 * (lg & 1);
+    }
+
+    f4 oacc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) oacc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+    const float scale = p.scale_log2;
+
+    const int ntiles = (p.nk + TK - 1) / TK;
+    load_tile(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (kt + 1 < ntiles) load_tile(kt + 1, cur ^ 1);
+        const half_t* cK = smem + cur * STAGE;
+        const half_t* cV = cK + TK * D;
+        // ---- S^T = K Q^T: two blocks of 16 keys, 16 k-steps of 32 d each
+        f4 sacc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const h8 kf = *reinterpret_cast<const h8*>(cK + (s >> 1) * 2048 + kb * 1024 + ko[s & 1]);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], sacc[kb], 0, 0, 0);
+            }
+        // lane (q = lr, lg) holds the scores of keys 16 kb + 4 lg + r
+        const int key_base = kt * TK;
+        if (key_base + TK > p.nk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (key_base + 16 * kb + 4 * lg + r >= p.nk) sacc[kb][r] = -1e30f;
+        }
+        // ---- online softmax (base 2, deferred running max as in flash_d64_kernel: the test is a ballot over the per-lane partial maxima)
+        float mx = fmaxf(fmaxf(fmaxf(sacc[0][0], sacc[0][1]), fmaxf(sacc[0][2], sacc[0][3])), fmaxf(fmaxf(sacc[1][0], sacc[1][1]), fmaxf(sacc[1][2], sacc[1][3])));
+        const float cand = mx * scale;
+        if (__builtin_amdgcn_ballot_w64(cand > m_run + FLASH_DEFER) != 0) {
+            const float m_new = fmaxf(m_run, quad_rows_max(cand));
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[i][r] *= alpha;
+        }
+        h8 pf;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], scale, -m_run));
+                psum += pv;
+                pf[4 * kb + r] = (half_t)pv;
+            }
+        l_run += psum;
+        // ---- O^T += V^T P^T: 32 blocks of 16 d rows, one k-step of 32 keys (this lane's k-slots: keys 4 lg .. + 3, 16 + 4 lg .. + 3)
+#pragma unroll
+        for (int db = 0; db < 32; ++db) {
+            // slab db / 4, d rows 16 (db & 3) + lr: 8 (db & 3) lines on - for an odd db & 3 that adds 4 to the line's swizzle term
+            // ((line >> 1) & 7, < 4 for the first eight lines): chunk ^ 4 = element offset ^ 32
+            const half_t* vrow = cV + (db >> 2) * 2048 + (db & 3) * 512;
+            const h4 lo = *reinterpret_cast<const h4*>(vrow + (vo[0] ^ ((db & 1) * 32)));
+            const h4 hi4 = *reinterpret_cast<const h4*>(vrow + (vo[1] ^ ((db & 1) * 32)));
+            const h8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[db], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- O[q][d] = O^T[d][q] / l: lane (q = lr, lg) holds d = 16 db + 4 lg + r: 8-byte stores
+    const float inv = 1.0f / quad_rows_sum(l_run);
+    if (qvalid) {
+        half_t* orow = p.o + ((int64_t)g * p.nq + qrow) * p.ldo + lg * 4;
+#pragma unroll
+        for (int db = 0; db < 32; ++db)
+            *reinterpret_cast<u2v*>(orow + db * 16) = __builtin_bit_cast(u2v, h4{(half_t)(oacc[db][0] * inv), (half_t)(oacc[db][1] * inv),
+                                                                              (half_t)(oacc[db][2] * inv), (half_t)(oacc[db][3] * inv)});
+    }
+#endif
+}
+
+// =======================================================================================
 // Temporal attention: T <= 32 frames, d = 64.
 // =======================================================================================
 struct TAttnArgs {
@@ -1170,6 +1354,32 @@ extern "C" int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const 
         hipLaunchKernelGGL((flash_d64_kernel<1, false, true>), grid, dim3(256), 0, s, a);
     }
     return vcx_check_launch("vcx_attn_flash_dual_d64_f16");
+}
+
+extern "C" int vcx_attn_flash_d512_f16(const void* q, const void* k, const void* vt, void* o, int n_groups, int nq, int nk, int kv_rows, int64_t ldq,
+                                       int64_t ldk, int64_t ldvt, int64_t ldo, float scale, void* stream) {
+    VCX_REQUIRE(q && k && vt && o, "vcx_attn_flash_d512_f16: null pointer");
+    VCX_REQUIRE(n_groups > 0 && nq > 0 && nk > 0, "vcx_attn_flash_d512_f16: empty problem");
+    VCX_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && kv_rows % 8 == 0 && kv_rows >= nk,
+                "vcx_attn_flash_d512_f16: strides must be multiples of 8 and kv_rows >= nk (ldq=%lld ldk=%lld ldvt=%lld kv_rows=%d nk=%d)",
+                (long long)ldq, (long long)ldk, (long long)ldvt, kv_rows, nk);
+    VCX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0 && ((uintptr_t)o & 7) == 0, "vcx_attn_flash_d512_f16: pointers must be 16-byte aligned");
+    VCX_REQUIRE(((int64_t)(nk - 1) * ldk + 512) * 2 < 0xFFFF0000ll && (511ll * ldvt + nk + 8) * 2 < 0xFFFF0000ll,
+                "vcx_attn_flash_d512_f16: K / V^T extents per group must stay below 4 GiB");
+    Flash512Args a;
+    a.q = (const half_t*)q; a.k = (const half_t*)k; a.vt = (const half_t*)vt; a.o = (half_t*)o;
+    a.nq = nq; a.nk = nk; a.kv_rows = kv_rows; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.nqb = (nq + 127) / 128;
+    a.nprob = n_groups;
+    VCX_REQUIRE((int64_t)a.nqb * ((n_groups + 7) / 8 * 8) < (1ll << 30), "vcx_attn_flash_d512_f16: too many workgroups");
+    hipStream_t s = (hipStream_t)stream;
+    VcxProfScope prof(VCX_FAM_FLASH, s, 4.0 * n_groups * (double)nq * nk * 512, 2.0 * n_groups * 512 * (2.0 * nq + 2.0 * nk));
+    constexpr int FSMEM = 2 * 2 * 32 * 512 * 2;
+    static VcxLdsAttr lds;
+    if (!lds.ensure(reinterpret_cast<const void*>(flash_d512_kernel), FSMEM, "vcx_attn_flash_d512_f16")) return VCX_ELAUNCH;
+    hipLaunchKernelGGL(flash_d512_kernel, dim3((unsigned)(a.nqb * ((n_groups + 7) / 8 * 8))), dim3(512), FSMEM, s, a);
+    return vcx_check_launch("vcx_attn_flash_d512_f16");
 }
 
 extern "C" int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads, int64_t ld,

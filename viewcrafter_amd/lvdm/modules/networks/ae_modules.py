@@ -5,6 +5,8 @@ Same sub-module names/shapes as the reference (`conv_in`, `mid.block_1`, `mid.at
 implicit-GEMM kernel; the single-head d=C attention of the mid block materialises its [N, N] score matrix per frame
 with two GEMMs and a row-softmax kernel (d = 512 does not fit the d = 64 flash tiling).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -63,6 +65,11 @@ class ResnetBlock(PackedModule):
                           residual=skip.reshape(n * H * W, self.out_channels))
 
 
+# the d = 512 flash kernel for AttnBlock (every AutoencoderKL config has 512 channels there); VCX_VAE_FUSED_ATTN=0: the GEMM -> row softmax
+# -> GEMM sequence of rounds 1-4, frame by frame (A/B runs)
+FUSED_ATTN = os.environ.get("VCX_VAE_FUSED_ATTN", "1") != "0"
+
+
 class AttnBlock(PackedModule):
     """Reference ae_modules.py:26-78: GN -> q,k,v 1x1 -> softmax(q k^T C^-1/2) v -> 1x1 -> + x (one head, d = C)."""
 
@@ -101,9 +108,15 @@ class AttnBlock(PackedModule):
         k = ops.linear(hn, *pk["k"])
         vt = ops.gemm(pk["v"][0], hn, M=C, N=n * Np, K=C, lda=C, bias=pk["v"][1], bias_m=True)      # [C, n*Np]
         o = torch.empty((n * Np, C), dtype=torch.float16, device=x.device)
-        s = torch.zeros((Np, Np), dtype=torch.float16, device=x.device)
         scale = float(int(C) ** (-0.5))
-        for i in range(n):   # one frame at a time: S is N x N (170 MB at 72x128)
+        if C == 512 and FUSED_ATTN:
+            # one launch over all frames, the N x N score matrix (170 MB per frame at 72x128) never written: flash_d512_kernel
+            ops.flash_attn_d512(q, k, vt, o, n_groups=n, nq=Np, nk=N, kv_rows=Np, ldq=C, ldk=C, ldvt=n * Np, ldo=C, scale=scale)
+            n_loop = 0
+        else:
+            n_loop = n
+            s = torch.zeros((Np, Np), dtype=torch.float16, device=x.device)
+        for i in range(n_loop):   # other widths: one frame at a time through a materialised S (N x N)
             qi, ki = q[i * Np:(i + 1) * Np], k[i * Np:(i + 1) * Np]
             ops.gemm(qi, ki, M=Np, N=N, K=C, lda=C, out=s, ldc=Np, alpha=scale)
             ops.softmax_rows_(s, N)

@@ -298,6 +298,14 @@ def flash_attn(q, k, vt, out, *, n_groups, heads, nq, nk, kv_rows, kv_div, ldq, 
     return out
 
 
+def flash_attn_d512(q, k, vt, out, *, n_groups, nq, nk, kv_rows, ldq, ldk, ldvt, ldo, scale):
+    """softmax(scale Q K^T) V per group with ONE head of dim 512 (VAE AttnBlock); K rows / V^T columns of group g start at g * kv_rows."""
+    _dev16(q, k, vt, out)
+    check(lib().vcx_attn_flash_d512_f16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), n_groups, nq, nk, kv_rows, ldq, ldk, ldvt, ldo,
+                                        scale, _stream()), "attn_flash_d512")
+    return out
+
+
 def flash_attn_dual(q, k1, vt1, k2, vt2, out, *, n_groups, heads, nq, nk1, kv_rows1, kv_div1, ldk1, ldvt1, nk2, kv_rows2, kv_div2,
                     ldk2, ldvt2, ldq, ldo, scale, log2_logits=False):
     """softmax(scale Q K1^T) V1 + softmax(scale Q K2^T) V2 in one pass over Q and O (text (+) image cross-attention)."""
