@@ -33,7 +33,15 @@ def record_forward(workload):
     fs = torch.tensor([10], device="cuda")
     seen = collections.Counter()
     L = _lib.lib()
-    real = L.vcx_gemm_f16
+    real, real_units = L.vcx_gemm_f16, L.vcx_gemm_units_f16
+
+    class SpyUnits:      # vcx_gemm_units_f16 (a folded GroupNorm's projection): key = the descriptor with mode = 2 and the unit size in in_h
+        def __call__(self, dref, unit_rows, ws, bs, stream):
+            d = dref._obj
+            key = {f: int(getattr(d, f)) for f in FIELDS}
+            key.update(mode=2, in_h=int(unit_rows))
+            seen[tuple(key[f] for f in FIELDS)] += 1
+            return real_units(dref, unit_rows, ws, bs, stream)
 
     class Spy:
         def __call__(self, dref, stream):
@@ -42,11 +50,11 @@ def record_forward(workload):
             return real(dref, stream)
     with torch.no_grad():
         model.apply_model(x, ts, both, fs=fs, cfg_repeat=2)      # warm (packs weights, caches context K/V)
-        L.vcx_gemm_f16 = Spy()
+        L.vcx_gemm_f16, L.vcx_gemm_units_f16 = Spy(), SpyUnits()
         try:
             model.apply_model(x, ts, both, fs=fs, cfg_repeat=2)
         finally:
-            L.vcx_gemm_f16 = real
+            L.vcx_gemm_f16, L.vcx_gemm_units_f16 = real, real_units
     torch.cuda.synchronize()
     del model
     torch.cuda.empty_cache()
@@ -56,6 +64,24 @@ def record_forward(workload):
 def time_shape(key, iters=5):
     d = dict(zip(FIELDS, key))
     M, N, K = d["M"], d["N"], d["K"]
+    if d["mode"] == 2:       # one weight / bias set per unit of in_h rows
+        units = M // d["in_h"]
+        a = torch.randn(M, d["lda"], device="cuda").half()
+        wn = (torch.randn(units, N, K, device="cuda") / K ** 0.5).half()
+        bn = torch.randn(units, N, device="cuda")
+        out = torch.empty(M, N, device="cuda", dtype=torch.float16)
+
+        def run_units():
+            ops.gemm_units(a, wn, bn, unit_rows=d["in_h"], out=out)
+        run_units()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run_units()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
     conv = d["mode"] == 1
     flags = d["flags"]
     if conv:
@@ -97,7 +123,7 @@ def main():
         d = dict(zip(FIELDS, key))
         ms = time_shape(key)
         fl = 2.0 * d["M"] * d["N"] * d["K"]
-        taps = d["kh"] * d["kw"] if d["mode"] else 1
+        taps = d["kh"] * d["kw"] if d["mode"] == 1 else 1
         n_out = d["N"] // 2 if d["flags"] & 16 else d["N"]
         nbytes = 2.0 * (d["M"] * d["K"] / taps + d["N"] * d["K"] + d["M"] * n_out * (2 if d["flags"] & 32 else 1) + (d["M"] * d["N"] if d["flags"] & 8 else 0))
         floor = max(fl / 1.35e15, nbytes / 5.5e12) * 1e3       # ms: best isolated MFMA rate seen on this part under load / achievable HBM
@@ -111,10 +137,18 @@ def main():
     cum = 0.0
     for r in rows:
         cum += r["total_ms"]
-        kind = f"conv{r['kh']}x{r['kw']}" + ("s2" if r["stride"] == 2 else "") + ("u" if r["ups"] else "") if r["mode"] else "linear"
+        kind = (f"conv{r['kh']}x{r['kw']}" + ("s2" if r["stride"] == 2 else "") + ("u" if r["ups"] else "") if r["mode"] == 1
+                else f"units/{r['M'] // r['in_h']}" if r["mode"] == 2 else "linear")
         print(f"{r['count']:4d} {r['M']:8d} {r['N']:6d} {r['K']:6d} {kind:>10} {r['flags']:5d} {r['ms']:8.3f} {r['total_ms']:8.2f} {r['tflops']:7.0f} {100*cum/tot:6.1f} {r['floor_ms']:7.3f} {'hbm' if r['hbm_bound'] else 'mfma':>5} {(r['ms'] - r['floor_ms']) * r['count']:7.2f}")
     if args.json:
-        json.dump(rows, open(args.json, "w"))
+        from bench import csrc_hash
+        top = sorted(rows, key=lambda r: -(r["ms"] - r["floor_ms"]) * r["count"])[:5]
+        json.dump(dict(workload=args.workload, csrc_sha256=csrc_hash(), total_ms=tot, tflops=tfl / tot / 1e9,
+                       excess_ms=sum((r["ms"] - r["floor_ms"]) * r["count"] for r in rows),
+                       floor="max(FLOP / 1.35 PFLOP/s, algorithmic bytes / 5.5 TB/s), problems timed in isolation (tools/gemm_shapes.py)",
+                       top_excess=[dict(M=r["M"], N=r["N"], K=r["K"], kind=("conv" if r["mode"] == 1 else "units" if r["mode"] == 2 else "linear"), flags=r["flags"],
+                                        count=r["count"], ms=r["ms"], floor_ms=r["floor_ms"], tflops=r["tflops"], excess_ms=(r["ms"] - r["floor_ms"]) * r["count"])
+                                   for r in top], rows=rows), open(args.json, "w"))
 
 
 if __name__ == "__main__":
