@@ -17,5 +17,6 @@ done
 cd ${root}
 # algorithmic GEMM bytes per step from the bench line of the FETCH pass (kernel_families.gemm.gbps * ms)
 algo=$(grep '^{"metric' /tmp/pmc_FETCH_SIZE.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); g=d['kernel_families']['gemm']; print(g['gbps']*1e9*g['ms_per_step']*1e-3)")
+calls=$(grep '^{"metric' /tmp/pmc_FETCH_SIZE.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['kernel_families']['gemm']['launches_per_step'])")
 python tools/pmc_traffic.py $(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1) \
-  --json gpurun_out/${tag}_pmc_traffic.json --algo-bytes-per-step ${algo} --commit ${commit} | tee gpurun_out/${tag}_pmc_traffic.txt
+  --json gpurun_out/${tag}_pmc_traffic.json --algo-bytes-per-step ${algo} --gemm-calls-per-step ${calls} --commit ${commit} | tee gpurun_out/${tag}_pmc_traffic.txt

@@ -3,7 +3,7 @@ FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes
 (checked in round 1 on the 460800x320x320+residual GEMM: 2 x 288 MB raw = 576 MB vs 590 MB algorithmic).
     python tools/pmc_traffic.py fetch.db write.db [--json out.json --algo-bytes-per-step B --gemm-calls-per-step N --commit C]
 The number of DDIM steps in each pass is read from the trace itself (one ddim_update_kernel dispatch per step)."""
-import argparse, collections, hashlib, json, os, sqlite3
+import argparse, collections, hashlib, json, os, sqlite3, sys
 
 ap = argparse.ArgumentParser()
 ap.add_argument("fetch_db"); ap.add_argument("write_db")
@@ -45,20 +45,16 @@ for k, (n, r, wr) in agg.items():
     print(f"{k:14s} {n:13.0f} {r/1e9:24.1f} {wr/1e9:14.1f} {(r+wr)/max(n,1):14.3e}")
 if a.json:
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    for name in ("gemm_dma.hip", "gemm.hip", "gemm_args.h", "gemm_epilogue.h"):
-        h.update(open(os.path.join(root, "viewcrafter_amd", "csrc", name), "rb").read())
-    hh = hashlib.sha256()
-    for name in ("attention.hip", "attention_v2.hip"):
-        hh.update(open(os.path.join(root, "viewcrafter_amd", "csrc", name), "rb").read())
-    ha = hh.hexdigest()
+    sys.path.insert(0, root)
+    from bench import csrc_hash                    # ONE definition of "the GEMM sources" (bench.py compares against it)
+    hgemm, ha = csrc_hash(), csrc_hash(("attention.hip", "attention_v2.hip"))
     n, r, wr = agg["gemm"]
     out = {"family": "gemm", "hbm_bytes_per_launch": (r + wr) / a.gemm_calls_per_step, "hbm_read_gb_per_step": r / 1e9,
            "hbm_write_gb_per_step": wr / 1e9, "kernel_dispatches_per_step": n, "launches_per_step": a.gemm_calls_per_step,
            "algorithmic_bytes_per_launch": (a.algo_bytes_per_step / a.gemm_calls_per_step) if a.algo_bytes_per_step else None,
            "note": "per vcx_gemm_f16 call; FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE as reported; separate --pmc passes",
            "source": "tools/pmc_passes.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 1 --warmup 0 ...)",
-           "csrc_sha256": h.hexdigest(), "attention_sha256": ha, "commit": a.commit, "workload": "ViewCrafter_25_576x1024x25",
+           "csrc_sha256": hgemm, "attention_sha256": ha, "commit": a.commit, "workload": "ViewCrafter_25_576x1024x25",
            "families": {k: {"launches_per_step": v[0], "read_gb_per_step": v[1] / 1e9, "write_gb_per_step": v[2] / 1e9,
                                 "hbm_bytes_per_launch": (v[1] + v[2]) / max(v[0], 1)} for k, v in agg.items()}}
     json.dump(out, open(a.json, "w"), indent=1)
