@@ -44,6 +44,9 @@ __global__ void __launch_bounds__(512) kfill(float* out, long long* cyc) {
                 const bool ex = KIND == 1 || (KIND == 2 && (f & 3) == 0);
                 if (ex) asm volatile("v_exp_f32 %0, %0" : "+v"(v[r]));
                 else if (KIND == 3) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[r]) : "v"(c1));
+                else if (KIND == 4) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(v[r]) : "v"(c1), "v"(c2));      // round 5: row sums of packed fp16 probabilities
+                else if (KIND == 5) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(v[r]) : "v"(c1), "v"(c2));
+                else if (KIND == 6) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[r]) : "v"(c1));
                 else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(c1), "v"(c2));
             }
         }
@@ -123,6 +126,10 @@ int main() {
     SWEEP(16, 3, "mfma16x16x32 + cvt_pk")
     SWEEP(32, 0, "mfma32x32x16 + fma")
     SWEEP(32, 2, "mfma32x32x16 + (1 exp : 3 fma)")
+    SWEEP(32, 6, "mfma32x32x16 + v_add_f32")
+    SWEEP(32, 4, "mfma32x32x16 + v_dot2c_f32_f16")
+    SWEEP(32, 5, "mfma32x32x16 + v_dot2_f32_f16")
+    SWEEP(32, 3, "mfma32x32x16 + cvt_pk")
     run(ksplit<0>, "w0-3 mfma16 x8 | w4-7 fma x32, prio 0", 512, 8);
     run(ksplit<1>, "same, fma waves s_setprio 2", 512, 8);
     run(ksplit<2>, "same, mfma waves s_setprio 2", 512, 8);
