@@ -197,6 +197,48 @@ def test_gemm_weight_stationary_wide_and_lnfold(M, N, alpha):
         assert rel_l2(got[1][1], ref) <= 1e-3
 
 
+@pytest.mark.parametrize("M,N,bias", [(8192, 2560, True), (9216 * 2 + 13, 2560, True), (20000, 512, False), (8200, 256, True), (460800, 2560, True),
+                                      (30000 + 7, 1280, True), (50, 2560, True), (1000, 2560, False)])
+def test_gemm_weight_stationary_geglu_matches_the_tiled_engine(M, N, bias):
+    """gemm_ws320_geglu_kernel (K = 320: a block keeps a 256-column slice of the packed [32 value | 32 gate] weight in owned accumulator
+    registers, the bias rides in the accumulators, the finished tile's GELU epilogue in the shadows of the next tile's 32x32x16 MFMAs)
+    against the tiled engine's GEGLU epilogue (knob GEMM_WS = 0; the bias enters at the other end of the sum: agreement to fp16
+    rounding, not bit for bit) and against fp32; ragged M down to less than one tile, one to ten column blocks per row stream, guard
+    band of a padded output, bit-reproducible, a row's bits independent of M."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import pack_geglu
+    K = 320
+    x = rnd(M, K, seed=171).to(DEV).half()
+    w = rnd(N, K, seed=172) / math.sqrt(K)
+    b = rnd(N, seed=173) if bias else torch.zeros(N)
+    wp, bp = pack_geglu(w.to(DEV), b.to(DEV))
+    wp, bp = wp.half(), (bp.float().contiguous() if bias else None)
+    outs = {}
+    for ws in (1, 0):
+        prev = ops.tune_set("GEMM_WS", ws)
+        try:
+            outs[ws] = ops.linear(x, wp, bp, geglu=True)
+            torch.cuda.synchronize()
+        finally:
+            ops.tune_set("GEMM_WS", prev)
+    assert outs[1].shape == (M, N // 2)
+    if M <= 30100:
+        y = x.float() @ w.to(DEV).half().float().t() + b.to(DEV)
+        ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+        check(outs[1], ref, name="ws geglu")
+    e = rel_l2(outs[1], outs[0].float())
+    assert e <= 5e-4, f"weight-stationary vs tiled GEGLU: rel-L2 {e:.2e}"
+    half_rows = max(M // 2 - 7, 1)                     # the first rows as a problem of their own: the same bits
+    part = ops.linear(x[:half_rows], wp, bp, geglu=True)
+    assert torch.equal(part, outs[1][:half_rows])
+    big = torch.full((M + 5, N // 2 + 8), 3.0, device=DEV, dtype=torch.float16)
+    ops.gemm(x, wp, M=M, N=N, K=K, lda=K, out=big, ldc=N // 2 + 8, bias=bp, geglu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(big[:M, :N // 2], outs[1]) and bool((big[M:] == 3.0).all()) and bool((big[:, N // 2:] == 3.0).all())
+    again = ops.linear(x, wp, bp, geglu=True)
+    assert torch.equal(again, outs[1])
+
+
 def test_gemm_weight_stationary_320_column_moments():
     """The COLSTATS epilogue on the weight-stationary kernel: data and (mean, M2) strips identical to the tiled engine's."""
     from viewcrafter_amd import ops

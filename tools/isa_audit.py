@@ -226,6 +226,28 @@ def store_data_hazards(listing):
     return found
 
 
+# Kernels that OWN accumulator registers by name (asm statements read / write them; the compiler must not allocate AGPRs of its own in
+# them, it does not know the owned ones are live): kernel name fragment -> number of v_accvgpr_write the source itself issues.
+AGPR_OWNERS = {"gemm_ws320_geglu_kernel": 160}
+
+
+def agpr_ownership(listing):
+    """[(kernel, what)] - compiler-generated AGPR traffic or scratch in a kernel that owns its accumulator registers."""
+    found = []
+    for frag, writes in AGPR_OWNERS.items():
+        m = re.search(r"^(_Z\w*" + frag + r"\w*):[^\n]*\n(.*?)^\.Lfunc_end", listing, re.S | re.M)
+        if not m:
+            continue
+        name, body = m.group(1), m.group(2)
+        nw = len(re.findall(r"^\s*v_accvgpr_write_b32", body, re.M))
+        nr = len(re.findall(r"^\s*v_accvgpr_(?:read|mov)_b32", body, re.M))
+        if nw != writes or nr:
+            found.append((name, "", f"{nw} v_accvgpr_write (the source issues {writes}) and {nr} v_accvgpr_read / mov: the compiler parks values in owned accumulator registers", 0))
+        if re.search(r"^\s*scratch_", body, re.M):
+            found.append((name, "", "scratch traffic", 0))
+    return found
+
+
 def audit_library_store_hazards():
     out = []
     with tempfile.TemporaryDirectory(prefix="vcx_isa_") as tmpdir:
@@ -237,6 +259,7 @@ def audit_library_store_hazards():
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed on " + name + ":\n" + r.stderr[-2000:])
             out += [(name,) + h for h in store_data_hazards(open(tmp).read())]
+            out += [(name,) + h for h in agpr_ownership(open(tmp).read())]
     return out
 
 

@@ -57,24 +57,35 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
 #else
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float a = fminf(fabsf(x), 9.0f);
-    float q = 3.3093042e-05f;
-    q = __builtin_fmaf(q, a, -7.6922239e-04f);
-    q = __builtin_fmaf(q, a, 8.0807274e-03f);
-    q = __builtin_fmaf(q, a, -5.3412125e-02f);
-    q = __builtin_fmaf(q, a, -4.5877096e-01f);
-    q = __builtin_fmaf(q, a, -1.1512017e+00f);
-    q = __builtin_fmaf(q, a, -9.9999309e-01f);
-    const float e = __builtin_amdgcn_exp2f(q);          // Phi(-|x|)
-    // x Phi(x) = max(x, 0) - |x| Phi(-|x|): one max and one multiply-add instead of subtract / compare / select / multiply - three
-    // VALU issue slots fewer per GEGLU output and one rounding instead of two (max error over every fp16 input 2.8e-7 against
-    // 3.7e-7, still within one fp16 unit in the last place everywhere).  The clamped |x| serves: beyond 9 the product is < 1e-17.
+// in pieces, so that a caller can spread them over several MFMA shadows (gemm_ws320_geglu_kernel); gelu_erf() below is their
+// composition - ONE definition of the arithmetic
+constexpr float GELU_Q[7] = {3.3093042e-05f, -7.6922239e-04f, 8.0807274e-03f, -5.3412125e-02f, -4.5877096e-01f, -1.1512017e+00f, -9.9999309e-01f};
+template <int I>
+__device__ __forceinline__ float gelu_q_step(float q, float a) { return __builtin_fmaf(q, a, GELU_Q[I]); }       // Horner step I = 1 .. 6, q0 = GELU_Q[0]
+__device__ __forceinline__ float gelu_clamp(float x) { return fminf(fabsf(x), 9.0f); }
+__device__ __forceinline__ float gelu_finish(float x, float a, float mx, float e) {       // e = exp2(q6) = Phi(-|x|), mx = max(x, 0)
 #ifdef VCX_GELU_SELECT_TAIL       // the round 3-4 tail, kept for the A/B build of tools/step_ab.py only (tools/_abl/libvcx_gelu_select.so)
     return x * (x > 0.f ? 1.0f - e : e);
 #else
-    return __builtin_fmaf(-a, e, __builtin_fmaxf(x, 0.f));
+    // x Phi(x) = max(x, 0) - |x| Phi(-|x|): one max and one multiply-add instead of subtract / compare / select / multiply - three
+    // VALU issue slots fewer per GEGLU output and one rounding instead of two (max error over every fp16 input 2.8e-7 against
+    // 3.7e-7, still within one fp16 unit in the last place everywhere).  The clamped |x| serves: beyond 9 the product is < 1e-17.
+    return __builtin_fmaf(-a, e, mx);
 #endif
+}
+__device__ __forceinline__ void gelu_erf_head(float x, float& a, float& mx, float& q) {
+    a = gelu_clamp(x);
+    mx = __builtin_fmaxf(x, 0.f);
+    q = gelu_q_step<3>(gelu_q_step<2>(gelu_q_step<1>(GELU_Q[0], a), a), a);
+}
+__device__ __forceinline__ float gelu_erf_tail(float x, float a, float mx, float q) {
+    q = gelu_q_step<6>(gelu_q_step<5>(gelu_q_step<4>(q, a), a), a);
+    return gelu_finish(x, a, mx, __builtin_amdgcn_exp2f(q));
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float a, mx, q;
+    gelu_erf_head(x, a, mx, q);
+    return gelu_erf_tail(x, a, mx, q);
 }
 #endif
 
@@ -121,6 +132,7 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
 
 int persistent_grid(int ntiles, int blocks_per_cu = 2);
 int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);
+int launch_ws320_geglu(GemmArgs& a, hipStream_t s);  // ... GEGLU projection, K = 320, N % 256 == 0
 int launch_ws320_units(GemmArgs& a, hipStream_t s);  // ... with one weight / bias set per unit of rows (vcx_gemm_units_f16)
 int launch_ws320(GemmArgs& a, hipStream_t s);        // gemm_ws.hip: weight-stationary linear layer, N = K = 320 (plain / COLSTATS epilogues)   // a.flags & VCX_GEMM_LNFOLD[_T] selects the folded-LayerNorm epilogue
 

@@ -402,6 +402,348 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
 #endif
 }
 
+// =============================================================================================================================
+// Weight-stationary GEGLU projection for K = 320 (level 0: 460800 x 2560 x 320, ten launches per step, the largest excess over floor of
+// the whole per-shape table: 0.93 ms against 0.56).  In the tiled engine the layer spends as long in its epilogue (bias, exact GELU of the
+// gate, product, fp16 rounding: ~12 VALU instructions per output) as in its five K-steps, and the deferred-epilogue experiment of round 5
+// showed why that cannot be hidden THERE: the K-step's own LDS / DMA traffic has spent the MFMA shadows, and a 16x16x32 MFMA has one free
+// issue slot.  Here it can: a block keeps a 256-column slice of the packed weight (value | gate blocks of 32) in registers - 40 KB per
+// wave, 160 registers - so a K-slice is two MFMAs and ONE LDS read, and the MFMAs are 32x32x16 (four to five free issue slots each,
+// tools/ubench_fill.hip): the finished tile's 16 outputs per lane are formed two at a time in the shadows of the next tile's MFMAs
+// (sched_group_barrier: one MFMA, six VALU), packed, exchanged between the lane halves and stored as two 16-byte pieces at its end.
+// A wave's 64 packed columns are exactly one [32 value | 32 gate] block = the two 32-row A blocks of the MFMA, so value and gate of an
+// output land in the same lane and register.  The ten column blocks that share a row stream sit on one XCD (block id = 8 slot + xcd):
+// the activation tile comes from HBM once and from that L2 nine times.  Results agree with the tiled engine's GEGLU to fp16 rounding
+// (32x32x16 sums K in another order than 16x16x32), are bit-reproducible and do not depend on M.
+// =============================================================================================================================
+struct WgCfg {
+    static constexpr int TBM = 64, TBN = 256;
+    static constexpr int THREADS = 256;
+};
+constexpr int WG_STAGE = WgCfg::TBM * WS_K * (int)sizeof(half_t);          // 40 KB: five [64 rows][64] slabs
+[[maybe_unused]] constexpr int WG_RING = 3, WG_AHEAD = 1;                  // (a stage is re-filled one barrier after its tile was consumed)
+[[maybe_unused]] constexpr int WG_PIECES = WG_STAGE / 1024 / 4;            // LDS-DMA instructions per wave and tile (10)
+[[maybe_unused]] constexpr int WG_KS = WS_K / 16;                          // twenty 16-deep K slices
+constexpr size_t WG_SMEM = (size_t)WG_RING * WG_STAGE;
+
+// ---- gemm_ws320_geglu_kernel: the 160 weight registers are OWNED accumulator registers a[0:159] (fragment I = 20 ab + kk in a[4 I .. 4 I + 3]),
+// read by the MFMAs as their A operand directly; the accumulators are ordinary VGPR tuples, so neither weights nor results pass through
+// v_accvgpr_read (the compiler's own allocation shuttled 45 weight fragments and all 64 pending results per tile through it).
+#define WG_CLOB "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159"
+template <int I>
+__device__ __forceinline__ void wg_load_w(const h8& w) {
+    typedef unsigned u4w __attribute__((ext_vector_type(4)));
+    const u4w v = __builtin_bit_cast(u4w, w);
+    if constexpr (I == 0) asm volatile("v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %1\n\tv_accvgpr_write_b32 a2, %2\n\tv_accvgpr_write_b32 a3, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a0", "a1", "a2", "a3");
+    if constexpr (I == 1) asm volatile("v_accvgpr_write_b32 a4, %0\n\tv_accvgpr_write_b32 a5, %1\n\tv_accvgpr_write_b32 a6, %2\n\tv_accvgpr_write_b32 a7, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a4", "a5", "a6", "a7");
+    if constexpr (I == 2) asm volatile("v_accvgpr_write_b32 a8, %0\n\tv_accvgpr_write_b32 a9, %1\n\tv_accvgpr_write_b32 a10, %2\n\tv_accvgpr_write_b32 a11, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a8", "a9", "a10", "a11");
+    if constexpr (I == 3) asm volatile("v_accvgpr_write_b32 a12, %0\n\tv_accvgpr_write_b32 a13, %1\n\tv_accvgpr_write_b32 a14, %2\n\tv_accvgpr_write_b32 a15, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a12", "a13", "a14", "a15");
+    if constexpr (I == 4) asm volatile("v_accvgpr_write_b32 a16, %0\n\tv_accvgpr_write_b32 a17, %1\n\tv_accvgpr_write_b32 a18, %2\n\tv_accvgpr_write_b32 a19, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a16", "a17", "a18", "a19");
+    if constexpr (I == 5) asm volatile("v_accvgpr_write_b32 a20, %0\n\tv_accvgpr_write_b32 a21, %1\n\tv_accvgpr_write_b32 a22, %2\n\tv_accvgpr_write_b32 a23, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a20", "a21", "a22", "a23");
+    if constexpr (I == 6) asm volatile("v_accvgpr_write_b32 a24, %0\n\tv_accvgpr_write_b32 a25, %1\n\tv_accvgpr_write_b32 a26, %2\n\tv_accvgpr_write_b32 a27, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a24", "a25", "a26", "a27");
+    if constexpr (I == 7) asm volatile("v_accvgpr_write_b32 a28, %0\n\tv_accvgpr_write_b32 a29, %1\n\tv_accvgpr_write_b32 a30, %2\n\tv_accvgpr_write_b32 a31, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a28", "a29", "a30", "a31");
+    if constexpr (I == 8) asm volatile("v_accvgpr_write_b32 a32, %0\n\tv_accvgpr_write_b32 a33, %1\n\tv_accvgpr_write_b32 a34, %2\n\tv_accvgpr_write_b32 a35, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a32", "a33", "a34", "a35");
+    if constexpr (I == 9) asm volatile("v_accvgpr_write_b32 a36, %0\n\tv_accvgpr_write_b32 a37, %1\n\tv_accvgpr_write_b32 a38, %2\n\tv_accvgpr_write_b32 a39, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a36", "a37", "a38", "a39");
+    if constexpr (I == 10) asm volatile("v_accvgpr_write_b32 a40, %0\n\tv_accvgpr_write_b32 a41, %1\n\tv_accvgpr_write_b32 a42, %2\n\tv_accvgpr_write_b32 a43, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a40", "a41", "a42", "a43");
+    if constexpr (I == 11) asm volatile("v_accvgpr_write_b32 a44, %0\n\tv_accvgpr_write_b32 a45, %1\n\tv_accvgpr_write_b32 a46, %2\n\tv_accvgpr_write_b32 a47, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a44", "a45", "a46", "a47");
+    if constexpr (I == 12) asm volatile("v_accvgpr_write_b32 a48, %0\n\tv_accvgpr_write_b32 a49, %1\n\tv_accvgpr_write_b32 a50, %2\n\tv_accvgpr_write_b32 a51, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a48", "a49", "a50", "a51");
+    if constexpr (I == 13) asm volatile("v_accvgpr_write_b32 a52, %0\n\tv_accvgpr_write_b32 a53, %1\n\tv_accvgpr_write_b32 a54, %2\n\tv_accvgpr_write_b32 a55, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a52", "a53", "a54", "a55");
+    if constexpr (I == 14) asm volatile("v_accvgpr_write_b32 a56, %0\n\tv_accvgpr_write_b32 a57, %1\n\tv_accvgpr_write_b32 a58, %2\n\tv_accvgpr_write_b32 a59, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a56", "a57", "a58", "a59");
+    if constexpr (I == 15) asm volatile("v_accvgpr_write_b32 a60, %0\n\tv_accvgpr_write_b32 a61, %1\n\tv_accvgpr_write_b32 a62, %2\n\tv_accvgpr_write_b32 a63, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a60", "a61", "a62", "a63");
+    if constexpr (I == 16) asm volatile("v_accvgpr_write_b32 a64, %0\n\tv_accvgpr_write_b32 a65, %1\n\tv_accvgpr_write_b32 a66, %2\n\tv_accvgpr_write_b32 a67, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a64", "a65", "a66", "a67");
+    if constexpr (I == 17) asm volatile("v_accvgpr_write_b32 a68, %0\n\tv_accvgpr_write_b32 a69, %1\n\tv_accvgpr_write_b32 a70, %2\n\tv_accvgpr_write_b32 a71, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a68", "a69", "a70", "a71");
+    if constexpr (I == 18) asm volatile("v_accvgpr_write_b32 a72, %0\n\tv_accvgpr_write_b32 a73, %1\n\tv_accvgpr_write_b32 a74, %2\n\tv_accvgpr_write_b32 a75, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a72", "a73", "a74", "a75");
+    if constexpr (I == 19) asm volatile("v_accvgpr_write_b32 a76, %0\n\tv_accvgpr_write_b32 a77, %1\n\tv_accvgpr_write_b32 a78, %2\n\tv_accvgpr_write_b32 a79, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a76", "a77", "a78", "a79");
+    if constexpr (I == 20) asm volatile("v_accvgpr_write_b32 a80, %0\n\tv_accvgpr_write_b32 a81, %1\n\tv_accvgpr_write_b32 a82, %2\n\tv_accvgpr_write_b32 a83, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a80", "a81", "a82", "a83");
+    if constexpr (I == 21) asm volatile("v_accvgpr_write_b32 a84, %0\n\tv_accvgpr_write_b32 a85, %1\n\tv_accvgpr_write_b32 a86, %2\n\tv_accvgpr_write_b32 a87, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a84", "a85", "a86", "a87");
+    if constexpr (I == 22) asm volatile("v_accvgpr_write_b32 a88, %0\n\tv_accvgpr_write_b32 a89, %1\n\tv_accvgpr_write_b32 a90, %2\n\tv_accvgpr_write_b32 a91, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a88", "a89", "a90", "a91");
+    if constexpr (I == 23) asm volatile("v_accvgpr_write_b32 a92, %0\n\tv_accvgpr_write_b32 a93, %1\n\tv_accvgpr_write_b32 a94, %2\n\tv_accvgpr_write_b32 a95, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a92", "a93", "a94", "a95");
+    if constexpr (I == 24) asm volatile("v_accvgpr_write_b32 a96, %0\n\tv_accvgpr_write_b32 a97, %1\n\tv_accvgpr_write_b32 a98, %2\n\tv_accvgpr_write_b32 a99, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a96", "a97", "a98", "a99");
+    if constexpr (I == 25) asm volatile("v_accvgpr_write_b32 a100, %0\n\tv_accvgpr_write_b32 a101, %1\n\tv_accvgpr_write_b32 a102, %2\n\tv_accvgpr_write_b32 a103, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a100", "a101", "a102", "a103");
+    if constexpr (I == 26) asm volatile("v_accvgpr_write_b32 a104, %0\n\tv_accvgpr_write_b32 a105, %1\n\tv_accvgpr_write_b32 a106, %2\n\tv_accvgpr_write_b32 a107, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a104", "a105", "a106", "a107");
+    if constexpr (I == 27) asm volatile("v_accvgpr_write_b32 a108, %0\n\tv_accvgpr_write_b32 a109, %1\n\tv_accvgpr_write_b32 a110, %2\n\tv_accvgpr_write_b32 a111, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a108", "a109", "a110", "a111");
+    if constexpr (I == 28) asm volatile("v_accvgpr_write_b32 a112, %0\n\tv_accvgpr_write_b32 a113, %1\n\tv_accvgpr_write_b32 a114, %2\n\tv_accvgpr_write_b32 a115, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a112", "a113", "a114", "a115");
+    if constexpr (I == 29) asm volatile("v_accvgpr_write_b32 a116, %0\n\tv_accvgpr_write_b32 a117, %1\n\tv_accvgpr_write_b32 a118, %2\n\tv_accvgpr_write_b32 a119, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a116", "a117", "a118", "a119");
+    if constexpr (I == 30) asm volatile("v_accvgpr_write_b32 a120, %0\n\tv_accvgpr_write_b32 a121, %1\n\tv_accvgpr_write_b32 a122, %2\n\tv_accvgpr_write_b32 a123, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a120", "a121", "a122", "a123");
+    if constexpr (I == 31) asm volatile("v_accvgpr_write_b32 a124, %0\n\tv_accvgpr_write_b32 a125, %1\n\tv_accvgpr_write_b32 a126, %2\n\tv_accvgpr_write_b32 a127, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a124", "a125", "a126", "a127");
+    if constexpr (I == 32) asm volatile("v_accvgpr_write_b32 a128, %0\n\tv_accvgpr_write_b32 a129, %1\n\tv_accvgpr_write_b32 a130, %2\n\tv_accvgpr_write_b32 a131, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a128", "a129", "a130", "a131");
+    if constexpr (I == 33) asm volatile("v_accvgpr_write_b32 a132, %0\n\tv_accvgpr_write_b32 a133, %1\n\tv_accvgpr_write_b32 a134, %2\n\tv_accvgpr_write_b32 a135, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a132", "a133", "a134", "a135");
+    if constexpr (I == 34) asm volatile("v_accvgpr_write_b32 a136, %0\n\tv_accvgpr_write_b32 a137, %1\n\tv_accvgpr_write_b32 a138, %2\n\tv_accvgpr_write_b32 a139, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a136", "a137", "a138", "a139");
+    if constexpr (I == 35) asm volatile("v_accvgpr_write_b32 a140, %0\n\tv_accvgpr_write_b32 a141, %1\n\tv_accvgpr_write_b32 a142, %2\n\tv_accvgpr_write_b32 a143, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a140", "a141", "a142", "a143");
+    if constexpr (I == 36) asm volatile("v_accvgpr_write_b32 a144, %0\n\tv_accvgpr_write_b32 a145, %1\n\tv_accvgpr_write_b32 a146, %2\n\tv_accvgpr_write_b32 a147, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a144", "a145", "a146", "a147");
+    if constexpr (I == 37) asm volatile("v_accvgpr_write_b32 a148, %0\n\tv_accvgpr_write_b32 a149, %1\n\tv_accvgpr_write_b32 a150, %2\n\tv_accvgpr_write_b32 a151, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a148", "a149", "a150", "a151");
+    if constexpr (I == 38) asm volatile("v_accvgpr_write_b32 a152, %0\n\tv_accvgpr_write_b32 a153, %1\n\tv_accvgpr_write_b32 a154, %2\n\tv_accvgpr_write_b32 a155, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a152", "a153", "a154", "a155");
+    if constexpr (I == 39) asm volatile("v_accvgpr_write_b32 a156, %0\n\tv_accvgpr_write_b32 a157, %1\n\tv_accvgpr_write_b32 a158, %2\n\tv_accvgpr_write_b32 a159, %3\n\ts_nop 1" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a156", "a157", "a158", "a159");
+}
+// D = W(a[4 I ..]) x X + C (first MFMA of a tile: C = the bias tuple) / D += W x X
+template <int I>
+__device__ __forceinline__ void wg_mfma_first(f16v& d, const h8& x, const f16v& c) {
+    if constexpr (I == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[0:3], %1, %2" : "=&v"(d) : "v"(x), "v"(c));
+    if constexpr (I == 20) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[80:83], %1, %2" : "=&v"(d) : "v"(x), "v"(c));
+}
+template <int I>
+__device__ __forceinline__ void wg_mfma_acc(f16v& d, const h8& x) {
+    if constexpr (I == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[0:3], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[4:7], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[8:11], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 3) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[12:15], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 4) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[16:19], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 5) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[20:23], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 6) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[24:27], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 7) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[28:31], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 8) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[32:35], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 9) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[36:39], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 10) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[40:43], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 11) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[44:47], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 12) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[48:51], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 13) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[52:55], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 14) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[56:59], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 15) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[60:63], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 16) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[64:67], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 17) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[68:71], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 18) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[72:75], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 19) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[76:79], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 20) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[80:83], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 21) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[84:87], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 22) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[88:91], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 23) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[92:95], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 24) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[96:99], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 25) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[100:103], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 26) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[104:107], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 27) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[108:111], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 28) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[112:115], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 29) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[116:119], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 30) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[120:123], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 31) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[124:127], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 32) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[128:131], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 33) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[132:135], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 34) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[136:139], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 35) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[140:143], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 36) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[144:147], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 37) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[148:151], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 38) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[152:155], %1, %0" : "+v"(d) : "v"(x));
+    if constexpr (I == 39) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[156:159], %1, %0" : "+v"(d) : "v"(x));
+}
+
+__global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_geglu_kernel(GemmArgs p, unsigned a_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
+
+    const int ntiles = p.tiles_m;
+    const int cb = (blockIdx.x >> 3) % p.tiles_n;
+    const int G = gridDim.x / p.tiles_n;
+    const int t_first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) / p.tiles_n;
+    const int ncol0 = cb * WgCfg::TBN;                     // first PACKED column (weight row) of the block; its outputs start at ncol0 / 2
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lq = lane & 31, hi = lane >> 5;
+
+    // A fragments: lane (i = lq, hi) holds W[ncol0 + 64 wave + 32 ab + i][16 kk + 8 hi .. + 7]; ab = 0 the block's 32 value columns, 1 their gates
+    // (into the owned accumulator registers: wg_load_w)
+    // The bias rides in the accumulators: the first MFMA of a tile takes C = bias (accumulator register r = 4 q + c holds packed column
+    // 8 q + 4 hi + c of its A block in every lane).  No multiply-add per output in the epilogue, and the 32 registers are MFMA
+    // operands - they may live in the accumulator half of the file.  (alpha = 1 only: the dispatcher sends other calls to the tiled engine.)
+    f16v binit[2];
+    {
+        const half_t* wrow = p.W + (size_t)(ncol0 + wave * 64 + lq) * p.ldw + hi * 8;
+        static_for_ws<2 * WG_KS>([&](auto I_) __attribute__((always_inline)) {
+            constexpr int I = decltype(I_)::value, ab = I / WG_KS, kk = I % WG_KS;
+            wg_load_w<I>(*reinterpret_cast<const h8*>(wrow + (size_t)ab * 32 * p.ldw + kk * 16));
+        });
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 bq = (p.flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + ncol0 + wave * 64 + 32 * ab + 8 * q + 4 * hi) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) binit[ab][4 * q + c] = bq[c];
+            }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
+
+    // LDS-DMA of one 64-row tile: 40 instructions of 8 rows x 128 bytes; wave w issues piece i = 0..9 = slab i / 2, rows 8 (w + 4 (i & 1)) .. + 7
+    const int drow = wave * 8 + (lane >> 3);
+    const unsigned dsrc = (unsigned)((lane & 7) ^ ((drow >> 1) & 7)) * 16u;
+    const unsigned rstep32 = 32u * (unsigned)p.lda * 2u;
+    int issued = 0;
+    int mark[WG_RING];
+    auto issue_tile = [&](int t, int buf) {
+        const int m0 = p.m_begin + t * WgCfg::TBM + drow;
+        const unsigned base = (unsigned)m0 * (unsigned)p.lda * 2u + dsrc;
+        const unsigned va = m0 < p.M ? base : OOB, vb = m0 + 32 < p.M ? base + rstep32 : OOB;
+        unsigned char* dst = smem_raw + buf * WG_STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < WG_PIECES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dst + (i >> 1) * 8192 + (i & 1) * 4096), 16, (i & 1) ? vb : va,
+                                                     (unsigned)(i >> 1) * (BK * 2), 0, 0);
+        issued += WG_PIECES;
+        mark[buf] = issued;
+    };
+    // B fragment of K slice kk and row block mb: lane (m = 32 mb + lq, hi) holds X[m][16 kk + 8 hi .. + 7] = chunk 2 (kk & 3) + hi of slab kk >> 2
+    int xo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xo[i] = lds_off(lq, 2 * i + hi);
+
+    f16v acc[2][2][2];                        // [accumulator set][value | gate][row block]
+    unsigned coff[2][2];                      // byte offset of (lane's row in row block mb, wave's first OUTPUT column + 8 hi) of the tile in each accumulator set
+
+    // The finished tile's epilogue in 68 chunks, one behind each of the next tile's MFMAs 6 .. 73 (sched_barrier(0) on both sides of every
+    // MFMA and chunk: the order below IS the instruction stream - left to the scheduler, sched_group_barrier or not, hipcc issues a
+    // region's MFMAs back to back, the wave stalls on the busy pipe and the VALU work runs behind it, not beside it).  Per row block:
+    //   chunks 0 .. 31: output pair c / 4 - accumulators; clamp, max, two Horner steps; four Horner steps; exp2, products, fp16 pair -
+    //   two independent chains side by side (one wave per SIMD: nothing else hides the latency of a dependent chain)
+    //   chunks 32, 33: half exchange + one 16-byte store each.     The arithmetic of gemm_epilogue's GEGLU path (bias in the accumulator).
+    float hx[2], hg[2], ha[2], hm[2], hq[2];
+    u2v pk[4];
+    auto chunk = [&](auto PAR_, auto C_) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value, mb = decltype(C_)::value / 34, c = decltype(C_)::value % 34;
+        if constexpr (c < 32) {
+            constexpr int P = c >> 2, ph = c & 3;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                constexpr int dummy = 0; (void)dummy;
+                const int r = 2 * P + e;
+                if constexpr (ph == 0) {
+                    hx[e] = acc[PAR][0][mb][r];
+                    hg[e] = acc[PAR][1][mb][r];
+                } else if constexpr (ph == 1) {
+                    // min(|g|, 9) and max(g, 0) as the two instructions they are: on a value that comes out of an accumulator read hipcc
+                    // puts a canonicalising v_max_f32 g, g, g in front of each (NaN rule of fminf / fmaxf; an MFMA result needs none)
+                    asm("v_min_f32 %0, |%1|, %2" : "=v"(ha[e]) : "v"(hg[e]), "s"(9.0f));
+                    asm("v_max_f32 %0, 0, %1" : "=v"(hm[e]) : "v"(hg[e]));
+                    hq[e] = gelu_q_step<2>(gelu_q_step<1>(GELU_Q[0], ha[e]), ha[e]);
+                } else if constexpr (ph == 2) {
+                    hq[e] = gelu_q_step<6>(gelu_q_step<5>(gelu_q_step<4>(gelu_q_step<3>(hq[e], ha[e]), ha[e]), ha[e]), ha[e]);
+                } else {
+                    hx[e] = hx[e] * gelu_finish(hg[e], ha[e], hm[e], __builtin_amdgcn_exp2f(hq[e]));
+                    asm volatile("" : "+v"(hx[e]));          // fp32 product first, then ONE fp16 rounding (no v_fma_mixlo_f16)
+                }
+            }
+            if constexpr (ph == 3) {          // outputs 2 P, 2 P + 1 = word P & 1 of column group P / 2
+                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                pk[P >> 1][P & 1] = __builtin_bit_cast(unsigned, h2v{(half_t)hx[0], (half_t)hx[1]});
+            }
+        } else {
+            // column group q holds columns 8 q + 4 hi .. + 3: after the half swap lanes 0-31 own columns 16 k .. + 7, lanes 32-63 columns 16 k + 8 .. + 15
+            constexpr int k = c - 32;
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * k][0], pk[2 * k + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * k][1], pk[2 * k + 1][1], false, false);
+            const epi_u4v w = {s0[0], s1[0], s0[1], s1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(w, srd_c, coff[PAR][mb], k * 32, 0);
+            asm volatile("s_nop 1" : : "v"(w));          // (the wide-store rule of tools/isa_audit.py)
+            issued += 1;
+        }
+    };
+
+    // one tile: its 80 MFMAs into accumulator set PAR; PEND: the other set holds a finished tile whose chunks ride behind MFMAs 6 .. 73
+    auto tile = [&](auto PAR_, auto PEND_, int t, int i) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value;
+        constexpr bool PEND = decltype(PEND_)::value != 0;
+        const int buf = i % WG_RING;
+        __builtin_amdgcn_sched_barrier(0);
+#if !(defined(VCX_WG_ABL) && (VCX_WG_ABL & 4))        // timing-only ablations (tools/ws_geglu_scan.py): 1 no epilogue chunks, 2 no MFMAs, 4 no per-tile barrier / wait
+        ws_wait_vmcnt(issued - mark[buf]);
+        __builtin_amdgcn_s_barrier();
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // (every wave has passed this barrier = has finished the tile before: its stage takes the tile after next)
+        if (t + (WG_AHEAD + 1) * G < ntiles) issue_tile(t + (WG_AHEAD + 1) * G, (i + WG_AHEAD + 1) % WG_RING);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int m = p.m_begin + t * WgCfg::TBM + 32 * mb + lq;
+            coff[PAR][mb] = m < p.M ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(ncol0 / 2 + wave * 32 + 8 * hi)) * 2u : OOB;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // four LDS byte addresses per tile (stage base + the lane's chunk of K slices 4 s + j), opaque to the compiler: every fragment
+        // read is one of them plus an immediate (slab, row block) - left alone, hipcc keeps ~20 address registers per tile alive, and
+        // with 256 VGPRs taken it parks values in a0 .. a3, i.e. in the owned weight registers
+        unsigned xb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xb[j] = (unsigned)(buf * WG_STAGE) + 2u * (unsigned)xo[j];
+            asm volatile("" : "+v"(xb[j]));
+        }
+        auto frag = [&](int kk, int mb) __attribute__((always_inline)) {
+            return *reinterpret_cast<const h8*>(smem_raw + xb[kk & 3] + (kk >> 2) * (WgCfg::TBM * BK * 2) + mb * 4096);
+        };
+        // B fragments through a ring of registers, requested XR K slices (= 4 XR MFMAs) ahead: one slice of cover is less than the LDS latency
+        constexpr int XR = 4;
+        h8 xr[XR][2];
+#pragma unroll
+        for (int k = 0; k < XR; ++k)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) xr[k][mb] = frag(k, mb);
+        static_for_ws<WG_KS>([&](auto KK_) __attribute__((always_inline)) {
+            constexpr int kk = decltype(KK_)::value;
+            static_for_ws<4>([&](auto J_) __attribute__((always_inline)) {
+                constexpr int j = decltype(J_)::value, ab = j & 1, mb = j >> 1, n = 4 * kk + j;
+                __builtin_amdgcn_sched_barrier(0);
+#if defined(VCX_WG_ABL) && (VCX_WG_ABL & 2)
+                if constexpr (kk == 0) acc[PAR][ab][mb] = binit[ab]; else acc[PAR][ab][mb][n & 15] += (float)xr[kk % XR][mb][0] * (float)xr[kk % XR][mb][1];
+#else
+                if constexpr (kk == 0) wg_mfma_first<WG_KS * ab>(acc[PAR][ab][mb], xr[kk % XR][mb], binit[ab]);
+                else wg_mfma_acc<WG_KS * ab + kk>(acc[PAR][ab][mb], xr[kk % XR][mb]);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ab == 1 && kk + XR < WG_KS) xr[kk % XR][mb] = frag(kk + XR, mb);
+#if defined(VCX_WG_ABL) && (VCX_WG_ABL & 1)
+                if constexpr (PEND && n >= 6 && n < 74 && (n - 6) % 34 >= 32) chunk(WInt<PAR ^ 1>{}, WInt<n - 6>{});
+#else
+                if constexpr (PEND && n >= 6 && n < 74) chunk(WInt<PAR ^ 1>{}, WInt<n - 6>{});
+#endif
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    auto drain = [&](auto PAR_) __attribute__((always_inline)) {
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs (asm: hipcc does not know their latency) have written their results
+        __builtin_amdgcn_sched_barrier(0);
+        static_for_ws<68>([&](auto C_) __attribute__((always_inline)) { chunk(PAR_, C_); });
+    };
+
+    int t = t_first, i = 0;
+#pragma unroll
+    for (int k = 0; k <= WG_AHEAD; ++k)
+        if (t + k * G < ntiles) issue_tile(t + k * G, k);
+    if (t < ntiles) {
+        tile(WInt<0>{}, WInt<0>{}, t, i);
+        t += G; ++i;
+        for (;;) {
+            if (t >= ntiles) {
+                drain(WInt<0>{});
+                break;
+            }
+            tile(WInt<1>{}, WInt<1>{}, t, i);
+            t += G; ++i;
+            if (t >= ntiles) {
+                drain(WInt<1>{});
+                break;
+            }
+            tile(WInt<0>{}, WInt<1>{}, t, i);
+            t += G; ++i;
+        }
+    }
+#endif
+}
+
+int launch_ws_geglu(const GemmArgs& a, hipStream_t s) {
+    static VcxLdsAttr lds;
+    auto kern = gemm_ws320_geglu_kernel;
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WG_SMEM, "vcx_gemm_f16(ws320 geglu)")) return VCX_ELAUNCH;
+    const int per_xcd = persistent_grid(1 << 30, 1) / 8;
+    int streams_per_xcd = per_xcd / a.tiles_n;
+    if (streams_per_xcd < 1) streams_per_xcd = 1;
+    const int needed = (a.tiles_m + 7) / 8;
+    if (streams_per_xcd > needed) streams_per_xcd = needed;
+    hipLaunchKernelGGL(kern, dim3(8 * streams_per_xcd * a.tiles_n), dim3(WgCfg::THREADS), WG_SMEM, s, a, a.a_bytes);
+    return vcx_check_launch("vcx_gemm_f16(ws320 geglu)");
+}
+
 template <bool RES>
 int launch_ws_pipe(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
@@ -448,6 +790,13 @@ int vcxgemm::launch_ws320_units(GemmArgs& a, hipStream_t s) {
     if (bpu > a.tiles_m) bpu = a.tiles_m;
     hipLaunchKernelGGL(kern, dim3(bpu * a.units), dim3(WpCfg::THREADS), WP_SMEM, s, a, a.a_bytes);
     return vcx_check_launch("vcx_gemm_units_f16(ws320 pipe)");
+}
+
+// GEGLU, linear mode, K = 320, N % 256 == 0 (packed columns), bias at most, fp16 output, 32-bit extents (the caller checks).
+int vcxgemm::launch_ws320_geglu(GemmArgs& a, hipStream_t s) {
+    a.tiles_m = (a.M - a.m_begin + WgCfg::TBM - 1) / WgCfg::TBM;
+    a.tiles_n = a.N / WgCfg::TBN;
+    return launch_ws_geglu(a, s);
 }
 
 int vcxgemm::launch_ws320(GemmArgs& a, hipStream_t s) {
