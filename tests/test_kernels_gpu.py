@@ -204,7 +204,7 @@ def test_gemm_weight_stationary_geglu_matches_the_tiled_engine(M, N, bias):
     registers, the bias rides in the accumulators, the finished tile's GELU epilogue in the shadows of the next tile's 32x32x16 MFMAs)
     against the tiled engine's GEGLU epilogue (knob GEMM_WS = 0; the bias enters at the other end of the sum: agreement to fp16
     rounding, not bit for bit) and against fp32; ragged M down to less than one tile, one to ten column blocks per row stream, guard
-    band of a padded output, bit-reproducible, a row's bits independent of M."""
+    band of a padded output, bit-reproducible, a row's bits independent of M and of the block -> row stream map (spare-CU streams)."""
     from viewcrafter_amd import ops
     from viewcrafter_amd.packing import pack_geglu
     K = 320
@@ -214,7 +214,7 @@ def test_gemm_weight_stationary_geglu_matches_the_tiled_engine(M, N, bias):
     wp, bp = pack_geglu(w.to(DEV), b.to(DEV))
     wp, bp = wp.half(), (bp.float().contiguous() if bias else None)
     outs = {}
-    for ws in (1, 0):
+    for ws in (1, 0, 3):                               # 3: without the cross-XCD row streams on the CUs that 32 / column blocks leaves over
         prev = ops.tune_set("GEMM_WS", ws)
         try:
             outs[ws] = ops.linear(x, wp, bp, geglu=True)
@@ -222,6 +222,7 @@ def test_gemm_weight_stationary_geglu_matches_the_tiled_engine(M, N, bias):
         finally:
             ops.tune_set("GEMM_WS", prev)
     assert outs[1].shape == (M, N // 2)
+    assert torch.equal(outs[3], outs[1]), "the block -> (row stream, column block) map must not change a bit"
     if M <= 30100:
         y = x.float() @ w.to(DEV).half().float().t() + b.to(DEV)
         ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])

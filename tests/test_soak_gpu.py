@@ -151,7 +151,7 @@ def test_attention_and_norm_kernels_are_bit_reproducible_at_the_benchmark_shapes
 
 def test_round5_kernels_are_bit_reproducible_at_the_benchmark_shapes():
     """The kernels of round 5 at the shapes the benchmark gives them, under a full chip: the weight-stationary K = 320 kernel in its plain,
-    residual and one-weight-set-per-frame / per-video forms, the folded-GroupNorm weight builder, both forms of the resident
+    residual, GEGLU and one-weight-set-per-frame / per-video forms, the folded-GroupNorm weight builder, both forms of the resident
     cross-attention kernel (level 0: 9216 queries x 5 heads per frame, 77 + 256 keys per video) and the d = 512 flash kernel of the
     VAE."""
     from viewcrafter_amd import ops
@@ -163,6 +163,12 @@ def test_round5_kernels_are_bit_reproducible_at_the_benchmark_shapes():
     res = rnd(M, C, seed=34).to(DEV).half()
     _soak(lambda: ops.linear(x, w, bias), calls, "weight-stationary linear")
     _soak(lambda: ops.linear(x, w, bias, residual=res), calls, "weight-stationary linear + residual")
+    # the weight-stationary GEGLU projection of level 0 (460800 x 2560 x 320 in the benchmark: here one video, ten column blocks per row stream)
+    from viewcrafter_amd.packing import pack_geglu
+    wg, bg = pack_geglu((rnd(2560, C, seed=38) / math.sqrt(C)).to(DEV), rnd(2560, seed=39).to(DEV))
+    wg, bg = wg.half(), bg.float().contiguous()
+    assert ops.tune_get("GEMM_WS") == 1
+    _soak(lambda: ops.linear(x, wg, bg, geglu=True), max(calls // 2, 10), "weight-stationary GEGLU projection")
     stats = ops.group_norm_stats(x.view(25, 9216, C))
     g, b = (1 + 0.2 * rnd(C, seed=35)).to(DEV), (0.1 * rnd(C, seed=36)).to(DEV)
     w32 = (rnd(C, C, seed=37) / math.sqrt(C)).to(DEV)

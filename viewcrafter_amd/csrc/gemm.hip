@@ -508,11 +508,12 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     // configuration is as good).  Not the LayerNorm-folded projections: a lean folded epilogue was built and measured level with the
     // tiled engine (0.407 vs 0.416 ms; profiles/r05_experiments.md section 3), so they stay there.
     // ... and for the GEGLU projection of level 0 (N = 2560 packed columns: ten 256-column blocks per row stream on one XCD), whose GELU
-    // epilogue rides in the next tile's MFMA stream there (knob GEMM_WS = 2: everything weight-stationary but this).  For EVERY M: its
+    // epilogue rides in the next tile's MFMA stream there (knob GEMM_WS = 2: everything weight-stationary but this; 3: this without its
+    // cross-XCD streams on the spare CUs).  For EVERY M: its
     // bias rides in the accumulators, so its last bits differ from the tiled engine's, and a row's bits must not depend on how many
     // rows the call has (B = 2 equals two B = 1 forwards bit for bit).  Beyond ten column blocks per row stream the tiled engine wins.
     if (dma_ok && !conv && geglu && !f32 && !lnf && d->K == 320 && d->N % 256 == 0 && d->N <= 2560 && !(flags & ~(VCX_GEMM_GEGLU | VCX_GEMM_BIAS_N)) &&
-        d->alpha == 1.0f && vcx_tune(VCX_TUNE_GEMM_WS) == 1 && force_cfg_unset())
+        d->alpha == 1.0f && (vcx_tune(VCX_TUNE_GEMM_WS) | 2) == 3 && force_cfg_unset())
         return launch_ws320_geglu(a, s);
     if (dma_ok && !conv && !geglu && !f32 && !lnf && d->K == 320 && d->N % 320 == 0 && d->N <= 1280 && d->M >= 8192 &&
         !(flags & VCX_GEMM_BIAS_M) && vcx_tune(VCX_TUNE_GEMM_WS) != 0 && force_cfg_unset())

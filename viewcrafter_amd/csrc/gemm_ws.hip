@@ -533,9 +533,14 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_geglu_kernel(Gem
     const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
 
     const int ntiles = p.tiles_m;
-    const int cb = (blockIdx.x >> 3) % p.tiles_n;
+    // G row streams of tiles_n column blocks each: 8 (G >> 3) of them with all their blocks on one XCD (block id = 8 slot + xcd), and G & 7
+    // more whose blocks take the CUs that division leaves over, across XCDs (ten column blocks: 3 streams per XCD = 240 blocks + 1
+    // stream on the 16 spare CUs; its activation tiles come from the memory side ten times instead of once - 4 % of the rows)
     const int G = gridDim.x / p.tiles_n;
-    const int t_first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) / p.tiles_n;
+    const int nb_main = (G >> 3) * 8 * p.tiles_n;
+    const int spare = (int)blockIdx.x - nb_main;
+    const int cb = spare < 0 ? (int)(blockIdx.x >> 3) % p.tiles_n : spare % p.tiles_n;
+    const int t_first = spare < 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) / p.tiles_n : (G & ~7) + spare / p.tiles_n;
     const int ncol0 = cb * WgCfg::TBN;                     // first PACKED column (weight row) of the block; its outputs start at ncol0 / 2
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -739,8 +744,15 @@ int launch_ws_geglu(const GemmArgs& a, hipStream_t s) {
     int streams_per_xcd = per_xcd / a.tiles_n;
     if (streams_per_xcd < 1) streams_per_xcd = 1;
     const int needed = (a.tiles_m + 7) / 8;
+    // the CUs that per_xcd / tiles_n leaves over run whole streams of their own across XCDs (fewer than 8 of them: the kernel reads
+    // their number as G & 7) - at ten column blocks 250 blocks instead of 240; not when the problem has fewer row tiles than streams,
+    // and not under knob GEMM_WS = 3 (the A/B setting of tools/ws_geglu_ab.py: one-XCD streams only)
+    int spare_streams = 0;
+    if (streams_per_xcd <= needed && 8 * streams_per_xcd * a.tiles_n < 8 * per_xcd && vcx_tune(VCX_TUNE_GEMM_WS) != 3)
+        spare_streams = (8 * per_xcd - 8 * streams_per_xcd * a.tiles_n) / a.tiles_n;
     if (streams_per_xcd > needed) streams_per_xcd = needed;
-    hipLaunchKernelGGL(kern, dim3(8 * streams_per_xcd * a.tiles_n), dim3(WgCfg::THREADS), WG_SMEM, s, a, a.a_bytes);
+    if (spare_streams > 7) spare_streams = 7;
+    hipLaunchKernelGGL(kern, dim3((8 * streams_per_xcd + spare_streams) * a.tiles_n), dim3(WgCfg::THREADS), WG_SMEM, s, a, a.a_bytes);
     return vcx_check_launch("vcx_gemm_f16(ws320 geglu)");
 }
 
