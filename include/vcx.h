@@ -313,7 +313,7 @@ int vcx_profile_end(double* out_host);
 #define VCX_TUNE_FLASH_IMPL 4      /* 0 auto | 1 phased v1 kernel | 2 software-pipelined v2 kernel           */
 #define VCX_TUNE_EXP0 5            /* free for one-off experiments (0)                                       */
 #define VCX_TUNE_EXP1 6
-#define VCX_TUNE_GEMM_WS 7         /* 1 | 0 = never use the weight-stationary kernels (K = 320) | 2 = not for the GEGLU projection | 3 = that one without its cross-XCD streams */
+#define VCX_TUNE_GEMM_WS 7         /* 1 | 0 = never use the weight-stationary kernels (K = 320) | 2 = not for the GEGLU projection | 3 = that one without its cross-XCD streams | 4 = not for the LayerNorm-folded projections | 5 = those for every N % 64 == 0 (tests) */
 #define VCX_TUNE_COUNT 8
 int vcx_tune_set(int knob, int value);
 int vcx_tune_get(int knob);

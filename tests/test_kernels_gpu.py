@@ -182,7 +182,7 @@ def test_gemm_weight_stationary_wide_and_lnfold(M, N, alpha):
     wf, colsum, bias_f = fold_layernorm(w32, gamma, beta, None)
     st = ops.row_stats(x, 1e-5)
     got = {}
-    for ws in (1, 0):           # (the folded projection stays on the tiled engine under both settings: its leg checks exactly that)
+    for ws in (4, 0):           # (4: everything weight-stationary but the folded projection - it stays on the tiled engine under both settings: its leg checks exactly that)
         prev = ops.tune_set("GEMM_WS", ws)
         try:
             got[ws] = (ops.linear(x, w32.half(), b, residual=res), ops.linear(x, wf, alpha * bias_f + b, alpha=alpha, ln_stats=st, ln_colsum=colsum))
@@ -190,11 +190,64 @@ def test_gemm_weight_stationary_wide_and_lnfold(M, N, alpha):
         finally:
             ops.tune_set("GEMM_WS", prev)
     for k, what in enumerate(("plain + residual", "LNFOLD")):
-        assert torch.equal(got[1][k], got[0][k]), f"{what}: weight-stationary and tiled results differ in {int((got[1][k] != got[0][k]).sum())} elements"
+        assert torch.equal(got[4][k], got[0][k]), f"{what}: weight-stationary and tiled results differ in {int((got[4][k] != got[0][k]).sum())} elements"
     if M <= 30000:
-        check(got[1][0], x.float() @ w32.half().float().t() + b + res.float(), name="ws wide")
+        check(got[4][0], x.float() @ w32.half().float().t() + b + res.float(), name="ws wide")
         ref = alpha * _ln_linear_ref(x, gamma, beta, w32, None) + b.double()
-        assert rel_l2(got[1][1], ref) <= 1e-3
+        assert rel_l2(got[4][1], ref) <= 1e-3
+
+
+@pytest.mark.parametrize("M,N,alpha,bias", [(9216 * 2, 960, 1.0, True), (20000 + 13, 640, 0.35, True), (460800, 960, 1.0, True), (8192 + 50, 1280, 1.0, False),
+                                            (50, 960, 0.125, True), (1000, 512, 1.0, True), (30000 + 7, 2560, 1.0, True), (9216, 576, 1.0, True)])
+def test_gemm_weight_stationary_lnfold_matches_the_tiled_engine(M, N, alpha, bias):
+    """gemm_ws320_lnf_kernel (K = 320, VCX_GEMM_LNFOLD: a block keeps a 256-column slice of the folded weight in owned accumulator
+    registers, colsum / bias' of the lane's columns beside them, the (mean, rstd) pairs of a tile's rows ride in its LDS stage, the
+    finished tile's outputs are formed behind the next tile's 32x32x16 MFMAs) against the tiled engine's folded epilogue (knob GEMM_WS = 4;
+    another K order: agreement to fp16 rounding, not bit for bit) and against fp64 LayerNorm -> Linear; ragged M down to less than one
+    tile, N = 512 ... 2560 with whole, half-empty and three-quarter-empty last column blocks, guard band of a padded output,
+    bit-reproducible, a row's bits independent of M."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import fold_layernorm
+    K = 320
+    x = (rnd(M, K, seed=181) * 2 + 0.4).to(DEV).half()
+    w32 = (rnd(N, K, seed=182) / math.sqrt(K)).to(DEV)
+    b = (0.2 * rnd(N, seed=183)).to(DEV) if bias else None
+    gamma = (1 + 0.3 * rnd(K, seed=184)).to(DEV)
+    beta = (0.2 * rnd(K, seed=185)).to(DEV)
+    wf, colsum, bias_f = fold_layernorm(w32, gamma, beta, None)
+    bf = (alpha * bias_f + b) if bias else (alpha * bias_f)
+    st = ops.row_stats(x, 1e-5)
+    outs = {}
+    for ws in (5, 4, 1):       # 5: the weight-stationary kernel for every N % 64 == 0 (the product rule, 1, wants a last column block >= 3/4 full)
+        prev = ops.tune_set("GEMM_WS", ws)
+        try:
+            outs[ws] = ops.linear(x, wf, bf, alpha=alpha, ln_stats=st, ln_colsum=colsum)
+            torch.cuda.synchronize()
+        finally:
+            ops.tune_set("GEMM_WS", prev)
+    pad = (N + 255) // 256 * 256 - N
+    assert torch.equal(outs[1], outs[5] if (pad <= 64 and 512 <= N <= 1536) else outs[4]), "the dispatch rule of csrc/gemm.hip"
+    outs[1] = outs[5]
+    assert outs[1].shape == (M, N)
+    e = rel_l2(outs[1], outs[4].float())
+    assert e <= 5e-4, f"weight-stationary vs tiled LNFOLD: rel-L2 {e:.2e}"
+    if M <= 30100:
+        ref = alpha * _ln_linear_ref(x, gamma, beta, w32, None) + (b.double() if bias else 0.0)
+        e_ws, e_tiled = rel_l2(outs[1], ref), rel_l2(outs[4], ref)
+        assert e_ws <= 1e-3 and e_ws <= 1.5 * e_tiled + 1e-5, (e_ws, e_tiled)
+    prev = ops.tune_set("GEMM_WS", 5)
+    try:
+        half_rows = max(M // 2 - 7, 1)                     # the first rows as a problem of their own: the same bits
+        part = ops.linear(x[:half_rows], wf, bf, alpha=alpha, ln_stats=st[:half_rows].contiguous(), ln_colsum=colsum)
+        assert torch.equal(part, outs[1][:half_rows])
+        big = torch.full((M + 5, N + 8), 3.0, device=DEV, dtype=torch.float16)
+        ops.gemm(x, wf, M=M, N=N, K=K, lda=K, out=big, ldc=N + 8, bias=bf, alpha=alpha, ln_stats=st, ln_colsum=colsum)
+        torch.cuda.synchronize()
+        assert torch.equal(big[:M, :N], outs[1]) and bool((big[M:] == 3.0).all()) and bool((big[:, N:] == 3.0).all())
+        again = ops.linear(x, wf, bf, alpha=alpha, ln_stats=st, ln_colsum=colsum)
+        assert torch.equal(again, outs[1])
+    finally:
+        ops.tune_set("GEMM_WS", prev)
 
 
 @pytest.mark.parametrize("M,N,bias", [(8192, 2560, True), (9216 * 2 + 13, 2560, True), (20000, 512, False), (8200, 256, True), (460800, 2560, True),

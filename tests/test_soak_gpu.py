@@ -169,6 +169,11 @@ def test_round5_kernels_are_bit_reproducible_at_the_benchmark_shapes():
     wg, bg = wg.half(), bg.float().contiguous()
     assert ops.tune_get("GEMM_WS") == 1
     _soak(lambda: ops.linear(x, wg, bg, geglu=True), max(calls // 2, 10), "weight-stationary GEGLU projection")
+    # ... and the LayerNorm-folded q | k | v projection (N = 960: four column blocks per row stream, the last three quarters full)
+    wq = (rnd(960, C, seed=61) / math.sqrt(C)).to(DEV).half()
+    bq, csq = rnd(960, seed=62).to(DEV), (0.01 * rnd(960, seed=63)).to(DEV)
+    st = ops.row_stats(x, 1e-5)
+    _soak(lambda: ops.linear(x, wq, bq, ln_stats=st, ln_colsum=csq), max(calls // 2, 10), "weight-stationary LayerNorm-folded projection")
     stats = ops.group_norm_stats(x.view(25, 9216, C))
     g, b = (1 + 0.2 * rnd(C, seed=35)).to(DEV), (0.1 * rnd(C, seed=36)).to(DEV)
     w32 = (rnd(C, C, seed=37) / math.sqrt(C)).to(DEV)

@@ -227,22 +227,24 @@ def store_data_hazards(listing):
 
 
 # Kernels that OWN accumulator registers by name (asm statements read / write them; the compiler must not allocate AGPRs of its own in
-# them, it does not know the owned ones are live): kernel name fragment -> number of v_accvgpr_write the source itself issues.
-AGPR_OWNERS = {"gemm_ws320_geglu_kernel": 160}
+# them, it does not know the owned ones are live): kernel name fragment -> number of v_accvgpr_write / v_accvgpr_read the source itself issues.
+AGPR_OWNERS = {"gemm_ws320_geglu_kernel": (160, 0),
+               # + colsum / bias' of the lane's columns in a[160:223], read back by the source itself: 64 reads in each of the 4 epilogue copies
+               "gemm_ws320_lnf_kernel": (224, 256)}
 
 
 def agpr_ownership(listing):
     """[(kernel, what)] - compiler-generated AGPR traffic or scratch in a kernel that owns its accumulator registers."""
     found = []
-    for frag, writes in AGPR_OWNERS.items():
+    for frag, (writes, reads) in AGPR_OWNERS.items():
         m = re.search(r"^(_Z\w*" + frag + r"\w*):[^\n]*\n(.*?)^\.Lfunc_end", listing, re.S | re.M)
         if not m:
             continue
         name, body = m.group(1), m.group(2)
         nw = len(re.findall(r"^\s*v_accvgpr_write_b32", body, re.M))
         nr = len(re.findall(r"^\s*v_accvgpr_(?:read|mov)_b32", body, re.M))
-        if nw != writes or nr:
-            found.append((name, "", f"{nw} v_accvgpr_write (the source issues {writes}) and {nr} v_accvgpr_read / mov: the compiler parks values in owned accumulator registers", 0))
+        if nw != writes or nr != reads:
+            found.append((name, "", f"{nw} v_accvgpr_write (the source issues {writes}) and {nr} v_accvgpr_read / mov (the source issues {reads}): the compiler parks values in owned accumulator registers", 0))
         if re.search(r"^\s*scratch_", body, re.M):
             found.append((name, "", "scratch traffic", 0))
     return found

@@ -513,8 +513,23 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     // bias rides in the accumulators, so its last bits differ from the tiled engine's, and a row's bits must not depend on how many
     // rows the call has (B = 2 equals two B = 1 forwards bit for bit).  Beyond ten column blocks per row stream the tiled engine wins.
     if (dma_ok && !conv && geglu && !f32 && !lnf && d->K == 320 && d->N % 256 == 0 && d->N <= 2560 && !(flags & ~(VCX_GEMM_GEGLU | VCX_GEMM_BIAS_N)) &&
-        d->alpha == 1.0f && (vcx_tune(VCX_TUNE_GEMM_WS) | 2) == 3 && force_cfg_unset())
+        d->alpha == 1.0f && ((vcx_tune(VCX_TUNE_GEMM_WS) | 2) == 3 || vcx_tune(VCX_TUNE_GEMM_WS) == 5) && force_cfg_unset())
         return launch_ws320_geglu(a, s);
+    // ... and for the LayerNorm-folded projections of level 0 (q | k | v of the spatial self-attention, N = 960, and the 640-column ones) on
+    // the same skeleton with a lighter epilogue (gemm_ws320_lnf_kernel; knob GEMM_WS = 4: everything weight-stationary but this).  For
+    // every M, like the GEGLU kernel: its bits differ from the tiled engine's (32x32x16 sums K in another order).
+    // Where: measured against the tiled engine at M = 460800 (profiles/r05am_ws_lnf_ab.txt) it wins when the last 256-column block is at
+    // least three quarters full - N = 512 (-15 %), 960 (-3 %), 1280 (-10 %); 640 (a half-empty third block) +5 %, 1920 level.  The kernel
+    // is bound by what a CU can pull through LDS-DMA (every column block streams all activation rows), not by its matrix work
+    // (profiles/r05an_ws_lnf_ablate.txt).  Knob GEMM_WS = 5 sends every N % 64 == 0 up to 2560 there (tests).
+    {
+        const int wsk = vcx_tune(VCX_TUNE_GEMM_WS);
+        const int pad = (d->N + 255) / 256 * 256 - d->N;
+        if (dma_ok && !conv && !geglu && !f32 && lnf == 1 && d->K == 320 && d->N % 64 == 0 && d->N <= 2560 &&
+            ((wsk >= 1 && wsk <= 3 && pad <= 64 && d->N >= 512 && d->N <= 1536) || wsk == 5) &&
+            !(flags & ~(VCX_GEMM_LNFOLD | VCX_GEMM_BIAS_N)) && 8ull * (unsigned long long)d->M < lim && force_cfg_unset())
+            return launch_ws320_lnfold(a, s);
+    }
     if (dma_ok && !conv && !geglu && !f32 && !lnf && d->K == 320 && d->N % 320 == 0 && d->N <= 1280 && d->M >= 8192 &&
         !(flags & VCX_GEMM_BIAS_M) && vcx_tune(VCX_TUNE_GEMM_WS) != 0 && force_cfg_unset())
         return launch_ws320(a, s);

@@ -133,6 +133,7 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
 int persistent_grid(int ntiles, int blocks_per_cu = 2);
 int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);
 int launch_ws320_geglu(GemmArgs& a, hipStream_t s);  // ... GEGLU projection, K = 320, N % 256 == 0
+int launch_ws320_lnfold(GemmArgs& a, hipStream_t s); // ... LayerNorm-folded projection (VCX_GEMM_LNFOLD), K = 320, N % 64 == 0
 int launch_ws320_units(GemmArgs& a, hipStream_t s);  // ... with one weight / bias set per unit of rows (vcx_gemm_units_f16)
 int launch_ws320(GemmArgs& a, hipStream_t s);        // gemm_ws.hip: weight-stationary linear layer, N = K = 320 (plain / COLSTATS epilogues)   // a.flags & VCX_GEMM_LNFOLD[_T] selects the folded-LayerNorm epilogue
 

@@ -555,9 +555,14 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_geglu_kernel(Gem
     f16v binit[2];
     {
         const half_t* wrow = p.W + (size_t)(ncol0 + wave * 64 + lq) * p.ldw + hi * 8;
-        static_for_ws<2 * WG_KS>([&](auto I_) __attribute__((always_inline)) {
-            constexpr int I = decltype(I_)::value, ab = I / WG_KS, kk = I % WG_KS;
-            wg_load_w<I>(*reinterpret_cast<const h8*>(wrow + (size_t)ab * 32 * p.ldw + kk * 16));
+        // twenty loads in flight, then their twenty register writes (each wg_load_w is an asm volatile: written load by load, hipcc
+        // waits with vmcnt(0) behind every single one - forty memory round trips in a row at the head of the kernel)
+        static_for_ws<2>([&](auto AB_) __attribute__((always_inline)) {
+            constexpr int ab = decltype(AB_)::value;
+            h8 wt[WG_KS];
+#pragma unroll
+            for (int kk = 0; kk < WG_KS; ++kk) wt[kk] = *reinterpret_cast<const h8*>(wrow + (size_t)ab * 32 * p.ldw + kk * 16);
+            static_for_ws<WG_KS>([&](auto KK_) __attribute__((always_inline)) { wg_load_w<WG_KS * ab + decltype(KK_)::value>(wt[decltype(KK_)::value]); });
         });
 #pragma unroll
         for (int ab = 0; ab < 2; ++ab)
@@ -736,6 +741,408 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_geglu_kernel(Gem
 #endif
 }
 
+// =============================================================================================================================
+// Weight-stationary LayerNorm-folded projection for K = 320 (level 0: the q | k | v projection of the spatial self-attention,
+// 460800 x 960 x 320, ten launches per step, and the 640-column ones: VCX_GEMM_LNFOLD, out = alpha rstd_m (x_m W'^T - mean_m colsum_n) + bias'_n).
+// The skeleton of gemm_ws320_geglu_kernel with a lighter epilogue: a block keeps a 256-column slice of the folded weight in the owned
+// accumulator registers a[0:159] (wave w: columns 64 w .. 64 w + 63 = the two 32-row A blocks of a 32x32x16 MFMA), a K slice is one
+// ds_read_b128 and two MFMAs, and the finished 64-row tile's outputs are formed behind the next tile's MFMAs 6 .. 45: 32 chunks of one
+// accumulator register in both row blocks each (two v_accvgpr_read for colsum_n / bias'_n, which live in the owned registers a[160:223];
+// four multiply-adds - the arithmetic of gemm_epilogue's LNF = 1 path: fma(acc, rb, fma(qb, colsum, bias)) - and a pair of fp16
+// conversions on every second one) and 8 chunks of a half exchange + one 16-byte store.  The row terms (mean, rstd) of a tile are
+// requested when its MFMAs start and used one tile later.  N % 64 == 0: the waves of the last column block that have no columns run
+// on zero weights and store nothing.  Agrees with the tiled engine to fp16 rounding (32x32x16 sums K in another order), bit-reproducible,
+// a row's bits independent of M and of the block map.
+// =============================================================================================================================
+constexpr int WL_STAGE = WG_STAGE + 1024;                                  // ... + the (mean, rstd) pairs of the tile's rows
+constexpr size_t WL_SMEM = (size_t)WG_RING * WL_STAGE;
+template <int R>
+__device__ __forceinline__ void wl_const_write(float x) {        // a[160 + R] = x
+    if constexpr (R == 0) asm volatile("v_accvgpr_write_b32 a160, %0" : : "v"(x) : "a160");
+    if constexpr (R == 1) asm volatile("v_accvgpr_write_b32 a161, %0" : : "v"(x) : "a161");
+    if constexpr (R == 2) asm volatile("v_accvgpr_write_b32 a162, %0" : : "v"(x) : "a162");
+    if constexpr (R == 3) asm volatile("v_accvgpr_write_b32 a163, %0" : : "v"(x) : "a163");
+    if constexpr (R == 4) asm volatile("v_accvgpr_write_b32 a164, %0" : : "v"(x) : "a164");
+    if constexpr (R == 5) asm volatile("v_accvgpr_write_b32 a165, %0" : : "v"(x) : "a165");
+    if constexpr (R == 6) asm volatile("v_accvgpr_write_b32 a166, %0" : : "v"(x) : "a166");
+    if constexpr (R == 7) asm volatile("v_accvgpr_write_b32 a167, %0" : : "v"(x) : "a167");
+    if constexpr (R == 8) asm volatile("v_accvgpr_write_b32 a168, %0" : : "v"(x) : "a168");
+    if constexpr (R == 9) asm volatile("v_accvgpr_write_b32 a169, %0" : : "v"(x) : "a169");
+    if constexpr (R == 10) asm volatile("v_accvgpr_write_b32 a170, %0" : : "v"(x) : "a170");
+    if constexpr (R == 11) asm volatile("v_accvgpr_write_b32 a171, %0" : : "v"(x) : "a171");
+    if constexpr (R == 12) asm volatile("v_accvgpr_write_b32 a172, %0" : : "v"(x) : "a172");
+    if constexpr (R == 13) asm volatile("v_accvgpr_write_b32 a173, %0" : : "v"(x) : "a173");
+    if constexpr (R == 14) asm volatile("v_accvgpr_write_b32 a174, %0" : : "v"(x) : "a174");
+    if constexpr (R == 15) asm volatile("v_accvgpr_write_b32 a175, %0" : : "v"(x) : "a175");
+    if constexpr (R == 16) asm volatile("v_accvgpr_write_b32 a176, %0" : : "v"(x) : "a176");
+    if constexpr (R == 17) asm volatile("v_accvgpr_write_b32 a177, %0" : : "v"(x) : "a177");
+    if constexpr (R == 18) asm volatile("v_accvgpr_write_b32 a178, %0" : : "v"(x) : "a178");
+    if constexpr (R == 19) asm volatile("v_accvgpr_write_b32 a179, %0" : : "v"(x) : "a179");
+    if constexpr (R == 20) asm volatile("v_accvgpr_write_b32 a180, %0" : : "v"(x) : "a180");
+    if constexpr (R == 21) asm volatile("v_accvgpr_write_b32 a181, %0" : : "v"(x) : "a181");
+    if constexpr (R == 22) asm volatile("v_accvgpr_write_b32 a182, %0" : : "v"(x) : "a182");
+    if constexpr (R == 23) asm volatile("v_accvgpr_write_b32 a183, %0" : : "v"(x) : "a183");
+    if constexpr (R == 24) asm volatile("v_accvgpr_write_b32 a184, %0" : : "v"(x) : "a184");
+    if constexpr (R == 25) asm volatile("v_accvgpr_write_b32 a185, %0" : : "v"(x) : "a185");
+    if constexpr (R == 26) asm volatile("v_accvgpr_write_b32 a186, %0" : : "v"(x) : "a186");
+    if constexpr (R == 27) asm volatile("v_accvgpr_write_b32 a187, %0" : : "v"(x) : "a187");
+    if constexpr (R == 28) asm volatile("v_accvgpr_write_b32 a188, %0" : : "v"(x) : "a188");
+    if constexpr (R == 29) asm volatile("v_accvgpr_write_b32 a189, %0" : : "v"(x) : "a189");
+    if constexpr (R == 30) asm volatile("v_accvgpr_write_b32 a190, %0" : : "v"(x) : "a190");
+    if constexpr (R == 31) asm volatile("v_accvgpr_write_b32 a191, %0" : : "v"(x) : "a191");
+    if constexpr (R == 32) asm volatile("v_accvgpr_write_b32 a192, %0" : : "v"(x) : "a192");
+    if constexpr (R == 33) asm volatile("v_accvgpr_write_b32 a193, %0" : : "v"(x) : "a193");
+    if constexpr (R == 34) asm volatile("v_accvgpr_write_b32 a194, %0" : : "v"(x) : "a194");
+    if constexpr (R == 35) asm volatile("v_accvgpr_write_b32 a195, %0" : : "v"(x) : "a195");
+    if constexpr (R == 36) asm volatile("v_accvgpr_write_b32 a196, %0" : : "v"(x) : "a196");
+    if constexpr (R == 37) asm volatile("v_accvgpr_write_b32 a197, %0" : : "v"(x) : "a197");
+    if constexpr (R == 38) asm volatile("v_accvgpr_write_b32 a198, %0" : : "v"(x) : "a198");
+    if constexpr (R == 39) asm volatile("v_accvgpr_write_b32 a199, %0" : : "v"(x) : "a199");
+    if constexpr (R == 40) asm volatile("v_accvgpr_write_b32 a200, %0" : : "v"(x) : "a200");
+    if constexpr (R == 41) asm volatile("v_accvgpr_write_b32 a201, %0" : : "v"(x) : "a201");
+    if constexpr (R == 42) asm volatile("v_accvgpr_write_b32 a202, %0" : : "v"(x) : "a202");
+    if constexpr (R == 43) asm volatile("v_accvgpr_write_b32 a203, %0" : : "v"(x) : "a203");
+    if constexpr (R == 44) asm volatile("v_accvgpr_write_b32 a204, %0" : : "v"(x) : "a204");
+    if constexpr (R == 45) asm volatile("v_accvgpr_write_b32 a205, %0" : : "v"(x) : "a205");
+    if constexpr (R == 46) asm volatile("v_accvgpr_write_b32 a206, %0" : : "v"(x) : "a206");
+    if constexpr (R == 47) asm volatile("v_accvgpr_write_b32 a207, %0" : : "v"(x) : "a207");
+    if constexpr (R == 48) asm volatile("v_accvgpr_write_b32 a208, %0" : : "v"(x) : "a208");
+    if constexpr (R == 49) asm volatile("v_accvgpr_write_b32 a209, %0" : : "v"(x) : "a209");
+    if constexpr (R == 50) asm volatile("v_accvgpr_write_b32 a210, %0" : : "v"(x) : "a210");
+    if constexpr (R == 51) asm volatile("v_accvgpr_write_b32 a211, %0" : : "v"(x) : "a211");
+    if constexpr (R == 52) asm volatile("v_accvgpr_write_b32 a212, %0" : : "v"(x) : "a212");
+    if constexpr (R == 53) asm volatile("v_accvgpr_write_b32 a213, %0" : : "v"(x) : "a213");
+    if constexpr (R == 54) asm volatile("v_accvgpr_write_b32 a214, %0" : : "v"(x) : "a214");
+    if constexpr (R == 55) asm volatile("v_accvgpr_write_b32 a215, %0" : : "v"(x) : "a215");
+    if constexpr (R == 56) asm volatile("v_accvgpr_write_b32 a216, %0" : : "v"(x) : "a216");
+    if constexpr (R == 57) asm volatile("v_accvgpr_write_b32 a217, %0" : : "v"(x) : "a217");
+    if constexpr (R == 58) asm volatile("v_accvgpr_write_b32 a218, %0" : : "v"(x) : "a218");
+    if constexpr (R == 59) asm volatile("v_accvgpr_write_b32 a219, %0" : : "v"(x) : "a219");
+    if constexpr (R == 60) asm volatile("v_accvgpr_write_b32 a220, %0" : : "v"(x) : "a220");
+    if constexpr (R == 61) asm volatile("v_accvgpr_write_b32 a221, %0" : : "v"(x) : "a221");
+    if constexpr (R == 62) asm volatile("v_accvgpr_write_b32 a222, %0" : : "v"(x) : "a222");
+    if constexpr (R == 63) asm volatile("v_accvgpr_write_b32 a223, %0" : : "v"(x) : "a223");
+}
+template <int R>
+__device__ __forceinline__ float wl_const_read() {               // a[160 + R]
+    float x;
+    if constexpr (R == 0) asm volatile("v_accvgpr_read_b32 %0, a160" : "=v"(x));
+    if constexpr (R == 1) asm volatile("v_accvgpr_read_b32 %0, a161" : "=v"(x));
+    if constexpr (R == 2) asm volatile("v_accvgpr_read_b32 %0, a162" : "=v"(x));
+    if constexpr (R == 3) asm volatile("v_accvgpr_read_b32 %0, a163" : "=v"(x));
+    if constexpr (R == 4) asm volatile("v_accvgpr_read_b32 %0, a164" : "=v"(x));
+    if constexpr (R == 5) asm volatile("v_accvgpr_read_b32 %0, a165" : "=v"(x));
+    if constexpr (R == 6) asm volatile("v_accvgpr_read_b32 %0, a166" : "=v"(x));
+    if constexpr (R == 7) asm volatile("v_accvgpr_read_b32 %0, a167" : "=v"(x));
+    if constexpr (R == 8) asm volatile("v_accvgpr_read_b32 %0, a168" : "=v"(x));
+    if constexpr (R == 9) asm volatile("v_accvgpr_read_b32 %0, a169" : "=v"(x));
+    if constexpr (R == 10) asm volatile("v_accvgpr_read_b32 %0, a170" : "=v"(x));
+    if constexpr (R == 11) asm volatile("v_accvgpr_read_b32 %0, a171" : "=v"(x));
+    if constexpr (R == 12) asm volatile("v_accvgpr_read_b32 %0, a172" : "=v"(x));
+    if constexpr (R == 13) asm volatile("v_accvgpr_read_b32 %0, a173" : "=v"(x));
+    if constexpr (R == 14) asm volatile("v_accvgpr_read_b32 %0, a174" : "=v"(x));
+    if constexpr (R == 15) asm volatile("v_accvgpr_read_b32 %0, a175" : "=v"(x));
+    if constexpr (R == 16) asm volatile("v_accvgpr_read_b32 %0, a176" : "=v"(x));
+    if constexpr (R == 17) asm volatile("v_accvgpr_read_b32 %0, a177" : "=v"(x));
+    if constexpr (R == 18) asm volatile("v_accvgpr_read_b32 %0, a178" : "=v"(x));
+    if constexpr (R == 19) asm volatile("v_accvgpr_read_b32 %0, a179" : "=v"(x));
+    if constexpr (R == 20) asm volatile("v_accvgpr_read_b32 %0, a180" : "=v"(x));
+    if constexpr (R == 21) asm volatile("v_accvgpr_read_b32 %0, a181" : "=v"(x));
+    if constexpr (R == 22) asm volatile("v_accvgpr_read_b32 %0, a182" : "=v"(x));
+    if constexpr (R == 23) asm volatile("v_accvgpr_read_b32 %0, a183" : "=v"(x));
+    if constexpr (R == 24) asm volatile("v_accvgpr_read_b32 %0, a184" : "=v"(x));
+    if constexpr (R == 25) asm volatile("v_accvgpr_read_b32 %0, a185" : "=v"(x));
+    if constexpr (R == 26) asm volatile("v_accvgpr_read_b32 %0, a186" : "=v"(x));
+    if constexpr (R == 27) asm volatile("v_accvgpr_read_b32 %0, a187" : "=v"(x));
+    if constexpr (R == 28) asm volatile("v_accvgpr_read_b32 %0, a188" : "=v"(x));
+    if constexpr (R == 29) asm volatile("v_accvgpr_read_b32 %0, a189" : "=v"(x));
+    if constexpr (R == 30) asm volatile("v_accvgpr_read_b32 %0, a190" : "=v"(x));
+    if constexpr (R == 31) asm volatile("v_accvgpr_read_b32 %0, a191" : "=v"(x));
+    if constexpr (R == 32) asm volatile("v_accvgpr_read_b32 %0, a192" : "=v"(x));
+    if constexpr (R == 33) asm volatile("v_accvgpr_read_b32 %0, a193" : "=v"(x));
+    if constexpr (R == 34) asm volatile("v_accvgpr_read_b32 %0, a194" : "=v"(x));
+    if constexpr (R == 35) asm volatile("v_accvgpr_read_b32 %0, a195" : "=v"(x));
+    if constexpr (R == 36) asm volatile("v_accvgpr_read_b32 %0, a196" : "=v"(x));
+    if constexpr (R == 37) asm volatile("v_accvgpr_read_b32 %0, a197" : "=v"(x));
+    if constexpr (R == 38) asm volatile("v_accvgpr_read_b32 %0, a198" : "=v"(x));
+    if constexpr (R == 39) asm volatile("v_accvgpr_read_b32 %0, a199" : "=v"(x));
+    if constexpr (R == 40) asm volatile("v_accvgpr_read_b32 %0, a200" : "=v"(x));
+    if constexpr (R == 41) asm volatile("v_accvgpr_read_b32 %0, a201" : "=v"(x));
+    if constexpr (R == 42) asm volatile("v_accvgpr_read_b32 %0, a202" : "=v"(x));
+    if constexpr (R == 43) asm volatile("v_accvgpr_read_b32 %0, a203" : "=v"(x));
+    if constexpr (R == 44) asm volatile("v_accvgpr_read_b32 %0, a204" : "=v"(x));
+    if constexpr (R == 45) asm volatile("v_accvgpr_read_b32 %0, a205" : "=v"(x));
+    if constexpr (R == 46) asm volatile("v_accvgpr_read_b32 %0, a206" : "=v"(x));
+    if constexpr (R == 47) asm volatile("v_accvgpr_read_b32 %0, a207" : "=v"(x));
+    if constexpr (R == 48) asm volatile("v_accvgpr_read_b32 %0, a208" : "=v"(x));
+    if constexpr (R == 49) asm volatile("v_accvgpr_read_b32 %0, a209" : "=v"(x));
+    if constexpr (R == 50) asm volatile("v_accvgpr_read_b32 %0, a210" : "=v"(x));
+    if constexpr (R == 51) asm volatile("v_accvgpr_read_b32 %0, a211" : "=v"(x));
+    if constexpr (R == 52) asm volatile("v_accvgpr_read_b32 %0, a212" : "=v"(x));
+    if constexpr (R == 53) asm volatile("v_accvgpr_read_b32 %0, a213" : "=v"(x));
+    if constexpr (R == 54) asm volatile("v_accvgpr_read_b32 %0, a214" : "=v"(x));
+    if constexpr (R == 55) asm volatile("v_accvgpr_read_b32 %0, a215" : "=v"(x));
+    if constexpr (R == 56) asm volatile("v_accvgpr_read_b32 %0, a216" : "=v"(x));
+    if constexpr (R == 57) asm volatile("v_accvgpr_read_b32 %0, a217" : "=v"(x));
+    if constexpr (R == 58) asm volatile("v_accvgpr_read_b32 %0, a218" : "=v"(x));
+    if constexpr (R == 59) asm volatile("v_accvgpr_read_b32 %0, a219" : "=v"(x));
+    if constexpr (R == 60) asm volatile("v_accvgpr_read_b32 %0, a220" : "=v"(x));
+    if constexpr (R == 61) asm volatile("v_accvgpr_read_b32 %0, a221" : "=v"(x));
+    if constexpr (R == 62) asm volatile("v_accvgpr_read_b32 %0, a222" : "=v"(x));
+    if constexpr (R == 63) asm volatile("v_accvgpr_read_b32 %0, a223" : "=v"(x));
+    return x;
+}
+template <int I>
+__device__ __forceinline__ void wl_mfma_zero(f16v& d, const h8& x) {       // D = W(a[4 I ..]) x X (first MFMA of a tile)
+    if constexpr (I == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[0:3], %1, 0" : "=&v"(d) : "v"(x));
+    if constexpr (I == 20) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[80:83], %1, 0" : "=&v"(d) : "v"(x));
+}
+
+__global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_lnf_kernel(GemmArgs p, unsigned a_bytes, unsigned s_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ln_stats), 0, (int)s_bytes, 0x00020000);
+
+    const int ntiles = p.tiles_m;
+    // the block -> (row stream, column block) map of gemm_ws320_geglu_kernel, spare-CU streams included
+    const int G = gridDim.x / p.tiles_n;
+    const int nb_main = (G >> 3) * 8 * p.tiles_n;
+    const int spare = (int)blockIdx.x - nb_main;
+    const int cb = spare < 0 ? (int)(blockIdx.x >> 3) % p.tiles_n : spare % p.tiles_n;
+    const int t_first = spare < 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) / p.tiles_n : (G & ~7) + spare / p.tiles_n;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int wcol = cb * WgCfg::TBN + wave * 64;          // first output column (weight row) of the wave
+    const bool wave_on = wcol < p.N;                       // N % 64 == 0: a wave has all of its 64 columns or none
+
+    // A fragments: lane (i = lq, hi) holds W'[wcol + 32 ab + i][16 kk + 8 hi .. + 7] (wg_load_w: the owned registers a[0:159]);
+    // colsum / bias' of the lane's 2 x 16 columns (accumulator register r = 4 q + c <-> column 32 ab + 8 q + 4 hi + c) in a[160:223]
+    {
+        const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const half_t* wrow = p.W + (size_t)(wave_on ? wcol + lq : 0) * p.ldw + hi * 8;
+        static_for_ws<2>([&](auto AB_) __attribute__((always_inline)) {         // twenty loads in flight, then their register writes
+            constexpr int ab = decltype(AB_)::value;
+            h8 wt[WG_KS];
+#pragma unroll
+            for (int kk = 0; kk < WG_KS; ++kk) wt[kk] = *reinterpret_cast<const h8*>(wrow + (size_t)(wave_on ? ab * 32 : 0) * p.ldw + kk * 16);
+            static_for_ws<WG_KS>([&](auto KK_) __attribute__((always_inline)) {
+                constexpr int kk = decltype(KK_)::value;
+                wg_load_w<WG_KS * ab + kk>(wave_on ? wt[kk] : zero8);
+            });
+        });
+        f4 cs[8], bq[8];                                  // (all sixteen loads in flight, then their register writes)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = (wave_on ? wcol : 0) + 32 * (i >> 2) + 8 * (i & 3) + 4 * hi;
+            cs[i] = *reinterpret_cast<const f4*>(p.ln_colsum + n);
+            bq[i] = (p.flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + n) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+        static_for_ws<8>([&](auto Q_) __attribute__((always_inline)) {
+            constexpr int i = decltype(Q_)::value, ab = i / 4, q = i % 4;
+            wl_const_write<16 * ab + 4 * q + 0>(cs[i][0]); wl_const_write<16 * ab + 4 * q + 1>(cs[i][1]);
+            wl_const_write<16 * ab + 4 * q + 2>(cs[i][2]); wl_const_write<16 * ab + 4 * q + 3>(cs[i][3]);
+            wl_const_write<32 + 16 * ab + 4 * q + 0>(bq[i][0]); wl_const_write<32 + 16 * ab + 4 * q + 1>(bq[i][1]);
+            wl_const_write<32 + 16 * ab + 4 * q + 2>(bq[i][2]); wl_const_write<32 + 16 * ab + 4 * q + 3>(bq[i][3]);
+        });
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
+
+    // LDS-DMA of one 64-row tile (as gemm_ws320_geglu_kernel)
+    const int drow = wave * 8 + (lane >> 3);
+    const unsigned dsrc = (unsigned)((lane & 7) ^ ((drow >> 1) & 7)) * 16u;
+    const unsigned rstep32 = 32u * (unsigned)p.lda * 2u;
+    int issued = 0;
+    int mark[WG_RING];
+    auto issue_tile = [&](int t, int buf) {
+        const int m0 = p.m_begin + t * WgCfg::TBM + drow;
+        const unsigned base = (unsigned)m0 * (unsigned)p.lda * 2u + dsrc;
+        const unsigned va = m0 < p.M ? base : OOB, vb = m0 + 32 < p.M ? base + rstep32 : OOB;
+        unsigned char* dst = smem_raw + buf * WL_STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < WG_PIECES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dst + (i >> 1) * 8192 + (i & 1) * 4096), 16, (i & 1) ? vb : va,
+                                                     (unsigned)(i >> 1) * (BK * 2), 0, 0);
+        issued += WG_PIECES;
+        // the (mean, rstd) pairs of the tile's 64 rows ride along: 512 contiguous bytes of ln_stats behind the stage's activation rows,
+        // one more piece of wave 0 (lanes 0-31 fetch two rows each; rows >= M read zeros through the descriptor's range check).  Through
+        // LDS, not into registers: a register load that is used a tile later gets a compiler-placed s_waitcnt in front of that use which
+        // must hold on every path into the tile - vmcnt(3), i.e. a drain of the DMA pieces just issued, in the first version of this kernel
+        if (wave == 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_s, (lds_ptr_t)(smem_raw + buf * WL_STAGE + WG_STAGE), 16,
+                                                     lane < 32 ? (unsigned)(p.m_begin + t * WgCfg::TBM) * 8u + (unsigned)lane * 16u : OOB, 0, 0, 0);
+            issued += 1;
+        }
+        mark[buf] = issued;
+    };
+    int xo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xo[i] = lds_off(lq, 2 * i + hi);
+
+    f16v acc[2][2][2];                        // [accumulator set][column half ab][row block]
+    unsigned coff[2][2];                      // byte offset of (lane's row in row block mb, wave's first column + 8 hi) of the tile in each accumulator set
+    f2v st[2][2];                             // (mean, rstd) of the lane's row in row block mb of the tile in each accumulator set
+    float rb[2], qb[2];                       // alpha rstd, -alpha rstd mean of the PENDING tile's rows
+    float ho[2][2];
+    u2v pk[2][4];
+
+    // The finished tile's epilogue in 40 chunks (sched_barrier(0) on both sides of every MFMA and chunk: the order below IS the
+    // instruction stream).  Per column half ab: chunks 0 .. 15 = accumulator register r in both row blocks, chunks 16 .. 19 =
+    // (row block, column pair k): half exchange + one 16-byte store.
+    auto chunk = [&](auto PAR_, auto C_) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value, ab = decltype(C_)::value / 20, c = decltype(C_)::value % 20;
+        if constexpr (c < 16) {
+            constexpr int r = c;
+            const float cs = wl_const_read<16 * ab + r>(), bn = wl_const_read<32 + 16 * ab + r>();
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                float t;
+                // as the instructions they are, in this order: left to itself hipcc pairs them into v_pk_fma_f32 with half-swapped
+                // operands (the form tools/isa_audit.py rejects library-wide)
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(qb[mb]), "v"(cs), "v"(bn));
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ho[mb][r & 1]) : "v"(acc[PAR][ab][mb][r]), "v"(rb[mb]), "v"(t));
+            }
+            if constexpr (r & 1) {            // outputs r - 1, r = word (r >> 1) & 1 of column group r >> 2
+                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    pk[mb][r >> 2][(r >> 1) & 1] = __builtin_bit_cast(unsigned, h2v{(half_t)ho[mb][0], (half_t)ho[mb][1]});
+            }
+        } else {
+            // column group q holds columns 8 q + 4 hi .. + 3: after the half swap lanes 0-31 own columns 16 k .. + 7, lanes 32-63 columns 16 k + 8 .. + 15
+            constexpr int mb = (c - 16) >> 1, k = (c - 16) & 1;
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[mb][2 * k][0], pk[mb][2 * k + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[mb][2 * k][1], pk[mb][2 * k + 1][1], false, false);
+            const epi_u4v w = {s0[0], s1[0], s0[1], s1[1]};
+#if !(defined(VCX_WL_ABL) && (VCX_WL_ABL & 8))
+            __builtin_amdgcn_raw_buffer_store_b128(w, srd_c, coff[PAR][mb], ab * 64 + k * 32, 0);
+#endif
+            asm volatile("s_nop 1" : : "v"(w));          // (the wide-store rule of tools/isa_audit.py)
+            issued += 1;
+        }
+    };
+    // the pending tile's row terms out of the (mean, rstd) pairs requested one tile ago
+    auto row_terms = [&](auto PAR_) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            rb[mb] = p.alpha * st[PAR][mb][1];
+            qb[mb] = -rb[mb] * st[PAR][mb][0];
+        }
+    };
+
+    // one tile: its 80 MFMAs into accumulator set PAR; PEND: the other set holds a finished tile whose chunks ride behind MFMAs 6 .. 45
+    auto tile = [&](auto PAR_, auto PEND_, int t, int i) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value;
+        constexpr bool PEND = decltype(PEND_)::value != 0;
+        const int buf = i % WG_RING;
+        __builtin_amdgcn_sched_barrier(0);
+        ws_wait_vmcnt(issued - mark[buf]);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + (WG_AHEAD + 1) * G < ntiles) issue_tile(t + (WG_AHEAD + 1) * G, (i + WG_AHEAD + 1) % WG_RING);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int m = p.m_begin + t * WgCfg::TBM + 32 * mb + lq;
+            st[PAR][mb] = *reinterpret_cast<const f2v*>(smem_raw + buf * WL_STAGE + WG_STAGE + (32 * mb + lq) * 8);      // (its stage is re-filled at the top of the next tile)
+            coff[PAR][mb] = (m < p.M && wave_on) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(wcol + 8 * hi)) * 2u : OOB;
+        }
+        if constexpr (PEND) row_terms(WInt<PAR ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned xb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xb[j] = (unsigned)(buf * WL_STAGE) + 2u * (unsigned)xo[j];
+            asm volatile("" : "+v"(xb[j]));
+        }
+        auto frag = [&](int kk, int mb) __attribute__((always_inline)) {
+            return *reinterpret_cast<const h8*>(smem_raw + xb[kk & 3] + (kk >> 2) * (WgCfg::TBM * BK * 2) + mb * 4096);
+        };
+        constexpr int XR = 4;
+        h8 xr[XR][2];
+#pragma unroll
+        for (int k = 0; k < XR; ++k)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) xr[k][mb] = frag(k, mb);
+        static_for_ws<WG_KS>([&](auto KK_) __attribute__((always_inline)) {
+            constexpr int kk = decltype(KK_)::value;
+            static_for_ws<4>([&](auto J_) __attribute__((always_inline)) {
+                constexpr int j = decltype(J_)::value, ab = j & 1, mb = j >> 1, n = 4 * kk + j;
+                __builtin_amdgcn_sched_barrier(0);
+#if defined(VCX_WL_ABL) && (VCX_WL_ABL & 2)
+                if constexpr (kk == 0) acc[PAR][ab][mb] = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; else acc[PAR][ab][mb][n & 15] += (float)xr[kk % XR][mb][0] * (float)xr[kk % XR][mb][1];
+#else
+                if constexpr (kk == 0) wl_mfma_zero<WG_KS * ab>(acc[PAR][ab][mb], xr[kk % XR][mb]);
+                else wg_mfma_acc<WG_KS * ab + kk>(acc[PAR][ab][mb], xr[kk % XR][mb]);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ab == 1 && kk + XR < WG_KS) xr[kk % XR][mb] = frag(kk + XR, mb);
+#if defined(VCX_WL_ABL) && (VCX_WL_ABL & 1)        // timing-only builds (tools/ws_lnf_ab.py <library>): 1 no arithmetic chunks, 2 no MFMAs, 8 no stores
+                if constexpr (PEND && n >= 6 && n < 46 && (n - 6) % 20 >= 16) chunk(WInt<PAR ^ 1>{}, WInt<n - 6>{});
+#else
+                if constexpr (PEND && n >= 6 && n < 46) chunk(WInt<PAR ^ 1>{}, WInt<n - 6>{});
+#endif
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    auto drain = [&](auto PAR_) __attribute__((always_inline)) {
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs (asm: hipcc does not know their latency) have written their results
+        __builtin_amdgcn_sched_barrier(0);
+        row_terms(PAR_);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for_ws<40>([&](auto C_) __attribute__((always_inline)) { chunk(PAR_, C_); });
+    };
+
+    int t = t_first, i = 0;
+#pragma unroll
+    for (int k = 0; k <= WG_AHEAD; ++k)
+        if (t + k * G < ntiles) issue_tile(t + k * G, k);
+    if (t < ntiles) {
+        tile(WInt<0>{}, WInt<0>{}, t, i);
+        t += G; ++i;
+        for (;;) {
+            if (t >= ntiles) {
+                drain(WInt<0>{});
+                break;
+            }
+            tile(WInt<1>{}, WInt<1>{}, t, i);
+            t += G; ++i;
+            if (t >= ntiles) {
+                drain(WInt<1>{});
+                break;
+            }
+            tile(WInt<0>{}, WInt<1>{}, t, i);
+            t += G; ++i;
+        }
+    }
+#endif
+}
+
+int launch_ws_lnf(const GemmArgs& a, hipStream_t s) {
+    static VcxLdsAttr lds;
+    auto kern = gemm_ws320_lnf_kernel;
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WL_SMEM, "vcx_gemm_f16(ws320 lnfold)")) return VCX_ELAUNCH;
+    const int per_xcd = persistent_grid(1 << 30, 1) / 8;
+    int streams_per_xcd = per_xcd / a.tiles_n;
+    if (streams_per_xcd < 1) streams_per_xcd = 1;
+    const int needed = (a.tiles_m + 7) / 8;
+    int spare_streams = 0;                      // (the block map of launch_ws_geglu)
+    if (streams_per_xcd <= needed && 8 * streams_per_xcd * a.tiles_n < 8 * per_xcd)
+        spare_streams = (8 * per_xcd - 8 * streams_per_xcd * a.tiles_n) / a.tiles_n;
+    if (streams_per_xcd > needed) streams_per_xcd = needed;
+    if (spare_streams > 7) spare_streams = 7;
+    hipLaunchKernelGGL(kern, dim3((8 * streams_per_xcd + spare_streams) * a.tiles_n), dim3(WgCfg::THREADS), WL_SMEM, s, a, a.a_bytes,
+                       (unsigned)(8ull * (unsigned long long)a.M));
+    return vcx_check_launch("vcx_gemm_f16(ws320 lnfold)");
+}
+
 int launch_ws_geglu(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
     auto kern = gemm_ws320_geglu_kernel;
@@ -809,6 +1216,13 @@ int vcxgemm::launch_ws320_geglu(GemmArgs& a, hipStream_t s) {
     a.tiles_m = (a.M - a.m_begin + WgCfg::TBM - 1) / WgCfg::TBM;
     a.tiles_n = a.N / WgCfg::TBN;
     return launch_ws_geglu(a, s);
+}
+
+// LayerNorm-folded projection (VCX_GEMM_LNFOLD), linear mode, K = 320, N % 64 == 0, bias at most, fp16 output, 32-bit extents, 8 M < 4 GiB (the caller checks).
+int vcxgemm::launch_ws320_lnfold(GemmArgs& a, hipStream_t s) {
+    a.tiles_m = (a.M - a.m_begin + WgCfg::TBM - 1) / WgCfg::TBM;
+    a.tiles_n = (a.N + WgCfg::TBN - 1) / WgCfg::TBN;
+    return launch_ws_lnf(a, s);
 }
 
 int vcxgemm::launch_ws320(GemmArgs& a, hipStream_t s) {
