@@ -437,7 +437,7 @@ def main():
         ach = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MI355X_FP16_DENSE_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / MI355X_FP16_DENSE_TFLOPS, "traffic": None,
-                           "kernel": "gemm_dma_kernel<TileCfg,CONV,GEGLU,OUT_F32> (csrc/gemm_dma.hip) + gemm_ws320_pipe_kernel for the K = 320 layers of level 0 "
+                           "kernel": "gemm_dma_kernel<TileCfg,CONV,GEGLU,OUT_F32> (csrc/gemm_dma.hip) + gemm_ws320_pipe / _geglu / _lnf kernels for the K = 320 layers of level 0 "
                                      "(csrc/gemm_ws.hip); <0.5% of FLOPs on the register-staged gemm_kernel fallback",
                            "launches_per_step": gemm["launches"] / args.steps,
                            "avg_launch_ms": gemm["ms"] / max(gemm["launches"], 1),
