@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--no-gpu-legs", action="store_true", help="skip parity-vs-oracle and the eager fp16 baseline on the GPU")
     ap.add_argument("--no-extra", action="store_true", help="skip the step times of the other two published configurations")
     ap.add_argument("--no-video", action="store_true", help="skip the measured 50-step video after the timed region")
+    ap.add_argument("--no-telemetry", action="store_true", help="no clock / power sampling thread beside the timed region")
     ap.add_argument("--no-shared-prefix", action="store_true", help="evaluate cond and uncond as a plain B=2 forward (A/B of the "
                     "shared CFG prefix: the layers ahead of the first cross-attention see identical inputs and run once by default)")
     ap.add_argument("--stub", action="store_true", help="CPU self-test of the launch / timing / reporting harness (gloo ranks, a "
@@ -367,6 +368,12 @@ def main():
     unet = model.model.diffusion_model
     unet.use_hip_graph = bool(args.graph)
     profile_in_region = not (args.graph or args.no_profile)
+    # graphics clock / socket power sampled every 50 ms by a side thread from the warm-up on (tools/telemetry.py: amdsmi gpu_metrics or
+    # sysfs hwmon); the statistics of the samples that fall inside the timed region go into the line as `telemetry`
+    from tools.telemetry import Telemetry
+    tm = Telemetry(device_index=dev_index, period_s=0.05) if rank == 0 and not args.no_telemetry else None
+    if tm is not None:
+        tm.__enter__()
     with torch.no_grad():
         for i in range(args.warmup):
             x = one_step(x, i)
@@ -378,6 +385,8 @@ def main():
             x = one_step(x, i)
         sync()
         elapsed = time.perf_counter() - t0
+        if tm is not None:
+            tm.__exit__(None, None, None)
         if profile_in_region:
             prof = ops.profile_end()
         else:   # per-family HIP-event timing on extra eager steps of the same loop (not part of `value`)
@@ -432,6 +441,9 @@ def main():
                    "parallelism": f"trajectory-sharded x{world} (no in-step collective)"},
     }
     if rank == 0:
+        if tm is not None:
+            out["telemetry"] = tm.summary(t0, t0 + elapsed)
+            out["telemetry"]["scope"] = "rank 0's GPU, samples inside the timed region"
         gemm = prof["gemm"]
         flops_per_step = sum(v["flops"] for v in prof.values()) / args.steps
         ach = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
@@ -555,8 +567,9 @@ def main():
                 del x2, cond2, uc2
             sampler._cfg_cache = None
             # Two clips per GPU on two HIP streams (viewcrafter_amd/interleave.py; what ViewCrafter.run_diffusion_many does with a rank's
-            # clips): 2 x 3 DDIM steps of the headline workload one clip after the other, then interleaved step by step - aggregate rate
-            # of both clips.  A throughput mode for several trajectories per GPU; `value` above is ONE trajectory per GPU.
+            # clips under VCX_CLIPS_PER_GPU=2 - opt-in since round 6, the default is one clip after the other): 2 x 3 DDIM steps of the
+            # headline workload one clip after the other, then interleaved step by step - aggregate rate of both clips, with the clock /
+            # power telemetry of each leg.  `value` above is ONE trajectory per GPU.
             from viewcrafter_amd.interleave import run_interleaved, step_yield
             xa, conda, uca = synth_conditioning(T, h, w, device, seed=123)
             xb = torch.randn_like(xa)
@@ -574,17 +587,28 @@ def main():
                 return xx
             with torch.no_grad():
                 res = {}
+                tms = {}
                 for lanes in (1, 2, 1, 2):
                     torch.cuda.synchronize()
-                    t0 = time.perf_counter()
+                    tl = Telemetry(device_index=dev_index, period_s=0.05) if tm is not None else None
+                    if tl is not None:
+                        tl.__enter__()
+                    t0l = time.perf_counter()
                     outs2 = run_interleaved(clip, [(0, xa), (1, xb)], n_lanes=lanes)
                     torch.cuda.synchronize()
-                    res.setdefault(lanes, []).append(time.perf_counter() - t0)
+                    res.setdefault(lanes, []).append(time.perf_counter() - t0l)
+                    if tl is not None:
+                        tl.__exit__(None, None, None)
+                        sm = tl.summary()
+                        tms.setdefault(lanes, []).append({k: (sm.get(k) or {}).get("mean") for k in ("sclk_mhz", "power_w")})
                     assert all(torch.isfinite(o).all() for o in outs2)
             seq, two = min(res[1]), min(res[2])
             out["extra"]["two_clips_per_gpu"] = {
                 "workload": args.workload, "ddim_steps_per_clip": 3, "clips": 2,
                 "one_after_the_other_steps_per_s": 6 / seq, "two_streams_steps_per_s": 6 / two, "gain": seq / two,
+                "default": "one after the other (VCX_CLIPS_PER_GPU=1); the two-stream mode is opt-in: its sign depends on the box "
+                           "(builder's boxes +3 ... +9 %, the driver's box of round 5 -8.7 %)",
+                "telemetry_mean": {"one_after_the_other": tms.get(1), "two_streams": tms.get(2)},
                 "note": "aggregate DDIM steps/s of two independent trajectories on one GPU; interleaved step by step on two HIP streams "
                         "(bit-identical outputs: tests/test_entry_gpu.py::test_two_clips_per_gpu_on_two_streams_equal_the_plain_loop); "
                         "the headline `value` stays one trajectory per GPU"}

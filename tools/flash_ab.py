@@ -1,8 +1,15 @@
 """A/B of the two flash-attention kernels (knob FLASH_IMPL: 1 = phased v1, 2 = software-pipelined v2) on the UNet's self-attention
 shapes, interleaved rounds in one process, median / min ms and TF/s, plus the largest difference between the two outputs.
-    python tools/flash_ab.py [rounds]"""
+    python tools/flash_ab.py [rounds] [library]
+With a library built with -DVCX_FLASH2_ABLATIONS (tools/build_abl.sh flash -DVCX_FLASH2_ABLATIONS) the stream variants of the pipelined
+kernel run side by side as well (knob EXP1 = 10 + VAR: 1 = permuted K rows / no half swaps, 2 = paired row sums)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from viewcrafter_amd import _lib
+ABL = len(sys.argv) > 2
+if ABL:
+    _lib.LIB_PATH = os.path.join(ROOT, sys.argv[2])
 from viewcrafter_amd import ops
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
@@ -15,6 +22,8 @@ for N, G, heads in shapes:
     qk = qk.half()
     vt = torch.randn(C, G * N, device="cuda").half()
     variants = {"v1": (1, 0), "v2": (2, 0)}       # name: (FLASH_IMPL, EXP1); with tools/_abl/libvcx_abl.so also "v2-mfma-sum": (2, 2)
+    if ABL:
+        variants.update({"var0": (2, 10), "var1": (2, 11), "var2": (2, 12), "var3": (2, 13)})
     outs, times = {}, {k: [] for k in variants}
     for k in variants:
         outs[k] = torch.empty(G * N, C, device="cuda", dtype=torch.float16)

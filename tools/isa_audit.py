@@ -25,7 +25,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "viewcrafter_amd", "csrc", "attention_v2.hip")
-KERNELS = ("flash2_d64_kernelILi0ELi0E", "flash2_d64_kernelILi0ELi1E")      # <no ablation, row sums by MFMA | by VALU>
+KERNELS = ("flash2_d64_kernelILi0ELi0E", "flash2_d64_kernelILi0ELi1E")      # <no ablation, row sums by MFMA | by VALU, any stream variant>
 MIN_MFMA_GAP = 16
 N_AGPR = 132
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -31,6 +31,11 @@ __global__ void __launch_bounds__(512) kfill(float* out, long long* cyc) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(threadIdx.x * 1e-3f); b[j] = (_Float16)(j * 1e-2f); }
     const float c1 = 1.0001f, c2 = 0.5f;
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v vp[4], cp = {1.0001f, 0.5f};
+    for (int i = 0; i < 4; ++i) vp[i] = f2v{threadIdx.x * 1e-3f, (float)i};
+    f2v ones4 = {1.875f, 1.875f};      // (bit pattern irrelevant for timing)
+    asm volatile("" : "+v"(cp), "+v"(ones4));
     __syncthreads();
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITERS; ++it) {
@@ -47,6 +52,14 @@ __global__ void __launch_bounds__(512) kfill(float* out, long long* cyc) {
                 else if (KIND == 4) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(v[r]) : "v"(c1), "v"(c2));      // round 5: row sums of packed fp16 probabilities
                 else if (KIND == 5) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(v[r]) : "v"(c1), "v"(c2));
                 else if (KIND == 6) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[r]) : "v"(c1));
+                // round 6 (what the flash kernel's softmax stream could be made of): packed fp32 add, an add with a compiler-style s_nop 0 behind
+                // it, a 4x4x4 MFMA with a ones operand (sums four packed fp16 values per lane on the matrix pipe in 2 passes), max3, half swap
+                else if (KIND == 7) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(vp[r & 3]) : "v"(cp));
+                else if (KIND == 8) asm volatile("v_add_f32 %0, %0, %1\n\ts_nop 0" : "+v"(v[r]) : "v"(c1));
+                else if (KIND == 9) asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+v"(a16[r]) : "v"(ones4), "v"(cp));
+                else if (KIND == 10) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(c1), "v"(c2));
+                else if (KIND == 11) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(v[r]), "+v"(v[(r + 4) & 7]));
+                else if (KIND == 12) asm volatile("s_nop 0");
                 else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(c1), "v"(c2));
             }
         }
@@ -56,7 +69,7 @@ __global__ void __launch_bounds__(512) kfill(float* out, long long* cyc) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += v[i] + a16[i][0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s += a32[i][0] + a32[i][9];
+    for (int i = 0; i < 4; ++i) s += a32[i][0] + a32[i][9] + vp[i][0] + vp[i][1];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
@@ -119,8 +132,27 @@ void run(K kern, const char* name, int threads, int groups) {
         run(kfill<MF, 8, KIND>, label " + 8", threads, 8);                                          \
     }
 
-int main() {
+#define SWEEP1(MF, KIND, label)                                                                     \
+    for (int threads : {256}) {                                                                     \
+        run(kfill<MF, 0, KIND>, label " + 0", threads, 8); run(kfill<MF, 2, KIND>, label " + 2", threads, 8); \
+        run(kfill<MF, 4, KIND>, label " + 4", threads, 8); run(kfill<MF, 6, KIND>, label " + 6", threads, 8); \
+        run(kfill<MF, 8, KIND>, label " + 8", threads, 8); run(kfill<MF, 12, KIND>, label " + 12", threads, 8); \
+    }
+
+int main(int argc, char** argv) {
     printf("cycles per group = 1 MFMA + NF fillers; 256 threads = one wave per SIMD, 512 = two (first wave of each SIMD pair shown: w0, w4)\n");
+    if (argc > 1) {      // round 6: the candidates for the flash kernel's softmax stream, one wave per SIMD, beside 32x32x16 MFMAs
+        SWEEP1(32, 6, "mfma32x32x16 + v_add_f32")
+        SWEEP1(32, 7, "mfma32x32x16 + v_pk_add_f32")
+        SWEEP1(32, 8, "mfma32x32x16 + (v_add_f32, s_nop 0)")
+        SWEEP1(32, 12, "mfma32x32x16 + s_nop 0")
+        SWEEP1(32, 9, "mfma32x32x16 + v_mfma_4x4x4 (ones)")
+        SWEEP1(32, 10, "mfma32x32x16 + v_max3_f32")
+        SWEEP1(32, 11, "mfma32x32x16 + v_permlane32_swap")
+        SWEEP1(32, 1, "mfma32x32x16 + v_exp_f32")
+        SWEEP1(32, 3, "mfma32x32x16 + v_cvt_pk")
+        return 0;
+    }
     SWEEP(16, 0, "mfma16x16x32 + fma")
     SWEEP(16, 2, "mfma16x16x32 + (1 exp : 3 fma)")
     SWEEP(16, 3, "mfma16x16x32 + cvt_pk")

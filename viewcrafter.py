@@ -96,10 +96,15 @@ class ViewCrafter:
             if world > 1 or index > 0:
                 torch.manual_seed(self.opts.seed + index)
             return self.run_diffusion(clip)
-        # two of a rank's clips in flight at a time, step by step on two HIP streams (viewcrafter_amd/interleave.py: +8.6 % aggregate
-        # rate at 576x1024x25, same outputs); VCX_CLIPS_PER_GPU=1 runs them one after the other
-        lanes = int(os.environ.get("VCX_CLIPS_PER_GPU", "2"))
-        return parallel.run_sharded(one, list(clips), gather=True, lanes=lanes)
+        # VCX_CLIPS_PER_GPU=2: two of a rank's clips in flight at a time, step by step on two HIP streams (viewcrafter_amd/interleave.py;
+        # same outputs).  OPT-IN since round 6: the builder's boxes measured +3 ... +9 % aggregate rate, the driver's box of round 5
+        # -8.7 % (BENCH_r05.json extra.two_clips_per_gpu gain 0.913) - a mode whose sign depends on the box is not a default; it also
+        # doubles the activation memory of a rank.  Default: one clip after the other.
+        try:
+            lanes = max(1, int(os.environ.get("VCX_CLIPS_PER_GPU", "1")))
+        except ValueError:
+            lanes = 1
+        return parallel.run_sharded(one, list(clips), gather=True, lanes=lanes, model=self.diffusion)
 
     def nvs_from_renderings(self, path):
         """Diffusion leg only: `path` holds point-cloud renders [T, H, W, 3] in [0, 1] (.pt or .npy) - or several

@@ -47,6 +47,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef unsigned u32;
 typedef u32 u4v __attribute__((ext_vector_type(4)));
 [[maybe_unused]] constexpr float F2_DEFER = 8.0f;
+#define F2_VAR_DEFAULT 1                  // stream variant (Stream<SUMV, VAR>): 1 no half swaps (permuted K rows) | 2 paired row sums
 #define F2_SUMV_DEFAULT 1                 // row sums: 0 = on the matrix pipe, 1 = v_add_f32 in the softmax stream          // log2 units, as FLASH_DEFER in attention.hip
 #define FI __device__ __forceinline__
 
@@ -193,8 +194,13 @@ FI float acc_read_l() {     // every element of L_B is the row sum of this lane'
 #define V_MAX2I(r, a, b) asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b))
 
 // ---- the softmax stream of one tile as a list of micro-operations (each one asm statement), in issue order
-template <int SUMV> struct Stream {
-    static constexpr int PAIR = SUMV ? 44 : 28;    // one (key half, k-step) chunk of BOTH query blocks: 16 exp2, [16 adds,] 8 packs, 4 half swaps
+// VAR (bits): 1 = the K fragment rows are read in the order that makes the lane's eight scores of a k-step eight CONSECUTIVE keys, so the
+// packed probabilities are the PV B operand as they stand (no v_permlane32_swap); 2 = row sums two scores at a time (v_pk_add_f32)
+template <int SUMV, int VAR> struct Stream {
+    static constexpr bool NOSWAP = (VAR & 1) != 0, PKSUM = SUMV && (VAR & 2);
+    static constexpr int NADD = SUMV ? (PKSUM ? 8 : 16) : 0;      // row-sum micro-operations per chunk pair
+    static constexpr int GRP = (NADD + 8) / 4;                    // one group = the adds of a word of BOTH query blocks, then its two packs
+    static constexpr int PAIR = 16 + NADD + 8 + (NOSWAP ? 0 : 4); // one (key half, k-step) chunk of BOTH query blocks: 16 exp2, [adds,] 8 packs, [4 half swaps]
     static constexpr int EXP = 4 * PAIR;
     static constexpr int ALL = EXP + 32 + 2;       // + row maxima of the next tile (4 accumulators x 8, round-robin), 2 combines (this lane's half of the row)
     static constexpr int MID = 20;                 // issued as one burst behind the per-tile barrier (covers the V^T fragment latency)
@@ -202,6 +208,8 @@ template <int SUMV> struct Stream {
     static constexpr int PVG = SUMV ? 4 : 6;       // gaps per k-step unit in the PV phase
 };
 #define V_ACC(acc, x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x))
+#define V_PKACC(acc, x) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x))
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 // One VALU micro-operation of the softmax stream.
 // F < EXP, tile `cur`: chunk t = 2 kb + s holds this lane's scores of keys 16 t + 4 hi + {0..3} and 16 t + 8 + 4 hi + {0..3} (the
@@ -211,27 +219,27 @@ template <int SUMV> struct Stream {
 // Chunks come in the order the PV MFMAs consume them.  F >= EXP: row maxima over tile `nxt`.
 // (separate scalars, not arrays, for the maxima and sums: an array becomes one register tuple, and a write to one element of a
 // tuple makes hipcc pad an s_nop in front of the next statement that touches any other element)
-template <int F, int SUMV>
+template <int F, int SUMV, int VAR>
 FI void filler(f16v (&cur)[2][2], f16v (&nxt)[2][2], u4v (&pf)[2][2][2], float& m00, float& m01, float& m10, float& m11, float& mx0, float& mx1,
-               float& l00, float& l01, float& l10, float& l11) {
-    using ST = Stream<SUMV>;
+               float& l00, float& l01, float& l10, float& l11, f2v& lp0, f2v& lp1) {
+    using ST = Stream<SUMV, VAR>;
     if constexpr (F < ST::EXP) {
         constexpr int t = F / ST::PAIR, q = F % ST::PAIR, kb = t / 2, s = t % 2;
         if constexpr (q < 16) {
             constexpr int b = q % 2, e = q / 2;
             V_EXP2(cur[b][kb][8 * s + e]);
-        } else if constexpr (q < ST::PAIR - 4) {
-            if constexpr (SUMV) {
-                constexpr int idx = q - 16, grp = idx / 6, w = idx % 6, b = w % 2;
-                if constexpr (w < 4) {
+        } else if constexpr (q < 16 + ST::NADD + 8) {
+            constexpr int idx = q - 16, grp = idx / ST::GRP, w = idx % ST::GRP, b = w % 2;
+            if constexpr (w < ST::GRP - 2) {
+                if constexpr (ST::PKSUM) {      // both scores of word grp at once: (l_b0, l_b1) += (S[2 grp], S[2 grp + 1])
+                    const f2v pair = __builtin_shufflevector(cur[b][kb], cur[b][kb], 8 * s + 2 * grp, 8 * s + 2 * grp + 1);
+                    if constexpr (b == 0) V_PKACC(lp0, pair); else V_PKACC(lp1, pair);
+                } else {
                     constexpr int e = 2 * grp + w / 2;
                     float& ll = b == 0 ? (w / 2 == 0 ? l00 : l01) : (w / 2 == 0 ? l10 : l11);
                     V_ACC(ll, cur[b][kb][8 * s + e]);
-                } else {
-                    V_PACK(pf[b][kb][s][grp], cur[b][kb][8 * s + 2 * grp], cur[b][kb][8 * s + 2 * grp + 1]);
                 }
             } else {
-                constexpr int idx = q - 16, b = idx % 2, grp = idx / 2;
                 V_PACK(pf[b][kb][s][grp], cur[b][kb][8 * s + 2 * grp], cur[b][kb][8 * s + 2 * grp + 1]);
             }
         } else {
@@ -262,7 +270,7 @@ FI float row_max_across_halves(float m) {
 // ABL: timing-only ablation bits (knob EXP0; 0 in production, anything else computes garbage): 1 no vmcnt wait at the barrier,
 // 2 no barrier, 4 no exp2, 8 no softmax stream at all, 16 no fragment reads in the loop, 32 no DMA in the loop, 64 no MFMAs
 // SUMV: row sums by v_add_f32 in the softmax stream (1) or by 8 extra MFMAs per tile (0)
-template <int ABL, int SUMV>
+template <int ABL, int SUMV, int VAR>
 __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // four distinct objects: slot s of K / V^T (see the header: compile-time slots keep the DMA waits exact)
@@ -333,14 +341,22 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
     // ---- fragment addresses inside a slot (element offsets).  K fragment unit u = 4 kb + s: row kb*32 + lq, chunk 2 s + hi;
     // V^T fragment (unit t = 2 kb + s, d half db): row db*32 + lq, chunk 4 kb + 2 s + hi = 2 t + hi - the same four offsets
     // (the row swizzle depends on lq only; kb / db add 32 rows = an immediate)
-    int fa[4];
+    // VAR & 1: K fragment row i of a 32-key half holds key pi(i) = i with bits 2 and 3 exchanged.  The 32x32 accumulator puts row
+    // i = 8 q + 4 hi + c into register 4 q + c of lane half hi, so registers 8 s .. 8 s + 7 of a lane then are keys 16 s + 8 hi + {0..7} -
+    // eight consecutive keys, the PV B operand of k-step s as it stands (the rows of an MFMA's A operand are independent: any
+    // assignment of keys to rows is legal, and the rows a 16-lane group reads stay the same 16 rows, conflict-free as before)
+    int fa[4], fk[4];
+    const int lqk = (VAR & 1) ? ((lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1)) : lq;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) fa[s] = tile_off2(lq, 2 * s + hi);
+    for (int s = 0; s < 4; ++s) {
+        fa[s] = tile_off2(lq, 2 * s + hi);
+        fk[s] = tile_off2(lqk, 2 * s + hi);
+    }
     h8 kf[4];                   // ring of K fragment units (slot u % 4), requested two units ahead
     h8 vf[3][2];                // ring of V^T fragment units (slot t % 3) x d half
     auto read_k = [&](const half_t* cK, auto u_c) {
         constexpr int u = decltype(u_c)::value;
-        kf[u % 4] = *reinterpret_cast<const h8*>(cK + (u / 4) * 32 * 64 + fa[u % 4]);
+        kf[u % 4] = *reinterpret_cast<const h8*>(cK + (u / 4) * 32 * 64 + fk[u % 4]);
     };
     auto read_v = [&](const half_t* cV, auto t_c) {
         constexpr int t = decltype(t_c)::value;
@@ -354,7 +370,9 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
     u4v pf[2][2][2];            // packed fp16 probabilities [query block][key half][k-step] (8 halves = the B operand of a PV MFMA)
     float m00, m01, m10, m11, mx0, mx1;     // row maxima: partial (per score accumulator) and per query block
     float l00 = 0.f, l01 = 0.f, l10 = 0.f, l11 = 0.f;      // SUMV: row sums, two partial accumulators per query block
-    using ST = Stream<SUMV>;
+    f2v lp0 = {0.f, 0.f}, lp1 = {0.f, 0.f};                // ... as register pairs (VAR & 2)
+    using ST = Stream<SUMV, VAR>;
+    constexpr bool PKSUM = ST::PKSUM;
     constexpr int NF_EXP = ST::EXP, NF_ALL = ST::ALL, NF_MID = ST::MID, NF_PAIR = ST::PAIR, NGAP = ST::NGAP, PVG = ST::PVG;
     float negm[2] = {0.f, 0.f};
 
@@ -383,7 +401,7 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
     if (ntiles > 2) dma_k(C0{}, 2);
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(S[0][0][0]), "+v"(S[0][0][1]), "+v"(S[0][1][0]), "+v"(S[0][1][1]));   // MFMA results -> VALU
     // first tile: the max moves to the row maximum itself (nothing is accumulated yet)
-    sfor<NF_EXP, NF_ALL>([&](auto f_c) { filler<decltype(f_c)::value, SUMV>(S[1], S[0], pf, m00, m01, m10, m11, mx0, mx1, l00, l01, l10, l11); });
+    sfor<NF_EXP, NF_ALL>([&](auto f_c) { filler<decltype(f_c)::value, SUMV, VAR>(S[1], S[0], pf, m00, m01, m10, m11, mx0, mx1, l00, l01, l10, l11, lp0, lp1); });
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const float m = row_max_across_halves(b ? mx1 : mx0);
@@ -447,7 +465,7 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
             constexpr int fmid = HAS_NEXT ? f1 - NF_MID : f1;       // gap 15: [f0, fmid) before the barrier, [fmid, f1) behind it
             sfor<f0, (gp == 15 ? fmid : f1)>([&](auto f_c) {
                 constexpr int F = decltype(f_c)::value;
-                if constexpr (!(ABL & 8) && !((ABL & 4) && F < NF_EXP && F % NF_PAIR < 16)) filler<F, SUMV>(S[PAR], S[PAR ^ 1], pf, m00, m01, m10, m11, mx0, mx1, l00, l01, l10, l11);
+                if constexpr (!(ABL & 8) && !((ABL & 4) && F < NF_EXP && F % NF_PAIR < 16)) filler<F, SUMV, VAR>(S[PAR], S[PAR ^ 1], pf, m00, m01, m10, m11, mx0, mx1, l00, l01, l10, l11, lp0, lp1);
             });
             // (3) later requests
             if constexpr (gp == 16 + PVG && !(ABL & 16)) read_v(cV, std::integral_constant<int, 3>{});      // slot 0: unit 0's PV MFMAs are gaps 16-19
@@ -471,7 +489,7 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
                 __builtin_amdgcn_sched_barrier(0);
                 sfor<fmid, f1>([&](auto f_c) {
                     constexpr int F = decltype(f_c)::value;
-                    if constexpr (!(ABL & 8) && !((ABL & 4) && F < NF_EXP && F % NF_PAIR < 16)) filler<F, SUMV>(S[PAR], S[PAR ^ 1], pf, m00, m01, m10, m11, mx0, mx1, l00, l01, l10, l11);
+                    if constexpr (!(ABL & 8) && !((ABL & 4) && F < NF_EXP && F % NF_PAIR < 16)) filler<F, SUMV, VAR>(S[PAR], S[PAR ^ 1], pf, m00, m01, m10, m11, mx0, mx1, l00, l01, l10, l11, lp0, lp1);
                 });
                 __builtin_amdgcn_s_waitcnt(0xc07f);        // V^T units 0-2
             }
@@ -486,7 +504,10 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
                     delta[b] = fmaxf(row_max_across_halves(b ? mx1 : mx0), 0.f);
                     alpha[b] = __builtin_amdgcn_exp2f(-delta[b]);
                     negm[b] -= delta[b];
-                    if constexpr (SUMV) {
+                    if constexpr (PKSUM) {
+                        if (b == 0) { lp0[0] *= alpha[0]; lp0[1] *= alpha[0]; }
+                        else { lp1[0] *= alpha[1]; lp1[1] *= alpha[1]; }
+                    } else if constexpr (SUMV) {
                         if (b == 0) { l00 *= alpha[0]; l01 *= alpha[0]; }
                         else { l10 *= alpha[1]; l11 *= alpha[1]; }
                     }
@@ -520,7 +541,7 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
         constexpr int b = decltype(b_c)::value;
         float l_tot;
         if constexpr (SUMV) {
-            const float lsum = b == 0 ? l00 + l01 : l10 + l11;
+            const float lsum = PKSUM ? (b == 0 ? lp0[0] + lp0[1] : lp1[0] + lp1[1]) : (b == 0 ? l00 + l01 : l10 + l11);
             l_tot = lsum + __shfl_xor(lsum, 32);
         } else {
             l_tot = acc_read_l<b>();                       // both key halves of the row are in the MFMA row sum already
@@ -549,7 +570,8 @@ __global__ void __launch_bounds__(256, 1) flash2_d64_kernel(Flash2Args p) {
 int vcx_flash2_launch(const Flash2Args& a, hipStream_t s) {
     const int prob_pad = (a.nprob + 7) / 8 * 8;
     const dim3 grid((unsigned)(a.nqb * prob_pad));
-#define F2_LAUNCH(A, SV) hipLaunchKernelGGL((flash2_d64_kernel<A, SV>), grid, dim3(256), 0, s, a)
+#define F2_LAUNCH(A, SV) hipLaunchKernelGGL((flash2_d64_kernel<A, SV, F2_VAR_DEFAULT>), grid, dim3(256), 0, s, a)
+#define F2_LAUNCHV(A, SV, V) hipLaunchKernelGGL((flash2_d64_kernel<A, SV, V>), grid, dim3(256), 0, s, a)
 #ifndef VCX_FLASH2_ABLATIONS
     // the product: one kernel, no knob read - the scratch knobs EXP0 / EXP1 ("free for one-off experiments", vcx.h) must not be
     // able to turn every 9216-key self-attention into VCX_EINVAL because some unrelated experiment set them
@@ -559,6 +581,12 @@ int vcx_flash2_launch(const Flash2Args& a, hipStream_t s) {
     if (abl == 0 && sumv == 0) F2_LAUNCH(0, F2_SUMV_DEFAULT);
     else if (abl == 0 && sumv == 1) F2_LAUNCH(0, 1);
     else if (abl == 0 && sumv == 2) F2_LAUNCH(0, 0);
+    else if (abl == 0 && sumv >= 10 && sumv <= 13) {       // A/B of the stream variants: EXP1 = 10 + VAR
+        if (sumv == 10) F2_LAUNCHV(0, 1, 0);
+        else if (sumv == 11) F2_LAUNCHV(0, 1, 1);
+        else if (sumv == 12) F2_LAUNCHV(0, 1, 2);
+        else F2_LAUNCHV(0, 1, 3);
+    }
     else if (abl == 1) F2_LAUNCH(1, F2_SUMV_DEFAULT);
     else if (abl == 3) F2_LAUNCH(3, F2_SUMV_DEFAULT);
     else if (abl == 4) F2_LAUNCH(4, F2_SUMV_DEFAULT);
@@ -575,5 +603,6 @@ int vcx_flash2_launch(const Flash2Args& a, hipStream_t s) {
     }
 #endif
 #undef F2_LAUNCH
+#undef F2_LAUNCHV
     return vcx_check_launch("vcx_attn_flash_d64_f16(v2)");
 }

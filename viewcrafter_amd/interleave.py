@@ -2,15 +2,24 @@
 
 Every kernel of the denoising graph fills the MI355X by itself, so one stream leaves idle what a kernel cannot use - the partial last
 round of a persistent GEMM, the launch gaps, the matrix pipe under an HBM-bound normalisation.  A second, INDEPENDENT trajectory on a
-second stream fills it: +8.6 % aggregate DDIM steps/s for two 576x1024x25 clips, bit-identical outputs (tools/two_stream_ab.py,
-profiles/r05q_two_stream_ab.txt).  Within one trajectory there is nothing independent to run (profiles/r05_experiments.md section 4).
+second stream can fill it - or get in its way: the builder's boxes measured +3.0 ... +8.6 % aggregate DDIM steps/s for two 576x1024x25
+clips (tools/two_stream_ab.py, profiles/r05q, r05ac, r05al, r05at), the driver's box of round 5 MINUS 8.7 % (BENCH_r05.json
+extra.two_clips_per_gpu: 5.329 steps/s one after the other, 4.865 on two streams, gain 0.913).  The sign depends on the box, so the mode
+is OPT-IN (VCX_CLIPS_PER_GPU=2; default 1 = one clip after the other); outputs are bit-identical either way.  Within one trajectory
+there is nothing independent to run (profiles/r05_experiments.md section 4).
 
 How: each clip runs the UNMODIFIED driver code (image_guided_synthesis: encoders, DDIM loop, decode) in its own host thread under its own
 `torch.cuda.stream`; a baton makes the threads take turns, and the sampler hands the baton on after every DDIM step (`step_yield`), so the
 host queues step i of clip A on stream A, then step i of clip B on stream B, ... and the GPU always has two streams to draw from.  The
 global random generators (CPU and current CUDA device) are part of a lane's context: saved when it gives the baton away, restored when it
 gets it back, so every clip sees exactly the sequence of draws it would see running alone after `torch.manual_seed(seed + index)` - the
-results do not depend on whether, or with whom, a clip shared the GPU."""
+results do not depend on whether, or with whom, a clip shared the GPU.
+
+Shared model state: the lanes run the SAME model, whose kernel-layout weight packs are built lazily by the first forward that needs them
+(PackedModule.packed()).  `prepack()` builds them all on the caller's stream before any lane starts (run_sharded does that when it is
+given the model); independently of that, a lane that takes the baton for the first time - and every lane that takes it from a lane that
+has just finished (its VAE decode may have built packs) - makes its stream wait for an event recorded on the yielding lane's stream, so
+a pack written on stream A is never read on stream B before the kernels that wrote it have run."""
 import threading
 
 import torch
@@ -26,12 +35,31 @@ def step_yield():
 
 
 class _Interleaver:
-    def __init__(self, n_lanes):
+    def __init__(self, n_lanes, streams=None):
         self.cv = threading.Condition()
+        self.streams = streams        # the lanes' HIP streams (None on a GPU-less host)
         self.turn = 0
         self.alive = [True] * n_lanes
         self.rng = [None] * n_lanes
-        self.cuda = torch.cuda.is_available()
+        self.cuda = torch.cuda.is_available() and streams is not None and streams[0] is not None
+        self.handoff = None           # event recorded on the yielding lane's stream at its last hand-over
+        self.sync_next = True         # the next lane to take the baton waits for it (first hand-over to each lane, hand-over from a finished lane)
+        self.seen = [False] * n_lanes
+
+    def _record(self, k, retiring):
+        """(under self.cv) the yielding lane k marks where its stream stands"""
+        if self.cuda:
+            self.handoff = torch.cuda.Event()
+            self.handoff.record(self.streams[k])
+            if retiring:
+                self.sync_next = True
+
+    def _wait_handoff(self, k):
+        """(under self.cv) lane k has the baton: order its stream behind the yielding lane's work where packs may have been built"""
+        if self.cuda and self.handoff is not None and (self.sync_next or not self.seen[k]):
+            self.streams[k].wait_event(self.handoff)
+        self.sync_next = False
+        self.seen[k] = True
 
     def _save(self, k):
         self.rng[k] = (torch.random.get_rng_state(), torch.cuda.get_rng_state() if self.cuda else None)
@@ -55,6 +83,7 @@ class _Interleaver:
             while self.turn != k:
                 self.cv.wait()
             self._load(k)
+            self._wait_handoff(k)
 
     def _switch(self, k):
         with self.cv:
@@ -62,18 +91,38 @@ class _Interleaver:
             if nxt == k:
                 return
             self._save(k)
+            self._record(k, False)
             self.turn = nxt
             self.cv.notify_all()
             while self.turn != k:
                 self.cv.wait()
             self._load(k)
+            self._wait_handoff(k)
 
     def _retire(self, k):
         with self.cv:
             self._save(k)
+            self._record(k, True)
             self.alive[k] = False
             self.turn = self._next_alive(k)
             self.cv.notify_all()
+
+
+def prepack(model):
+    """Build every lazily built kernel-layout pack below `model` now, on the current stream (PackedModule.packed()), so that no lane of
+    run_interleaved is the first to need one.  Modules whose pack depends on call-time information keep building it on demand."""
+    from .lvdm.modules.attention import PackedModule
+    if model is None:
+        return 0
+    n = 0
+    for m in model.modules():
+        if isinstance(m, PackedModule):
+            try:
+                m.packed()
+                n += 1
+            except NotImplementedError:
+                pass
+    return n
 
 
 def run_interleaved(fn, items, n_lanes=2):
@@ -91,23 +140,28 @@ def run_interleaved(fn, items, n_lanes=2):
     final_rng = None
     for base in range(0, len(items), n_lanes):
         group = items[base:base + n_lanes]
-        il = _Interleaver(len(group))
         errors = [None] * len(group)
         streams = [torch.cuda.Stream() for _ in group] if cuda else [None] * len(group)
+        il = _Interleaver(len(group), streams)
         device = torch.cuda.current_device() if cuda else None
+        # thread-local torch state of the caller that a new thread does not inherit (a caller's `with torch.no_grad()` must hold in the lanes)
+        grad_on, infer_on = torch.is_grad_enabled(), torch.is_inference_mode_enabled()
 
         def lane(k):
             _tls.interleaver, _tls.lane = il, k
             try:
-                il._acquire(k)
-                index, item = group[k]
-                if cuda:
-                    torch.cuda.set_device(device)
-                    streams[k].wait_stream(main)
-                    with torch.cuda.stream(streams[k]):
+                with torch.inference_mode(infer_on), torch.set_grad_enabled(grad_on):
+                    if cuda:
+                        torch.cuda.set_device(device)
+                        streams[k].wait_stream(main)
+                        with torch.cuda.stream(streams[k]):
+                            il._acquire(k)
+                            index, item = group[k]
+                            out[base + k] = fn(item, index)
+                    else:
+                        il._acquire(k)
+                        index, item = group[k]
                         out[base + k] = fn(item, index)
-                else:
-                    out[base + k] = fn(item, index)
             except BaseException as e:      # noqa: BLE001 - re-raised by the caller
                 errors[k] = e
             finally:

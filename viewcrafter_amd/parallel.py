@@ -160,13 +160,16 @@ def gather_results(local, n_items, dst=0, _force=False):
     return [out[owner_of(i, world)][i // world] for i in range(n_items)]
 
 
-def run_sharded(fn, items, gather=True, lanes=1):
+def run_sharded(fn, items, gather=True, lanes=1, model=None):
     """Apply fn(item, index) to the items this rank owns; optionally gather the tensor results on rank 0.  lanes > 1: that many of the
-    rank's items in flight at a time, interleaved step by step on their own HIP streams (interleave.run_interleaved)."""
+    rank's items in flight at a time, interleaved step by step on their own HIP streams (interleave.run_interleaved); `model`: the
+    module the lanes share - its lazily built weight packs are built here, on the caller's stream, before the lanes start."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     mine = list(shard_indices(len(items), rank, world))
     if lanes > 1 and len(mine) > 1:
-        from .interleave import run_interleaved
+        from .interleave import prepack, run_interleaved
+        if model is not None and torch.cuda.is_available():
+            prepack(model)
         local = dict(zip(mine, run_interleaved(fn, [(i, items[i]) for i in mine], n_lanes=lanes)))
     else:
         local = {i: fn(items[i], i) for i in mine}
