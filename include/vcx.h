@@ -36,8 +36,8 @@ extern "C" {
  * vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32.  5: vcx_gemm_desc starts with
  * struct_size - a descriptor of another layout is rejected instead of read past its end; ldcs; vcx_clip_preprocess_f32,
  * vcx_add_nchw_f32_to_nhwc_f16.  6: vcx_ddim_ws_bytes, ws_bytes argument of the DDIM steps.  7: vcx_groupnorm_fold_linear_f16,
- * vcx_gemm_units_f16, vcx_attn_flash_d512_f16. */
-#define VCX_ABI_VERSION 7
+ * vcx_gemm_units_f16, vcx_attn_flash_d512_f16.  8: vcx_gemm_desc grows rowstats / rowstats_eps (VCX_GEMM_ROWSTATS). */
+#define VCX_ABI_VERSION 8
 
 int vcx_abi_version(void);
 const char* vcx_last_error(void);
@@ -96,6 +96,16 @@ int vcx_device_arch(char* name_host, int len);
  * GroupNorm) or by a concatenated skip (openaimodel3d.py:596: the two producers write their columns of ONE moment buffer,
  * ldcs = C1 + C2).  DMA kernel only (K % 64 == 0 / cin % 64 == 0), fp16 output, M % 64 == 0, no GEGLU, no LNFOLD. */
 #define VCX_GEMM_COLSTATS 0x200
+/* LayerNorm statistics from the producing layer (round 6): besides out, the layer writes rowstats[m] = (mean, rstd = 1 / sqrt(var +
+ * rowstats_eps)) of the fp16-ROUNDED output row m over its N columns - what vcx_rowstats_f16 computes from the stored tensor, so the
+ * LayerNorm-folded projection behind it (VCX_GEMM_LNFOLD: nn.LayerNorm -> nn.Linear of BasicTransformerBlock, attention.py:226-246)
+ * needs no statistics pass.  The row's deviations from a per-row shift (the median of three of its values) are summed and squared on
+ * the matrix pipe (ones x D and the diagonal of D^T D, fp32 accumulation of fp16 products), per 80-column strip, and the four strips
+ * of a row merged Chan-style in a fixed order: robust to |mean| >> std, bit-reproducible, independent of M; agrees with
+ * vcx_rowstats_f16 to fp32 rounding of the sums, not bit for bit (another summation order).  Only where ONE block owns whole rows:
+ * the weight-stationary kernel, linear mode, N = K = 320, M >= 8192, BIAS_N / RESIDUAL at most, fp16 output (the attention output
+ * projections and proj_in of the C = 320 level); with vcx_gemm_units_f16 too.  Any other shape: VCX_EINVAL. */
+#define VCX_GEMM_ROWSTATS 0x400
 
 typedef struct vcx_gemm_desc {
     size_t struct_size;   /* = sizeof(vcx_gemm_desc) of the header the caller was compiled against; anything else is VCX_EINVAL */
@@ -117,6 +127,9 @@ typedef struct vcx_gemm_desc {
     const float* ln_colsum; /* VCX_GEMM_LNFOLD[_T]: fp32 row sums of the folded weight              */
     float* colstats;        /* VCX_GEMM_COLSTATS: out, fp32 [M / 64][ldcs][2] (first of this call's N columns) */
     int64_t ldcs;           /* columns between consecutive strips of colstats; 0 = N                */
+    float* rowstats;        /* VCX_GEMM_ROWSTATS: out, fp32 [M][2] = (mean, rstd) of every output row, 8-byte aligned */
+    float rowstats_eps;     /* VCX_GEMM_ROWSTATS: the LayerNorm's eps                                */
+    int32_t reserved0;      /* 0                                                                     */
 } vcx_gemm_desc;
 
 int vcx_gemm_f16(const vcx_gemm_desc* desc_host, void* stream);

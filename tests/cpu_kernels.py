@@ -22,7 +22,7 @@ def _view2d(t, rows, cols, ld, extra=0):
 
 def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, residual=None, ldr=None, rowadd=None, rowadd_div=0,
          geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None, ln_stats=None, ln_colsum=None, ln_t=False, colstats=None,
-         colstats_ld=None, colstats_col=0):
+         colstats_ld=None, colstats_col=0, rowstats=None, rowstats_eps=1e-5):
     n_out = N // 2 if geglu else N
     ldw = K if ldw is None else ldw
     W = _view2d(w, N, K, ldw).float()
@@ -82,16 +82,20 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
         mean = v.mean(1)
         m2 = ((v - mean.unsqueeze(1)) ** 2).sum(1)
         colstats.view(M // 64, cld, 2)[:, colstats_col:colstats_col + n_out] = torch.stack([mean, m2], dim=-1)
+    if rowstats is not None:       # VCX_GEMM_ROWSTATS: LayerNorm's statistics of the ROUNDED output rows
+        assert not out_f32 and not geglu and conv is None
+        rowstats.view(M, 2).copy_(row_stats(stored, rowstats_eps))
     return out
 
 
-def gemm_units(a, wn, bn, *, unit_rows, out=None):
+def gemm_units(a, wn, bn, *, unit_rows, out=None, rowstats=None, rowstats_eps=1e-5):
     M, K = a.shape
     units, N, _ = wn.shape
     if out is None:
         out = torch.empty((M, N), dtype=_f16)
     for u in range(units):
-        gemm(a[u * unit_rows:], wn[u], M=unit_rows, N=N, K=K, lda=a.stride(0), out=out[u * unit_rows:], ldc=out.stride(0), bias=bn[u])
+        gemm(a[u * unit_rows:], wn[u], M=unit_rows, N=N, K=K, lda=a.stride(0), out=out[u * unit_rows:], ldc=out.stride(0), bias=bn[u],
+             rowstats=None if rowstats is None else rowstats[u * unit_rows:(u + 1) * unit_rows], rowstats_eps=rowstats_eps)
     return out
 
 

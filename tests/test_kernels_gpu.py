@@ -697,6 +697,150 @@ def test_rowstats_are_layernorms_statistics(rows, C):
     assert rel_l2(st[:, 1], 1.0 / torch.sqrt(var + 1e-5)) <= 1e-6
 
 
+def _check_rowstats(st, y, eps, name, mean_tol=2e-6, rstd_tol=6e-5, chunk=65536):
+    """st [M, 2] fp32 = (mean, rstd) against fp64 LayerNorm statistics of the stored fp16 rows y, 65536 rows at a time.  Stated tolerance:
+    mean 2e-6 of the tensor's magnitude (the row sum is exact products into fp32); rstd 6e-5 relative, a tenth of the fp16 step of the
+    normalised value it scales (fp32 sums of squares; a strip that is shifted although its row is not offset rounds its deviations to
+    fp16: ~3e-5 in the variance of that row)."""
+    assert torch.isfinite(st).all(), f"{name}: non-finite statistics"
+    for r0 in range(0, y.shape[0], chunk):
+        yd = y[r0:r0 + chunk].double()
+        mu, var = yd.mean(-1), yd.var(-1, unbiased=False)
+        scale = float(yd.abs().max()) + 1.0
+        e_mu = float((st[r0:r0 + chunk, 0].double() - mu).abs().max())
+        assert e_mu <= mean_tol * scale, f"{name}: mean off by {e_mu:.3e} (rows {r0}..., |y| max {scale:.1f})"
+        rstd = 1.0 / torch.sqrt(var + eps)
+        e_rs = float(((st[r0:r0 + chunk, 1].double() - rstd).abs() / rstd).max())
+        assert e_rs <= rstd_tol, f"{name}: rstd off by {e_rs:.3e} relative (rows {r0}...)"
+
+
+@pytest.mark.parametrize("M,variant,offset", [(8192, "bias", 0.0), (10000 + 13, "bias+res", 0.0), (9216 * 3, "plain", 0.0), (460800, "bias+res", 0.0),
+                                              (460800, "bias", 0.0), (20000, "bias+res", 1000.0), (16384 + 32, "res", -300.0), (8192 + 31, "bias", 50.0)])
+def test_gemm_rowstats_are_the_layernorm_statistics_of_the_output(M, variant, offset):
+    """VCX_GEMM_ROWSTATS (round 6): the weight-stationary N = K = 320 layer also writes (mean, rstd) of every fp16-ROUNDED output row -
+    what vcx_rowstats_f16 reads the stored tensor for (reference: the nn.LayerNorm in front of attn1 / attn2 of BasicTransformerBlock,
+    attention.py:226-228,238-241).  Against fp64 statistics of the very tensor the layer stored and against vcx_rowstats_f16; the output
+    itself must not change by a bit; rows with a common offset 1000x their spread (sums of squares cancel there unless the row is
+    shifted first); sentinels behind the statistics; the same bits for the first rows as a problem of their own and from run to run."""
+    from viewcrafter_amd import ops
+    N = K = 320
+    eps = 1e-5
+    x = rnd(M, K, seed=811).to(DEV).half()
+    scale = 1.0
+    w = (rnd(N, K, seed=812) * scale / math.sqrt(K)).to(DEV).half()
+    b = (rnd(N, seed=813) * 0.3 + offset).to(DEV) if ("bias" in variant or offset) else None
+    res = (rnd(M, N, seed=814) * 0.7).to(DEV).half() if "res" in variant else None
+    assert ops.rowstats_ok(M, N, K, ldr=N if res is not None else 0)
+    guard = torch.full((M + 64, 2), 7.0, device=DEV)
+    st = guard[:M]
+    y = ops.linear(x, w, b, residual=res, rowstats=st, rowstats_eps=eps)
+    y_plain = ops.linear(x, w, b, residual=res)
+    assert torch.equal(y, y_plain), "the statistics are a by-product: the output must not change"
+    assert bool((guard[M:] == 7.0).all()), "row statistics written beyond row M"
+    # fp16 spacing at |y| ~ 1000 is 0.5: the shifted deviations are exact there, the tolerance stays the one of the centred case
+    _check_rowstats(st, y, eps, f"rowstats {variant} offset {offset}")
+    ref = ops.row_stats(y, eps)
+    assert float((st[:, 0] - ref[:, 0]).abs().max()) <= 2e-6 * (float(y.float().abs().max()) + 1.0)
+    assert float(((st[:, 1] - ref[:, 1]).abs() / ref[:, 1]).max()) <= 6e-5
+    for _ in range(3):
+        st2 = torch.empty(M, 2, device=DEV)
+        ops.linear(x, w, b, residual=res, rowstats=st2, rowstats_eps=eps)
+        assert torch.equal(st2, st), "row statistics differ from run to run"
+    half_rows = max(M // 2 - 7, 8192)
+    if half_rows < M:
+        st3 = torch.empty(half_rows, 2, device=DEV)
+        ops.linear(x[:half_rows], w, b, residual=None if res is None else res[:half_rows], rowstats=st3, rowstats_eps=eps)
+        assert torch.equal(st3, st[:half_rows]), "a row's statistics depend on how many rows the call has"
+
+
+@pytest.mark.parametrize("units,unit_rows", [(50, 9216), (2, 230400), (3, 4096), (300, 1024)])
+def test_gemm_units_rowstats(units, unit_rows):
+    """... and from vcx_gemm_units_f16 (proj_in with the GroupNorm folded in: one weight set per frame / video, attention.py:265-269,299)."""
+    from viewcrafter_amd import ops
+    C = N = 320
+    M = units * unit_rows
+    x = rnd(M, C, seed=821).to(DEV).half()
+    wn = (rnd(units, N, C, seed=822) / math.sqrt(C)).to(DEV).half()
+    bn = (rnd(units, N, seed=823) + torch.arange(units).view(-1, 1) * 3.0).to(DEV)
+    assert ops.rowstats_ok(M, N, C, unit_rows=unit_rows)
+    guard = torch.full((M + 64, 2), 7.0, device=DEV)
+    y = ops.gemm_units(x, wn, bn, unit_rows=unit_rows, rowstats=guard[:M], rowstats_eps=1e-5)
+    assert torch.equal(y, ops.gemm_units(x, wn, bn, unit_rows=unit_rows))
+    assert bool((guard[M:] == 7.0).all())
+    _check_rowstats(guard[:M], y, 1e-5, "gemm_units rowstats")
+
+
+def test_gemm_rowstats_feed_the_folded_projection_behind_it():
+    """The consumer's view: LayerNorm -> Linear as a folded projection with the producer's statistics against the same projection
+    with vcx_rowstats_f16's, and against fp64 LayerNorm -> Linear of the stored rows."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import fold_layernorm
+    M, C, N2 = 9216 * 2, 320, 960
+    x = rnd(M, C, seed=831).to(DEV).half()
+    w = (rnd(C, C, seed=832) / math.sqrt(C)).to(DEV).half()
+    b = (rnd(C, seed=833) * 0.3).to(DEV)
+    res = (rnd(M, C, seed=834) * 2 + 0.5).to(DEV).half()
+    st = ops.rowstats_buffer(M, DEV)
+    t = ops.linear(x, w, b, residual=res, rowstats=st, rowstats_eps=1e-5)
+    gamma, beta = (1 + 0.3 * rnd(C, seed=835)).to(DEV), (0.2 * rnd(C, seed=836)).to(DEV)
+    w2 = (rnd(N2, C, seed=837) / math.sqrt(C)).to(DEV)
+    wf, colsum, bias_f = fold_layernorm(w2, gamma, beta, None)
+    q_epi = ops.linear(t, wf, bias_f, ln_stats=st, ln_colsum=colsum)
+    q_pass = ops.linear(t, wf, bias_f, ln_stats=ops.row_stats(t, 1e-5), ln_colsum=colsum)
+    assert rel_l2(q_epi, q_pass.float()) <= 2e-4
+    check_rows(q_epi, lambda r0, r1: _ln_linear_ref(t[r0:r1], gamma, beta, w2, None), tol=1e-3, name="folded projection on producer statistics")
+
+
+def test_gemm_rowstats_rejects_what_the_kernel_cannot_do():
+    from viewcrafter_amd import ops
+    from viewcrafter_amd._lib import VcxError
+    x = rnd(9000, 320, seed=841).to(DEV).half()
+    w = rnd(640, 320, seed=842).to(DEV).half()
+    with pytest.raises(VcxError, match="ROWSTATS"):           # N = 640: a block owns half rows
+        ops.linear(x, w, rowstats=torch.empty(9000, 2, device=DEV))
+    with pytest.raises(VcxError, match="ROWSTATS"):           # M < 8192: the tiled engine
+        ops.linear(x[:4096], w[:320], rowstats=torch.empty(4096, 2, device=DEV))
+    assert not ops.rowstats_ok(9000, 640, 320) and not ops.rowstats_ok(4096, 320, 320) and ops.rowstats_ok(9000, 320, 320)
+
+
+@pytest.mark.parametrize("n,strips,C", [(3, 1, 320), (50, 144, 320), (7, 36, 640), (5, 9, 1280), (2, 900, 640), (2, 225, 1280), (2, 1024, 64), (3, 37, 960),
+                                        (2, 17, 2560), (2, 100, 1920), (2, 3600, 320)])
+def test_groupnorm_statistics_from_column_moments_in_one_launch(n, strips, C):
+    """vcx_groupnorm_stats_from_colstats_f32, round 6: one kernel per norm up to 1024 strips (thread = (column, strip lane), whole groups
+    per block), the two-kernel form beyond.  Exact fp64 moments of a random tensor in, (mean, variance) per (n, group) out, against
+    fp64 statistics of the tensor; common offsets per column; bit-reproducible and independent of the batch size."""
+    from viewcrafter_amd import ops
+    pixels = strips * 64
+    x = (rnd(n, pixels, C, seed=851) * (1 + rnd(1, 1, C, seed=852).abs()) + 3 * rnd(1, 1, C, seed=853)).to(DEV).double()
+    v = x.view(n * strips, 64, C)
+    mean = v.mean(1)
+    cs = torch.stack([mean, ((v - mean.unsqueeze(1)) ** 2).sum(1)], dim=-1).float().contiguous()
+    stats = ops.group_norm_stats_from_colstats(cs, n, pixels, C)
+    xd = x.view(n, pixels, 32, C // 32)
+    mu, var = xd.mean(dim=(1, 3)), xd.var(dim=(1, 3), unbiased=False)
+    assert float((stats[..., 0].double() - mu).abs().max()) <= 2e-6 * float(mu.abs().max() + 1)
+    assert rel_l2(stats[..., 1], var) <= 2e-6
+    assert all(torch.equal(ops.group_norm_stats_from_colstats(cs, n, pixels, C), stats) for _ in range(3))
+    one = ops.group_norm_stats_from_colstats(cs[(n - 1) * strips:].contiguous(), 1, pixels, C)
+    assert torch.equal(one[0], stats[n - 1]), "the statistics of a sample depend on the batch it is in"
+
+
+@pytest.mark.parametrize("n,pix,C", [(50, 144, 1280), (2, 3600, 1280), (50, 144, 2560), (3, 40, 320), (2, 512, 960), (2, 513, 960), (4, 8, 64), (2, 4096, 640), (2, 4097, 320)])
+def test_groupnorm_statistics_pass_small_images(n, pix, C):
+    """vcx_groupnorm_stats_f16, round 6: up to 512 pixels one block per (n, slice of whole groups) writes the statistics directly (one
+    launch); up to 4096 pixels 16-pixel chunks (the 9 x 16-pixel level of the UNet: 18 MB tensors were 58 - 100 blocks).  Against fp64,
+    with a common offset, bit-reproducible, batch-independent."""
+    from viewcrafter_amd import ops
+    x = (rnd(n, pix, C, seed=861) * 2 + 40.0 + rnd(1, 1, C, seed=862)).to(DEV).half()
+    st = ops.group_norm_stats(x)
+    xd = x.double().view(n, pix, 32, C // 32)
+    mu, var = xd.mean(dim=(1, 3)), xd.var(dim=(1, 3), unbiased=False)
+    assert float((st[..., 0].double() - mu).abs().max()) <= 2e-6 * float(mu.abs().max() + 1)
+    assert rel_l2(st[..., 1], var) <= 2e-5
+    assert all(torch.equal(ops.group_norm_stats(x), st) for _ in range(3))
+    assert torch.equal(ops.group_norm_stats(x[n - 1:])[0], st[n - 1])
+
+
 @pytest.mark.parametrize("M,N,K,alpha,offset", [(1000, 320, 320, 1.0, 0.0), (700, 960, 320, 0.37, 0.0), (40000, 960, 320, 1.0, 0.0),
                                                 (5000, 1280, 640, 1.0, 0.0), (3000, 640, 640, 1.0, 900.0), (513, 72, 128, 1.0, 0.0)])
 def test_gemm_lnfold_matches_layernorm_then_linear(M, N, K, alpha, offset):

@@ -21,12 +21,12 @@ SYMBOLS = [
     "vcx_profile_begin", "vcx_profile_end", "vcx_tune_set", "vcx_tune_get",
 ]
 
-ABI_VERSION = 7          # include/vcx.h VCX_ABI_VERSION
+ABI_VERSION = 8          # include/vcx.h VCX_ABI_VERSION
 # experiment knobs (include/vcx.h VCX_TUNE_*): name -> (index, default)
 TUNE = {"GEMM_CFG": (0, -1), "GEMM_DMA": (1, 1), "FLASH_QB": (2, 0), "XATTN_RESIDENT": (3, 1), "FLASH_IMPL": (4, 0), "EXP0": (5, 0),
         "EXP1": (6, 0), "GEMM_WS": (7, 1)}
 GEMM_BIAS_N, GEMM_BIAS_M, GEMM_ROWADD, GEMM_RESIDUAL, GEMM_GEGLU, GEMM_OUT_F32, GEMM_CONV_SLABK = 1, 2, 4, 8, 16, 32, 64
-GEMM_LNFOLD, GEMM_LNFOLD_T, GEMM_COLSTATS = 0x80, 0x100, 0x200
+GEMM_LNFOLD, GEMM_LNFOLD_T, GEMM_COLSTATS, GEMM_ROWSTATS = 0x80, 0x100, 0x200, 0x400
 PROF_FAMILIES = ("gemm", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "elementwise")
 
 
@@ -40,6 +40,7 @@ class GemmDesc(ctypes.Structure):
         ("kh", c_int32), ("kw", c_int32), ("stride", c_int32), ("pad_h", c_int32), ("pad_w", c_int32),
         ("ups", c_int32), ("rowadd_div", c_int32), ("flags", c_int32), ("alpha", c_float),
         ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("colstats", c_void_p), ("ldcs", c_int64),
+        ("rowstats", c_void_p), ("rowstats_eps", c_float), ("reserved0", c_int32),
     ]
 
     def __init__(self, *args, **kw):

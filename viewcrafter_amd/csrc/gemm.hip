@@ -481,6 +481,9 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.colstats = d->colstats;
     a.ldcs = d->ldcs > 0 ? d->ldcs : d->N;
     a.unit_rows = 0; a.units = 1; a.w_unit_stride = 0; a.bias_unit_stride = 0;
+    a.rowstats = d->rowstats; a.rowstats_eps = d->rowstats_eps;
+    if (flags & VCX_GEMM_ROWSTATS)
+        VCX_REQUIRE(d->rowstats && ((uintptr_t)d->rowstats & 7) == 0 && d->rowstats_eps >= 0.f, "vcx_gemm_f16: ROWSTATS needs an 8-byte aligned rowstats buffer and eps >= 0");
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * (double)d->N * d->K;
     const double bytes = 2.0 * ((double)d->M * d->K / (conv ? d->kh * d->kw : 1) + (double)d->N * d->K + (double)d->M * d->N);
@@ -530,9 +533,13 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
             !(flags & ~(VCX_GEMM_LNFOLD | VCX_GEMM_BIAS_N)) && 8ull * (unsigned long long)d->M < lim && force_cfg_unset())
             return launch_ws320_lnfold(a, s);
     }
-    if (dma_ok && !conv && !geglu && !f32 && !lnf && d->K == 320 && d->N % 320 == 0 && d->N <= 1280 && d->M >= 8192 &&
+    // ROWSTATS (LayerNorm statistics of the output rows) exists where one block owns whole rows: the pipelined weight-stationary kernel, N = 320
+    const bool rs_ok = !(flags & VCX_GEMM_ROWSTATS) || (d->N == 320 && !(flags & ~(VCX_GEMM_ROWSTATS | VCX_GEMM_BIAS_N | VCX_GEMM_RESIDUAL)) && 8ull * (unsigned long long)d->M < lim);
+    if (dma_ok && !conv && !geglu && !f32 && !lnf && d->K == 320 && d->N % 320 == 0 && d->N <= 1280 && d->M >= 8192 && rs_ok &&
         !(flags & VCX_GEMM_BIAS_M) && vcx_tune(VCX_TUNE_GEMM_WS) != 0 && force_cfg_unset())
         return launch_ws320(a, s);
+    VCX_REQUIRE(!(flags & VCX_GEMM_ROWSTATS), "vcx_gemm_f16: ROWSTATS needs the weight-stationary kernel (linear, N = K = 320, M >= 8192, BIAS_N / RESIDUAL at most, knob GEMM_WS on); M=%d N=%d K=%d flags=0x%x",
+                d->M, d->N, d->K, flags);
     if (dma_ok) {
         // tile choice: the large (256-row, 8-wave) tiles halve the LDS traffic per MFMA but need >= ~1.5 waves of 256 tiles
         const int force = vcx_tune(VCX_TUNE_GEMM_CFG);      // -1 in production; tools/gemm_quick.py A/Bs tile configurations
@@ -584,7 +591,8 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
 extern "C" int vcx_gemm_units_f16(const vcx_gemm_desc* d, int unit_rows, int64_t w_unit_stride, int64_t bias_unit_stride, void* stream) {
     VCX_REQUIRE(d != nullptr && d->struct_size == sizeof(vcx_gemm_desc), "vcx_gemm_units_f16: null descriptor or wrong struct_size");
     VCX_REQUIRE(d->A && d->W && d->C && d->M > 0 && d->N > 0 && d->K > 0, "vcx_gemm_units_f16: null A/W/C or empty problem");
-    VCX_REQUIRE(d->mode == 0 && !(d->flags & ~VCX_GEMM_BIAS_N), "vcx_gemm_units_f16: linear layers with a per-column bias at most (mode %d flags 0x%x)", d->mode, d->flags);
+    VCX_REQUIRE(d->mode == 0 && !(d->flags & ~(VCX_GEMM_BIAS_N | VCX_GEMM_ROWSTATS)), "vcx_gemm_units_f16: linear layers with a per-column bias (and ROWSTATS) at most (mode %d flags 0x%x)", d->mode, d->flags);
+    VCX_REQUIRE(!(d->flags & VCX_GEMM_ROWSTATS) || (d->rowstats && ((uintptr_t)d->rowstats & 7) == 0 && d->rowstats_eps >= 0.f), "vcx_gemm_units_f16: ROWSTATS needs an 8-byte aligned rowstats buffer and eps >= 0");
     VCX_REQUIRE(unit_rows > 0 && d->M % unit_rows == 0, "vcx_gemm_units_f16: M (%d) must be a whole number of units of %d rows", d->M, unit_rows);
     VCX_REQUIRE(w_unit_stride % 8 == 0 && bias_unit_stride % 4 == 0, "vcx_gemm_units_f16: unit strides must keep W 16-byte and bias 16-byte aligned");
     VCX_REQUIRE(!(d->flags & VCX_GEMM_BIAS_N) || d->bias, "vcx_gemm_units_f16: bias flag without bias");
@@ -604,9 +612,12 @@ extern "C" int vcx_gemm_units_f16(const vcx_gemm_desc* d, int unit_rows, int64_t
         a.ldcs = d->N;
         a.a_bytes = (unsigned)a_ext; a.c_bytes = (unsigned)c_ext; a.w_bytes = 0; a.r_bytes = 0;
         a.unit_rows = unit_rows; a.units = units; a.w_unit_stride = w_unit_stride; a.bias_unit_stride = bias_unit_stride;
+        a.rowstats = d->rowstats; a.rowstats_eps = d->rowstats_eps;
         VcxProfScope prof(VCX_FAM_GEMM, s, 2.0 * d->M * (double)d->N * d->K, 2.0 * ((double)d->M * d->K + (double)units * d->N * d->K + (double)d->M * d->N));
         return launch_ws320_units(a, s);
     }
+    VCX_REQUIRE(!(d->flags & VCX_GEMM_ROWSTATS), "vcx_gemm_units_f16: ROWSTATS needs the one-launch weight-stationary form (N = K = 320, unit_rows %% 32 == 0, >= 1024, M >= 8192); M=%d N=%d K=%d unit_rows=%d",
+                d->M, d->N, d->K, unit_rows);
     for (int u = 0; u < units; ++u) {
         vcx_gemm_desc du = *d;
         du.A = (const half_t*)d->A + (int64_t)u * unit_rows * d->lda;

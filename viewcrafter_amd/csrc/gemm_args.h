@@ -33,6 +33,8 @@ struct GemmArgs {
     // vcx_gemm_units_f16 (weight-stationary kernel only): one weight / bias set per unit_rows consecutive rows; 0 = one set for all
     int unit_rows, units;
     int64_t w_unit_stride, bias_unit_stride;      // elements between consecutive units' weights / biases
+    float* rowstats;          // VCX_GEMM_ROWSTATS (gemm_ws320_pipe_kernel only): (mean, rstd) of every output row
+    float rowstats_eps;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {

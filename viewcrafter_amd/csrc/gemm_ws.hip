@@ -208,6 +208,10 @@ constexpr int WP_STAGE = WpCfg::TBM * WS_K * (int)sizeof(half_t);          // 20
 [[maybe_unused]] constexpr int WP_RING = 5, WP_AHEAD = 3;
 [[maybe_unused]] constexpr int WP_PIECES = WP_STAGE / 1024 / 4;            // LDS-DMA instructions per wave and tile (5)
 constexpr size_t WP_SMEM = (size_t)WP_RING * WP_STAGE;
+// VCX_GEMM_ROWSTATS: two slots of [32 rows][4 waves] (mean, M2) partials behind the ring (the SAME __shared__ object: a second one makes
+// hipcc drain the LDS-DMA queue in front of every fragment read)
+constexpr size_t WP_RS_SLOT = (size_t)WpCfg::TBM * 4 * 2 * sizeof(float);
+constexpr size_t WP_SMEM_RS = WP_SMEM + 2 * WP_RS_SLOT;
 
 __device__ __forceinline__ void ws_wait_vmcnt(int n) {        // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the count is an immediate)
     switch (n < 63 ? n : 63) {
@@ -221,7 +225,15 @@ __device__ __forceinline__ void ws_wait_vmcnt(int n) {        // s_waitcnt vmcnt
 
 template <int I> using WInt = std::integral_constant<int, I>;
 
-template <bool RES>
+// RS (VCX_GEMM_ROWSTATS, round 6): the block owns whole output rows, so it also writes LayerNorm's (mean, rstd) of every ROUNDED output
+// row - the statistics pass in front of the LayerNorm-folded projection behind this layer (vcx_rowstats_f16: one read of the tensor,
+// 20 launches / 1.2 ms per DDIM step at level 0) disappears.  On the matrix pipe, which is two thirds idle here: a unit's eight packed
+// fp16 outputs per lane ARE a 16x16x32 B operand (row = lane & 15, 32 of the wave's columns over the four lane groups), so
+// ones x X is the row sum (exact products) and the diagonal of D^T D the row's sum of squares - two MFMAs per unit, no VALU reduction,
+// no shuffles.  D = X minus a per-(row, wave) shift K: 0, or - where the strip's first three values say the row is offset - their
+// median (value - K is then exact in fp16, and |mean| >> std does not cancel); per wave (mean, M2) of its 80 columns -> LDS -> one
+// wave merges the four strips of the 32 rows of the tile before last (Chan, fixed order) and stores (mean, rstd).
+template <bool RES, bool RS>
 __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(GemmArgs p, unsigned a_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MF = WpCfg::MF, NF = WpCfg::NF, UNITS = NF / 2 + NF % 2, NUNIT = UNITS * MF;
@@ -229,6 +241,7 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t srd_s = __builtin_amdgcn_make_buffer_rsrc(p.rowstats, 0, RS ? (int)(8u * (unsigned)p.M) : 0, 0x00020000);
 
     int ntiles = p.tiles_m;
     const int cb = (blockIdx.x >> 3) % p.tiles_n;
@@ -290,6 +303,13 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
     const unsigned odd = lg & 1, half = lg >> 1;
     const unsigned cstep = 32u * (unsigned)p.ldc;
     const float alpha = p.alpha;
+    // ---- ROWSTATS state: one pending tile at a time (its units all run inside the next tile's MFMA stream)
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    [[maybe_unused]] f4 rsS[MF], rsQ[MF];          // ones x D (every element = the row sum) / D^T D (diagonal = the row's sum of squares), per 16-row group
+    [[maybe_unused]] h2v rsK[MF];                  // the shift of (row = lr of group b, this wave's strip), in both halves
+    [[maybe_unused]] int rs_row[2] = {0, 0};       // first row of the tile in each accumulator set
+    [[maybe_unused]] float* const rs_lds = reinterpret_cast<float*>(smem_raw + WP_SMEM);
+    [[maybe_unused]] const h8 rs_ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
 
     // unit J = b UNITS + u of the tile held in accumulator set PAR: the arithmetic, access units and store order of the plain path of
     // gemm_epilogue (and of gemm_ws320_kernel's lean epilogue) - the same bits
@@ -319,8 +339,38 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
 #pragma unroll
         for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v0[r]), "+v"(v1[r]));      // fp32 first, then ONE fp16 rounding (no v_fma_mixlo_f16)
         const u2v p0 = __builtin_bit_cast(u2v, h4{(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]});
+        [[maybe_unused]] u2v p1s = {0u, 0u};
+        if constexpr (wide) p1s = __builtin_bit_cast(u2v, h4{(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]});
+        if constexpr (RS) {
+            if constexpr (u == 0) {
+                // The shift of (row lr, this wave's strip), from the strip's first three values (lane lg = 0, fragment 0, columns 0 .. 2): their
+                // median where the row is OFFSET (|median| > 8 x their spread: then value - shift is exact in fp16, and sums of squares of
+                // the raw values would cancel), else 0 (the deviations are the values themselves: exact, and nothing to cancel).
+                const h4 f = __builtin_bit_cast(h4, p0);
+                const float fa = (float)f[0], fb = (float)f[1], fc = (float)f[2];
+                const float med = __builtin_amdgcn_fmed3f(fa, fb, fc);
+                const float spread = __builtin_fmaxf(__builtin_fmaxf(fa, fb), fc) - __builtin_fminf(__builtin_fminf(fa, fb), fc);
+                const half_t k3 = (half_t)(__builtin_fabsf(med) > 8.0f * spread ? med : 0.0f);      // (exact: one of the three, or 0)
+                const unsigned kk = (unsigned)__builtin_bit_cast(unsigned short, k3) * 0x10001u;
+                rsK[b] = __builtin_bit_cast(h2v, (unsigned)__shfl((int)kk, lr));
+            }
+            const h2v k2 = rsK[b];
+            const h2v x0 = __builtin_bit_cast(h2v, p0[0]), x1 = __builtin_bit_cast(h2v, p0[1]), x2 = __builtin_bit_cast(h2v, p1s[0]), x3 = __builtin_bit_cast(h2v, p1s[1]);
+            const h2v d0 = x0 - k2, d1 = x1 - k2;
+            h2v d2 = {(half_t)0.f, (half_t)0.f}, d3 = d2;
+            if constexpr (wide) { d2 = x2 - k2; d3 = x3 - k2; }
+            const h8 xv = {x0[0], x0[1], x1[0], x1[1], x2[0], x2[1], x3[0], x3[1]};      // the stored values: their sum is exact (fp16 x 1.0 into fp32)
+            const h8 dv = {d0[0], d0[1], d1[0], d1[1], d2[0], d2[1], d3[0], d3[1]};      // their deviations from the shift: the squares must not cancel
+            if constexpr (u == 0) {
+                rsS[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rs_ones, xv, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                rsQ[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dv, dv, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            } else {
+                rsS[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rs_ones, xv, rsS[b], 0, 0, 0);
+                rsQ[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dv, dv, rsQ[b], 0, 0, 0);
+            }
+        }
         if constexpr (wide) {
-            const u2v p1 = __builtin_bit_cast(u2v, h4{(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]});
+            const u2v p1 = p1s;
             const unsigned a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1];
             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
             const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
@@ -333,6 +383,67 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
         issued += 1;
     };
 
+    // ROWSTATS, second step: group b of the pending tile (held in set PAR) is complete - (mean, M2) of this wave's 80 columns of row
+    // b 16 + lr go to slot PAR; the diagonal element of row lr is element lr & 3 of the lane with lg = lr >> 2
+    [[maybe_unused]] auto rs_part = [&](auto PAR_, auto B_) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value, b = decltype(B_)::value;
+        const float S = rsS[b][0];
+        const int r = lr & 3;
+        float Q = rsQ[b][0];
+        Q = r == 1 ? rsQ[b][1] : Q;
+        Q = r == 2 ? rsQ[b][2] : Q;
+        Q = r == 3 ? rsQ[b][3] : Q;
+        constexpr float n1 = (float)(NF * 16), inv = 1.0f / n1;
+        const float mean = S * inv;                                        // of the stored values, unshifted
+        const float Sd = __builtin_fmaf(-n1, (float)rsK[b][0], S);         // sum of the deviations from the shift
+        const float m2 = __builtin_fmaf(-Sd * inv, Sd, Q);
+        if (lg == (lr >> 2))
+            *reinterpret_cast<float2*>(rs_lds + PAR * (WP_RS_SLOT / sizeof(float)) + ((b * 16 + lr) * 4 + wave) * 2) = make_float2(mean, m2 > 0.f ? m2 : 0.f);
+    };
+    // ROWSTATS, last step: one wave merges the four strips of the 32 rows in `slot` (equal counts: ((0, 1), (2, 3)), a fixed order) and
+    // stores (mean, rstd) of rows row0 .. row0 + 31 (rows >= M are dropped by the descriptor's range check)
+    [[maybe_unused]] auto rs_fin = [&](int slot, int row0) __attribute__((always_inline)) {
+        if (lane < WpCfg::TBM) {
+            const f4* src = reinterpret_cast<const f4*>(rs_lds + slot * (WP_RS_SLOT / sizeof(float)) + lane * 8);
+            const f4 x01 = src[0], x23 = src[1];           // (mean0, M2_0, mean1, M2_1), (mean2, M2_2, mean3, M2_3)
+            constexpr float n1 = (float)(NF * 16);
+            // (scalars behind empty asm statements: left to itself the SLP vectoriser pairs these into v_pk_add_f32 ... op_sel, the
+            // encoding tools/isa_audit.py bans - profiles/r04_pkfma_rootcause.md)
+            float m0 = x01[0], q0 = x01[1], m1 = x01[2], q1 = x01[3], m2 = x23[0], q2 = x23[1], m3 = x23[2], q3 = x23[3];
+            asm volatile("" : "+v"(m0), "+v"(q0), "+v"(m1), "+v"(q1), "+v"(m2), "+v"(q2), "+v"(m3), "+v"(q3));
+            // every statement takes an operand from the asm statement behind the previous one: no two of them can be paired
+            float d01 = m1 - m0;
+            asm volatile("" : "+v"(d01), "+v"(m3));
+            float d23 = m3 - m2;
+            asm volatile("" : "+v"(d23), "+v"(m0));
+            float ma = __builtin_fmaf(0.5f, d01, m0);
+            asm volatile("" : "+v"(ma), "+v"(m2));
+            float mb = __builtin_fmaf(0.5f, d23, m2);
+            asm volatile("" : "+v"(mb), "+v"(q0));
+            float qa = q0 + q1;
+            asm volatile("" : "+v"(qa), "+v"(q2));
+            float qb = q2 + q3;
+            asm volatile("" : "+v"(qb), "+v"(d01));
+            float e01 = d01 * d01;
+            asm volatile("" : "+v"(e01), "+v"(d23));
+            float e23 = d23 * d23;
+            asm volatile("" : "+v"(e23), "+v"(qa));
+            qa = __builtin_fmaf(e01, 0.5f * n1, qa);
+            asm volatile("" : "+v"(qa), "+v"(qb));
+            qb = __builtin_fmaf(e23, 0.5f * n1, qb);
+            asm volatile("" : "+v"(qb), "+v"(mb));
+            float dd = mb - ma;
+            asm volatile("" : "+v"(dd), "+v"(qa));
+            const float mean = __builtin_fmaf(0.5f, dd, ma);
+            float qs = qa + qb;
+            asm volatile("" : "+v"(qs), "+v"(dd));
+            const float q = __builtin_fmaf(dd * dd, n1, qs);
+            const float rstd = rsqrtf(q * (1.0f / (4.0f * n1)) + p.rowstats_eps);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, make_float2(mean, rstd)), srd_s, (unsigned)(row0 + lane) * 8u, 0, 0);
+        }
+        issued += 1;
+    };
+
     // one tile: its MFMAs into accumulator set PAR; PEND: the other set holds a finished tile - its units ride along
     auto tile = [&](auto PAR_, auto PEND_, int t, int i) __attribute__((always_inline)) {
         constexpr int PAR = decltype(PAR_)::value;
@@ -340,8 +451,11 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
         const int buf = i % WP_RING;
         __builtin_amdgcn_sched_barrier(0);
         ws_wait_vmcnt(issued - mark[buf]);           // everything up to this tile's last DMA piece has retired
+        if constexpr (RS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and this wave's row-moment partials are in LDS
         __builtin_amdgcn_s_barrier();                // ... for every wave; and every wave is done with the tiles before
         __builtin_amdgcn_sched_barrier(0);
+        [[maybe_unused]] const int fin_row = rs_row[PAR];       // the tile before last used this set: its partials (slot PAR) are complete behind this barrier
+        if constexpr (RS) rs_row[PAR] = p.m_begin + t * WpCfg::TBM;
         if (t + WP_AHEAD * G < ntiles) issue_tile(t + WP_AHEAD * G, (i + WP_AHEAD) % WP_RING);      // into the stage of tile i - 2: long consumed
         if constexpr (RES) {
             gemm_epilogue_fetch_residual<WpCfg>(p, t, cb, 0, wave, lane, rr[PAR]);
@@ -374,7 +488,32 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
             // six units over ten K slices: slices 1, 2, 4, 5, 7, 8 (the first leaves the residual request of the PREVIOUS tile one more
             // slice; the last keeps the stores clear of the barrier)
             if constexpr (PEND && kk % 3 != 0 && kk < 9) unit(WInt<PAR ^ 1>{}, WInt<(kk / 3) * 2 + (kk % 3) - 1>{});
+            // ROWSTATS: the moments of a 16-row group two K slices behind its last unit (no wait states); the tile before last is merged
+            // and stored by one wave (which one rotates with the tile) behind the matrix work
+            if constexpr (RS && PEND && kk == 6) rs_part(WInt<PAR ^ 1>{}, WInt<0>{});
+            if constexpr (RS && PEND && kk == 9) rs_part(WInt<PAR ^ 1>{}, WInt<1>{});
         });
+        if constexpr (RS) {
+            if (i >= 2 && wave == (i & 3)) rs_fin(PAR, fin_row);
+        }
+    };
+
+    // the last tile (set PAR, the i-th of this block): its units, its moments, and - behind one more barrier - the merges of the last two tiles
+    auto finish = [&](auto PAR_, int i) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value;
+        if constexpr (RS) {       // (the wave that merges the tile before last may still be reading slot PAR: nobody overwrites it before this barrier)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        static_for_ws<NUNIT>([&](auto J_) __attribute__((always_inline)) { unit(PAR_, J_); });
+        if constexpr (RS) {
+            rs_part(PAR_, WInt<0>{});
+            rs_part(PAR_, WInt<1>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (i >= 2 && wave == 0) rs_fin(PAR ^ 1, rs_row[PAR ^ 1]);
+            if (wave == 1) rs_fin(PAR, rs_row[PAR]);
+        }
     };
 
     int t = t_first, i = 0;
@@ -386,13 +525,13 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
         t += G; ++i;
         for (;;) {
             if (t >= ntiles) {
-                static_for_ws<NUNIT>([&](auto J_) __attribute__((always_inline)) { unit(WInt<0>{}, J_); });
+                finish(WInt<0>{}, i);
                 break;
             }
             tile(WInt<1>{}, WInt<1>{}, t, i);
             t += G; ++i;
             if (t >= ntiles) {
-                static_for_ws<NUNIT>([&](auto J_) __attribute__((always_inline)) { unit(WInt<1>{}, J_); });
+                finish(WInt<1>{}, i);
                 break;
             }
             tile(WInt<0>{}, WInt<1>{}, t, i);
@@ -1163,16 +1302,17 @@ int launch_ws_geglu(const GemmArgs& a, hipStream_t s) {
     return vcx_check_launch("vcx_gemm_f16(ws320 geglu)");
 }
 
-template <bool RES>
+template <bool RES, bool RS>
 int launch_ws_pipe(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
-    auto kern = gemm_ws320_pipe_kernel<RES>;
-    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WP_SMEM, "vcx_gemm_f16(ws320 pipe)")) return VCX_ELAUNCH;
+    auto kern = gemm_ws320_pipe_kernel<RES, RS>;
+    constexpr size_t smem = RS ? WP_SMEM_RS : WP_SMEM;
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)smem, "vcx_gemm_f16(ws320 pipe)")) return VCX_ELAUNCH;
     const int per_xcd = persistent_grid(1 << 30, 1) / 8;
     int streams_per_xcd = per_xcd / a.tiles_n;
     const int needed = (a.tiles_m + 7) / 8;
     if (streams_per_xcd > needed) streams_per_xcd = needed;
-    hipLaunchKernelGGL(kern, dim3(8 * streams_per_xcd * a.tiles_n), dim3(WpCfg::THREADS), WP_SMEM, s, a, a.a_bytes);
+    hipLaunchKernelGGL(kern, dim3(8 * streams_per_xcd * a.tiles_n), dim3(WpCfg::THREADS), smem, s, a, a.a_bytes);
     return vcx_check_launch("vcx_gemm_f16(ws320 pipe)");
 }
 
@@ -1198,16 +1338,18 @@ int launch_ws(const GemmArgs& a, hipStream_t s) {
 // 32-bit operand and output extents (the caller checks; it also fills a_bytes / c_bytes / r_bytes).  Sets the tiling itself.
 // One launch, `units` weight / bias sets (vcx_gemm_units_f16): N = K = 320, bias at most, unit_rows % 32 == 0 (the caller checks).
 int vcxgemm::launch_ws320_units(GemmArgs& a, hipStream_t s) {
-    static VcxLdsAttr lds;
-    auto kern = gemm_ws320_pipe_kernel<false>;
-    if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WP_SMEM, "vcx_gemm_units_f16(ws320 pipe)")) return VCX_ELAUNCH;
+    static VcxLdsAttr lds, lds_rs;
+    const bool rs = (a.flags & VCX_GEMM_ROWSTATS) != 0;
+    auto kern = rs ? gemm_ws320_pipe_kernel<false, true> : gemm_ws320_pipe_kernel<false, false>;
+    const size_t smem = rs ? WP_SMEM_RS : WP_SMEM;
+    if (!(rs ? lds_rs : lds).ensure(reinterpret_cast<const void*>(kern), (int)smem, "vcx_gemm_units_f16(ws320 pipe)")) return VCX_ELAUNCH;
     a.tiles_n = 1;
     a.tiles_m = a.unit_rows / WpCfg::TBM;
     const int cus = persistent_grid(1 << 30, 1);
     int bpu = cus / a.units;                        // blocks per unit: the chip's CUs shared out, at least one, at most one per row tile
     if (bpu < 1) bpu = 1;
     if (bpu > a.tiles_m) bpu = a.tiles_m;
-    hipLaunchKernelGGL(kern, dim3(bpu * a.units), dim3(WpCfg::THREADS), WP_SMEM, s, a, a.a_bytes);
+    hipLaunchKernelGGL(kern, dim3(bpu * a.units), dim3(WpCfg::THREADS), smem, s, a, a.a_bytes);
     return vcx_check_launch("vcx_gemm_units_f16(ws320 pipe)");
 }
 
@@ -1231,5 +1373,6 @@ int vcxgemm::launch_ws320(GemmArgs& a, hipStream_t s) {
     if (a.flags & VCX_GEMM_COLSTATS) return launch_ws<3>(a, s);
     if (a.flags & VCX_GEMM_ROWADD) return launch_ws<2>(a, s);
     a.tiles_m = (a.M - a.m_begin + WpCfg::TBM - 1) / WpCfg::TBM;
-    return (a.flags & VCX_GEMM_RESIDUAL) ? launch_ws_pipe<true>(a, s) : launch_ws_pipe<false>(a, s);
+    if (a.flags & VCX_GEMM_ROWSTATS) return (a.flags & VCX_GEMM_RESIDUAL) ? launch_ws_pipe<true, true>(a, s) : launch_ws_pipe<false, true>(a, s);
+    return (a.flags & VCX_GEMM_RESIDUAL) ? launch_ws_pipe<true, false>(a, s) : launch_ws_pipe<false, false>(a, s);
 }

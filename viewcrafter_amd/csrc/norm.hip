@@ -21,8 +21,11 @@ __device__ __forceinline__ void gn_merge(float& na, float& ma, float& qa, float 
     na = n;
 }
 
-__global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ partials, int64_t pixels, int C, int groups,
-                                int64_t pix_per_block, int cw, int pl) {
+// Cs < C (gridDim.z = C / Cs slices of whole groups, Cs % 8 == 0): a block sums the channels [blockIdx.z Cs, + Cs) only.  `stats` != nullptr
+// (gridDim.x == 1: the block sees every pixel of its n): the block's moments ARE the statistics - (mean, biased variance) go straight
+// to stats[n][group] and no finalize launch follows (small pixel counts: the 9 x 16-pixel level of the UNet).
+__global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ partials, float* __restrict__ stats, int64_t pixels, int C,
+                                int groups, int Cs, int64_t pix_per_block, int cw, int pl) {
     // Numerically robust and deterministic (no atomics).  A thread sums x - K_t and (x - K_t)^2 with K_t = the first value it
     // loads (a sample of the data: |mean| >> std does not cancel - torch's GroupNorm is Welford too - and no load has to be
     // waited for before the streaming loop starts).  After the loop the sums are re-based algebraically to a shift that is
@@ -37,8 +40,9 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
     const int64_t p1 = (p0 + pix_per_block < pixels) ? p0 + pix_per_block : pixels;
     const int cpg = C / groups;
     const int c8 = tid % cw, plane = tid / cw;
-    const half_t* xp = x + ((int64_t)n * pixels) * C + c8 * 8;
-    float* kshare = red + (size_t)pl * C * 2;           // x[p0][c] for every channel c (written by pixel lane 0)
+    const half_t* xp = x + ((int64_t)n * pixels) * C + (int64_t)blockIdx.z * Cs + c8 * 8;
+    const int gslice = Cs / cpg;                         // groups per block
+    float* kshare = red + (size_t)pl * Cs * 2;          // x[p0][c] for every channel c of the slice (written by pixel lane 0)
     float s[8], ss[8], K[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; K[e] = 0.f; }
@@ -83,21 +87,21 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
         // re-base from K_t to the group's block shift K_b: sum(x - K_b) = S + n d, sum((x - K_b)^2) = Q + 2 d S + n d^2, d = K_t - K_b
         const float kb = kshare[((c8 * 8 + e) / cpg) * cpg];
         const float d = K[e] - kb;
-        red[((size_t)plane * C + c8 * 8 + e) * 2 + 0] = s[e] + cnt_t * d;
-        red[((size_t)plane * C + c8 * 8 + e) * 2 + 1] = ss[e] + d * (2.f * s[e] + cnt_t * d);
+        red[((size_t)plane * Cs + c8 * 8 + e) * 2 + 0] = s[e] + cnt_t * d;
+        red[((size_t)plane * Cs + c8 * 8 + e) * 2 + 1] = ss[e] + d * (2.f * s[e] + cnt_t * d);
     }
     __syncthreads();
-    for (int c = tid; c < C; c += blockDim.x) {          // pixel lanes, in order
+    for (int c = tid; c < Cs; c += blockDim.x) {         // pixel lanes, in order
         float a = red[(size_t)c * 2], q = red[(size_t)c * 2 + 1];
         for (int p = 1; p < pl; ++p) {
-            a += red[((size_t)p * C + c) * 2];
-            q += red[((size_t)p * C + c) * 2 + 1];
+            a += red[((size_t)p * Cs + c) * 2];
+            q += red[((size_t)p * Cs + c) * 2 + 1];
         }
         red[(size_t)c * 2] = a;
         red[(size_t)c * 2 + 1] = q;
     }
     __syncthreads();
-    if (tid < groups) {                                   // channels of the group, in order
+    if (tid < gslice) {                                   // channels of the group, in order
         float a = 0.f, q = 0.f;
         for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
             a += red[(size_t)c * 2];
@@ -106,10 +110,17 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
         const float cnt = (float)((p1 - p0) * cpg);
         const float m = a / cnt;
         const float m2 = q - a * m;
-        float* dst = partials + (((int64_t)n * gridDim.x + blockIdx.x) * groups + tid) * 3;
-        dst[0] = cnt;
-        dst[1] = kshare[tid * cpg] + m;
-        dst[2] = m2 > 0.f ? m2 : 0.f;
+        const int g = blockIdx.z * gslice + tid;
+        const float mean = kshare[tid * cpg] + m, m2c = m2 > 0.f ? m2 : 0.f;
+        if (stats) {
+            stats[((int64_t)n * groups + g) * 2 + 0] = mean;
+            stats[((int64_t)n * groups + g) * 2 + 1] = m2c / cnt;
+        } else {
+            float* dst = partials + (((int64_t)n * gridDim.x + blockIdx.x) * groups + g) * 3;
+            dst[0] = cnt;
+            dst[1] = mean;
+            dst[2] = m2c;
+        }
     }
 }
 
@@ -330,11 +341,90 @@ void gn_geometry(int C, int& cw, int& pl) {
 int64_t pick_pix_per_block(int n_outer, int64_t pixels) {
     // A function of `pixels` only: the summation order - hence the bits of the result - must not depend on how many
     // samples are batched (cond/uncond run as one B=2 forward and must equal two B=1 forwards exactly).
-    // <= 1024 partials per n, >= 128 pixels per block.
+    // <= 1024 partials per n; >= 128 pixels per block on large images, 16 up to 4096 pixels: the 18 MB tensors of the 9 x 16-pixel level
+    // (3600 pixels per video, n = 2) are 450 blocks instead of 58 - round 6: 24 -> ~8 us per pass.
     (void)n_outer;
+    if (pixels <= 4096) return 16;
     int64_t ppb = (pixels + 1023) / 1024;
     if (ppb < 128) ppb = 128;
     return ppb;
+}
+
+// Direct form of the statistics pass (gn_stats_kernel with `stats`): one block per (n, slice of whole groups) sees all pixels.  Taken
+// up to 512 pixels when C splits into slices of Cs = the smallest multiple of a group AND of eight channels, doubled up to 64.
+bool gn_direct_geometry(int64_t pixels, int C, int groups, int& Cs, int& cw, int& pl) {
+    if (pixels > 512) return false;
+    const int cpg = C / groups;
+    Cs = cpg;
+    while (Cs % 8 != 0) Cs += cpg;
+    if (Cs > C || C % Cs != 0) return false;
+    while (Cs < 64 && C % (2 * Cs) == 0) Cs *= 2;
+    cw = Cs >> 3;
+    pl = 512 / cw;
+    if (pl > pixels) pl = (int)pixels;
+    if (pl < 1) return false;
+    return sizeof(float) * (2 * (size_t)pl * Cs + Cs) <= 64 * 1024;
+}
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm statistics from column moments in ONE launch (round 6; two kernels before: 287 launches of 5-9 us per DDIM step).  A block
+// takes `gpb` whole groups (cols = gpb * C / groups consecutive columns) of one n and ALL strips: thread (column j, strip lane l) folds
+// the strips l, l + L, ... of its column in order (eight 8-byte loads in flight), the L lanes of a column are folded in order, then the
+// columns of each group in order -> stats[n][g] = (mean, biased variance).  No atomics, no second pass: bit-reproducible, and the
+// geometry is a function of (strips, C, groups) only - the same bits for any batch size.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) gn_colstats_direct_kernel(const float2* __restrict__ cs, float* __restrict__ stats, int strips, int C,
+                                                                  int groups, int gpb, int L) {
+    extern __shared__ float red[];                      // [L][cols][3]
+    const int cpg = C / groups, cols = gpb * cpg;
+    const int n = blockIdx.y, g0 = blockIdx.x * gpb;
+    const int tid = threadIdx.x, j = tid % cols, l = tid / cols;
+    const int c = g0 * cpg + j;
+    if (l < L) {
+        float na = 0.f, a = 0.f, q = 0.f;
+        if (c < C) {
+            const float2* src = cs + ((int64_t)n * strips) * C + c;
+            for (int sb = l; sb < strips; sb += 8 * L) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(sb + u * L < strips ? sb + u * L : l) * C];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gn_merge(na, a, q, sb + u * L < strips ? 64.f : 0.f, v[u].x, sb + u * L < strips ? v[u].y : 0.f);
+            }
+        }
+        float* r = red + ((size_t)l * cols + j) * 3;
+        r[0] = na; r[1] = a; r[2] = q;
+    }
+    __syncthreads();
+    if (tid < cols) {                                   // strip lanes of a column, in order
+        float na = red[tid * 3], a = red[tid * 3 + 1], q = red[tid * 3 + 2];
+        for (int k = 1; k < L; ++k) {
+            const float* r = red + ((size_t)k * cols + tid) * 3;
+            gn_merge(na, a, q, r[0], r[1], r[2]);
+        }
+        red[tid * 3] = na; red[tid * 3 + 1] = a; red[tid * 3 + 2] = q;
+    }
+    __syncthreads();
+    if (tid < gpb && g0 + tid < groups) {               // columns of a group, in order
+        const int c0 = tid * cpg;
+        float na = red[c0 * 3], a = red[c0 * 3 + 1], q = red[c0 * 3 + 2];
+        for (int k = c0 + 1; k < c0 + cpg; ++k) gn_merge(na, a, q, red[k * 3], red[k * 3 + 1], red[k * 3 + 2]);
+        stats[((int64_t)n * groups + g0 + tid) * 2 + 0] = a;
+        stats[((int64_t)n * groups + g0 + tid) * 2 + 1] = na > 0.f ? q / na : 0.f;
+    }
+}
+
+// geometry of the one-launch form: up to 1024 strips per n, groups of at most 256 columns
+bool gn_colstats_direct_geometry(int64_t strips, int C, int groups, int& gpb, int& L) {
+    const int cpg = C / groups;
+    if (strips > 1024 || cpg > 256) return false;
+    gpb = 80 / cpg;
+    if (gpb < 1) gpb = 1;
+    if (gpb > groups) gpb = groups;
+    const int cols = gpb * cpg;
+    L = 1024 / cols;
+    if (L > strips) L = (int)strips;
+    return L >= 1;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -418,6 +508,13 @@ extern "C" int vcx_groupnorm_stats_from_colstats_f32(const float* colstats, floa
     hipStream_t s = (hipStream_t)stream;
     VcxProfScope prof(VCX_FAM_GN, s, 0.0, 8.0 * n_outer * (double)(pixels / 64) * C);
     const int64_t strips = pixels / 64;
+    int gpb, L;
+    if (gn_colstats_direct_geometry(strips, C, groups, gpb, L)) {
+        const int cols = gpb * (C / groups);
+        hipLaunchKernelGGL(gn_colstats_direct_kernel, dim3((unsigned)((groups + gpb - 1) / gpb), (unsigned)n_outer), dim3(cols * L),
+                           sizeof(float) * 3 * (size_t)cols * L, s, reinterpret_cast<const float2*>(colstats), stats, (int)strips, C, groups, gpb, L);
+        return vcx_check_launch("vcx_groupnorm_stats_from_colstats_f32(direct)");
+    }
     // <= 1024 chunks per n (the workspace of vcx_groupnorm_ws_bytes), a function of `pixels` only: same bits for any batch size
     int64_t spb = (strips + 1023) / 1024;
     if (spb < 16) spb = 16;
@@ -447,13 +544,18 @@ extern "C" int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, in
     VCX_REQUIRE(n_outer <= 65535, "vcx_groupnorm_stats_f16: n_outer too large");
     hipStream_t s = (hipStream_t)stream;
     VcxProfScope prof(VCX_FAM_GN, s, 0.0, 2.0 * n_outer * (double)pixels * C);
+    int cw, pl, Cs;
+    if (gn_direct_geometry(pixels, C, groups, Cs, cw, pl)) {       // small images: the block's moments are the statistics, one launch
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(1, (unsigned)n_outer, (unsigned)(C / Cs)), dim3(cw * pl), sizeof(float) * (2 * (size_t)pl * Cs + Cs), s,
+                           (const half_t*)x, (float*)nullptr, stats, pixels, C, groups, Cs, pixels, cw, pl);
+        return vcx_check_launch("vcx_groupnorm_stats_f16(direct)");
+    }
     const int64_t ppb = pick_pix_per_block(n_outer, pixels);
     const int chunks = (int)((pixels + ppb - 1) / ppb);
     dim3 grid((unsigned)chunks, n_outer);
-    int cw, pl;
     gn_geometry(C, cw, pl);
     const size_t smem = sizeof(float) * (2 * (size_t)pl * C + C);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(cw * pl), smem, s, (const half_t*)x, (float*)ws, pixels, C, groups, ppb, cw, pl);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(cw * pl), smem, s, (const half_t*)x, (float*)ws, (float*)nullptr, pixels, C, groups, C, ppb, cw, pl);
     int rc = vcx_check_launch("vcx_groupnorm_stats_f16");
     if (rc) return rc;
     // the choice depends on the pixel count only (never on the batch): same bits for B = 1 and B = 2

@@ -55,7 +55,12 @@ def spatial_fold_ok(n, pixels, C, D):
     """Does vcx_gemm_units_f16 take n frames of `pixels` rows in ONE weight-stationary launch (csrc/gemm.hip)?"""
     return (GN_FOLD and GN_FOLD_SPATIAL and n > 1 and C == 320 and D == 320 and pixels % 32 == 0 and pixels >= 1024 and n * pixels >= 8192
             and 2 * n * pixels * C >= GN_FOLD_MIN_BYTES and 2 * (n * pixels + 256) * C < 0xFFFF0000 and ops.tune_get("GEMM_DMA") != 0
-            and ops.tune_get("GEMM_WS") != 0)
+            and ops.tune_get("GEMM_WS") != 0 and ops.tune_get("GEMM_CFG") < 0)      # (a forced tile configuration means the tiled engine: ADVICE r5)
+
+
+def _folded(pj, rows, K, lda, transposed=False):
+    """Will ln_linear / ln_linear_t run this pack as a folded projection (and so want row statistics)?"""
+    return pj["colsum"] is not None and ops.lnfold_ok(rows, pj["w"].shape[0], K, lda=lda, transposed=transposed)
 
 
 def _ln_projection(w, ln, alpha=1.0, bias=None):
@@ -383,9 +388,18 @@ class SpatialTransformer(PackedModule):
             if stats is None:
                 stats = ops.group_norm_stats(x.view(n, N_img, C))
             wn, bn = ops.group_norm_fold_linear(pk["win32"], pk["bin"], pk["gn_w"], pk["gn_b"], stats, self.norm.eps)
-            t = ops.gemm_units(xin, wn, bn, unit_rows=N_img)
+        # LayerNorm statistics of the token stream from the layer that writes it (VCX_GEMM_ROWSTATS, round 6): proj_in for norm1 of the
+        # first block, attn1's output projection for norm2 - where the producer is the weight-stationary kernel (C = 320) and the
+        # consumer a folded projection; row_stats (one read of the tensor) otherwise
+        blk0 = self.transformer_blocks[0]
+        rs_eps = blk0.norm1.eps
+        rs = None
+        if _folded(blk0.attn1.packed()["qk"], tokens, D_in, D_in) and ops.rowstats_ok(tokens, D_in, C, lda=C, unit_rows=N_img if fold else None):
+            rs = ops.rowstats_buffer(tokens, x.device)
+        if fold:
+            t = ops.gemm_units(xin, wn, bn, unit_rows=N_img, rowstats=rs, rowstats_eps=rs_eps)
         else:
-            t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
+            t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"], rowstats=rs, rowstats_eps=rs_eps)
         D, heads = t.shape[1], self.n_heads
         for bi, (blk, kv) in enumerate(zip(self.transformer_blocks, context_kv)):
             ln = blk.ln_params()
@@ -396,15 +410,16 @@ class SpatialTransformer(PackedModule):
             pqk, pv, qk_alpha = a1["qk"], a1["v"], math.sqrt(blk.attn1.scale * ops.LOG2E)
             # norm1 folded into both projections (they read the token stream itself) wherever the pack is folded and the kernel
             # takes the shape; layer_norm + plain projections otherwise (ln_linear / ln_linear_t)
-            st = ops.row_stats(t, ln[0][2]) if pqk["colsum"] is not None else None
+            st = rs if (bi == 0 and rs is not None) else (ops.row_stats(t, ln[0][2]) if pqk["colsum"] is not None else None)
             qk = ln_linear(t, pqk, ln[0], alpha=qk_alpha, stats=st)                 # [tokens, 2D]
             vt = ln_linear_t(t, pv, ln[0], stats=st)                                # [D, tokens]
             o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
             ops.flash_attn(qk, qk[:, D:], vt, o, n_groups=n, heads=heads, nq=N, nk=N_img, kv_rows=N, kv_div=1, ldq=2 * D,
                            ldk=2 * D, ldvt=tokens, ldo=D, scale=blk.attn1.scale, log2_logits=True)
-            t = ops.linear(o, a1["wo"], a1["bo"], residual=t)
+            st2 = ops.rowstats_buffer(tokens, x.device) if (_folded(a2["q"], tokens, D, D) and ops.rowstats_ok(tokens, D, D, ldr=D)) else None
+            t = ops.linear(o, a1["wo"], a1["bo"], residual=t, rowstats=st2, rowstats_eps=ln[1][2])
             # ---- cross-attention: softmax(Q K_txt) V_txt + softmax(Q K_img) V_img
-            q2 = ln_linear(t, a2["q"], ln[1], alpha=blk.attn2.scale * ops.LOG2E)
+            q2 = ln_linear(t, a2["q"], ln[1], alpha=blk.attn2.scale * ops.LOG2E, stats=st2)
             if bi == 0 and cfg_repeat > 1:      # from here on the r conditionings differ
                 t, q2, xin = ops.repeat_rows(t, cfg_repeat), ops.repeat_rows(q2, cfg_repeat), ops.repeat_rows(xin, cfg_repeat)
                 n, tokens = n * cfg_repeat, tokens * cfg_repeat
@@ -486,19 +501,31 @@ class TemporalTransformer(PackedModule):
             if stats is None:
                 stats = ops.group_norm_stats(x.view(B, rows, C))
             wn, bn = ops.group_norm_fold_linear(pk["win32"], pk["bin"], pk["gn_w"], pk["gn_b"], stats, self.norm.eps)
-            t = ops.gemm_units(xin, wn, bn, unit_rows=rows)
+            fold = True
         else:
             a = ops.group_norm(x.view(B, rows, C), pk["gn_w"], pk["gn_b"], self.norm.eps, False, stats=stats)
-            t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"])
+            fold = False
+        # LayerNorm statistics from the producing layer (VCX_GEMM_ROWSTATS): proj_in for norm1, attn1's output projection for norm2
+        blk0 = self.transformer_blocks[0]
+        st = None
+        if _folded(blk0.attn1.packed()["qkv"], tokens, D, D) and ops.rowstats_ok(tokens, D, C, lda=C, unit_rows=rows if fold else None):
+            st = ops.rowstats_buffer(tokens, x.device)
+        if fold:
+            t = ops.gemm_units(xin, wn, bn, unit_rows=rows, rowstats=st, rowstats_eps=blk0.norm1.eps)
+        else:
+            t = ops.linear(a.view(tokens, C), pk["win"], pk["bin"], rowstats=st, rowstats_eps=blk0.norm1.eps)
         for blk in self.transformer_blocks:
             ln = blk.ln_params()
-            for attn, lnp in ((blk.attn1, ln[0]), (blk.attn2, ln[1])):
+            for ai, (attn, lnp) in enumerate(((blk.attn1, ln[0]), (blk.attn2, ln[1]))):
                 ap = attn.packed()
-                qkv = ln_linear(t, ap["qkv"], lnp)                                   # [tokens, 3D]
+                qkv = ln_linear(t, ap["qkv"], lnp, stats=st)                         # [tokens, 3D]
                 o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
                 ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D, ldo=D,
                                   scale=attn.scale)
-                t = ops.linear(o, ap["wo"], ap["bo"], residual=t)
+                st = None
+                if ai == 0 and _folded(blk.attn2.packed()["qkv"], tokens, D, D) and ops.rowstats_ok(tokens, D, D, ldr=D):
+                    st = ops.rowstats_buffer(tokens, x.device)
+                t = ops.linear(o, ap["wo"], ap["bo"], residual=t, rowstats=st, rowstats_eps=ln[1][2])
             t = blk.ff.run(t, ln[2])
         kw, cs_out = out_kwargs(target, want_colstats, tokens, P, D, C, x.device)
         out = ops.linear(t, pk["wout"], pk["bout"], residual=xin, **kw)

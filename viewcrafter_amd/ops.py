@@ -9,14 +9,18 @@ openaimodel3d.py:69-186, GroupNorm basics.py:76-81, LayerNorm attention.py:226-2
 attention.py:175,187, the DDIM update ddim.py:228-279, ...) is tabulated in INTEGRATION.md section 2 and include/vcx.h.
 """
 import ctypes
+import os
+
 import torch
 
-from ._lib import (GEMM_BIAS_M, GEMM_BIAS_N, GEMM_COLSTATS, GEMM_CONV_SLABK, GEMM_GEGLU, GEMM_LNFOLD, GEMM_LNFOLD_T, GEMM_OUT_F32, GEMM_RESIDUAL, GEMM_ROWADD, PROF_FAMILIES,
+from ._lib import (GEMM_BIAS_M, GEMM_BIAS_N, GEMM_COLSTATS, GEMM_CONV_SLABK, GEMM_GEGLU, GEMM_LNFOLD, GEMM_LNFOLD_T, GEMM_OUT_F32, GEMM_RESIDUAL, GEMM_ROWADD, GEMM_ROWSTATS, PROF_FAMILIES,
                    TUNE, GemmDesc, VcxError, check, lib)
 from .packing import conv_slab_major
 
 _f16 = torch.float16
 _f32 = torch.float32
+# LayerNorm statistics from the producing layer's epilogue (VCX_GEMM_ROWSTATS, round 6); 0 = a statistics pass everywhere (A/B runs)
+LN_ROWSTATS = os.environ.get("VCX_LN_ROWSTATS", "1") != "0"
 
 
 def _stream():
@@ -53,13 +57,14 @@ def require_gpu():
 # ------------------------------------------------------------------------------------------
 def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, residual=None, ldr=None, rowadd=None,
          rowadd_div=0, geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None, ln_stats=None, ln_colsum=None, ln_t=False, colstats=None,
-         colstats_ld=None, colstats_col=0):
+         colstats_ld=None, colstats_col=0, rowstats=None, rowstats_eps=1e-5):
     """out[M, N] = epilogue(alpha * X W^T); see include/vcx.h.  `conv` = dict(in_h, in_w, out_h, out_w, cin, kh, kw,
     stride, pad_h, pad_w, ups) switches X to the im2col gather of a channels-last image.  `ln_stats` (from row_stats) +
     `ln_colsum` select the folded-LayerNorm epilogue (VCX_GEMM_LNFOLD; `ln_t`: the normalised rows are the W operand).
     `colstats` (fp32 [M / 64, N, 2], see colstats_buffer) makes the layer write the column moments of its output for the
     GroupNorm behind it (VCX_GEMM_COLSTATS); with `colstats_ld` / `colstats_col` the buffer is [M / 64, colstats_ld, 2] and this
-    call fills the columns [colstats_col, colstats_col + N) - the moments of a tensor that is one part of a channel concat."""
+    call fills the columns [colstats_col, colstats_col + N) - the moments of a tensor that is one part of a channel concat.
+    `rowstats` (fp32 [M, 2], see rowstats_ok) makes the layer write LayerNorm's (mean, rstd) of its output rows (VCX_GEMM_ROWSTATS)."""
     n_out = N // 2 if geglu else N
     _dev16(a, w, residual)
     _dev32(bias, rowadd)
@@ -98,6 +103,12 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
         d.colstats = colstats.data_ptr() + 8 * int(colstats_col)
         d.ldcs = cld
         flags |= GEMM_COLSTATS
+    if rowstats is not None:
+        _dev32(rowstats)
+        if rowstats.numel() != 2 * M or not rowstats.is_contiguous():
+            raise VcxError(f"rowstats must hold [M = {M}, 2] floats, got {tuple(rowstats.shape)}")
+        d.rowstats, d.rowstats_eps = rowstats.data_ptr(), float(rowstats_eps)
+        flags |= GEMM_ROWSTATS
     d.lda, d.M, d.N, d.K = lda, M, N, K
     d.ldw = ldw if ldw is not None else K
     d.ldc = ldc
@@ -114,9 +125,28 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
     return out
 
 
-def gemm_units(a, wn, bn, *, unit_rows, out=None):
+def rowstats_ok(M, N, K, *, lda=None, ldc=None, ldr=0, unit_rows=None):
+    """Will the layer producing an [M, N] output - vcx_gemm_f16 (bias / residual at most), or vcx_gemm_units_f16 with `unit_rows` rows per
+    weight set - write LayerNorm's row statistics of its output (VCX_GEMM_ROWSTATS)?  Only the pipelined weight-stationary kernel has
+    that epilogue: a mirror of its dispatch conditions in csrc/gemm.hip (N = K = 320, M >= 8192, 32-bit extents, knobs GEMM_DMA /
+    GEMM_WS on and no forced tile configuration); elsewhere the consumer makes its statistics pass (row_stats)."""
+    lim = 0xFFFF0000
+    lda, ldc = K if lda is None else lda, N if ldc is None else ldc
+    ok = (LN_ROWSTATS and N == 320 and K == 320 and M >= 8192 and tune_get("GEMM_DMA") != 0 and tune_get("GEMM_WS") != 0 and tune_get("GEMM_CFG") < 0
+          and 2 * ((M - 1) * lda + K) < lim and 2 * (M + 256) * ldc < lim and 2 * (M + 256) * ldr < lim and 8 * M < lim)
+    if unit_rows is not None:
+        ok = ok and M // unit_rows > 1 and M // unit_rows <= 65535 and unit_rows % 32 == 0 and unit_rows >= 1024
+    return ok
+
+
+def rowstats_buffer(M, device):
+    return torch.empty((M, 2), dtype=_f32, device=device)
+
+
+def gemm_units(a, wn, bn, *, unit_rows, out=None, rowstats=None, rowstats_eps=1e-5):
     """out[M, N] = a[M, K] Wn[u]^T + bn[u] for the rows of unit u = m // unit_rows: wn [units, N, K] fp16, bn [units, N] fp32 (the
-    sets of group_norm_fold_linear).  One launch of the weight-stationary kernel where it applies, else unit by unit (include/vcx.h)."""
+    sets of group_norm_fold_linear).  One launch of the weight-stationary kernel where it applies, else unit by unit (include/vcx.h).
+    `rowstats`: as in gemm (one-launch form only, see rowstats_ok)."""
     M, K = a.shape
     units, N, K2 = wn.shape
     _dev16(a, wn, out)
@@ -129,6 +159,12 @@ def gemm_units(a, wn, bn, *, unit_rows, out=None):
     d.A, d.W, d.C, d.bias = a.data_ptr(), wn.data_ptr(), out.data_ptr(), bn.data_ptr()
     d.lda, d.M, d.N, d.K, d.ldw, d.ldc = a.stride(0), M, N, K, K, out.stride(0)
     d.flags, d.alpha = GEMM_BIAS_N, 1.0
+    if rowstats is not None:
+        _dev32(rowstats)
+        if rowstats.numel() != 2 * M or not rowstats.is_contiguous():
+            raise VcxError(f"rowstats must hold [M = {M}, 2] floats, got {tuple(rowstats.shape)}")
+        d.rowstats, d.rowstats_eps = rowstats.data_ptr(), float(rowstats_eps)
+        d.flags |= GEMM_ROWSTATS
     check(lib().vcx_gemm_units_f16(ctypes.byref(d), int(unit_rows), N * K, N, _stream()), "vcx_gemm_units_f16")
     return out
 
