@@ -99,10 +99,11 @@ int vcx_device_arch(char* name_host, int len);
 /* LayerNorm statistics from the producing layer (round 6): besides out, the layer writes rowstats[m] = (mean, rstd = 1 / sqrt(var +
  * rowstats_eps)) of the fp16-ROUNDED output row m over its N columns - what vcx_rowstats_f16 computes from the stored tensor, so the
  * LayerNorm-folded projection behind it (VCX_GEMM_LNFOLD: nn.LayerNorm -> nn.Linear of BasicTransformerBlock, attention.py:226-246)
- * needs no statistics pass.  The row's deviations from a per-row shift (the median of three of its values) are summed and squared on
- * the matrix pipe (ones x D and the diagonal of D^T D, fp32 accumulation of fp16 products), per 80-column strip, and the four strips
- * of a row merged Chan-style in a fixed order: robust to |mean| >> std, bit-reproducible, independent of M; agrees with
- * vcx_rowstats_f16 to fp32 rounding of the sums, not bit for bit (another summation order).  Only where ONE block owns whole rows:
+ * needs no statistics pass.  Sums on the matrix pipe (fp32 accumulation of exact fp16 products): the row sum as ones x X, the sum of
+ * squares as the diagonal of D^T D with D = X minus a per-strip shift - 0, or one of the row's values where the strip is offset
+ * (|value| > 4 x the spread of eight samples: X - shift is then exact in fp16) - per 80-column strip; the four strips of a row
+ * merged Chan-style in a fixed order: robust to |mean| >> std, bit-reproducible, independent of M; agrees with vcx_rowstats_f16
+ * to fp32 rounding of the sums (mean 2e-6 of the row's magnitude, rstd 6e-5 relative), not bit for bit (another summation order).  Only where ONE block owns whole rows:
  * the weight-stationary kernel, linear mode, N = K = 320, M >= 8192, BIAS_N / RESIDUAL at most, fp16 output (the attention output
  * projections and proj_in of the C = 320 level); with vcx_gemm_units_f16 too.  Any other shape: VCX_EINVAL. */
 #define VCX_GEMM_ROWSTATS 0x400

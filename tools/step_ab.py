@@ -9,6 +9,7 @@ A variant is  name:key=value,key=value  with keys
     lnff     0 | 1   LayerNorm folded into the GEGLU projection (FOLD_LAYERNORM_FF)
     xattn    1 | 2   resident cross-attention kernel: second form | first form (knob XATTN_RESIDENT)
     ws       1 | 0   weight-stationary K = 320 kernel (knob GEMM_WS)
+    lnrs     1 | 0   LayerNorm statistics from the producing layer's epilogue (VCX_GEMM_ROWSTATS; ops.LN_ROWSTATS)
 e.g.   base:gnfold=0,xattn=2  gnfold:gnfold=1,xattn=2  xattn2:gnfold=0,xattn=1  all:gnfold=1,xattn=1
 --lib runs everything on another build of the library of the SAME ABI (e.g. tools/_abl/libvcx_gelu_select.so, built by
 tools/build_abl.sh): a library-level change is then compared across two invocations on the same box."""
@@ -75,6 +76,7 @@ def main():
                     m._drop_packed()
         ops.tune_set("XATTN_RESIDENT", int(settings.get("xattn", "1")))
         ops.tune_set("GEMM_WS", int(settings.get("ws", "1")))
+        ops.LN_ROWSTATS = settings.get("lnrs", "1") != "0"
 
     def run(settings, steps, profile):
         apply(settings)

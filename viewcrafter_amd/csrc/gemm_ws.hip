@@ -338,24 +338,50 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v0[r]), "+v"(v1[r]));      // fp32 first, then ONE fp16 rounding (no v_fma_mixlo_f16)
-        const u2v p0 = __builtin_bit_cast(u2v, h4{(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]});
+        // RS: the packed words are formed ONCE, as pairs (v_cvt_pk_f16_f32), and serve the statistics and the store; the plain kernels keep
+        // the expression their listing was tuned with
+        typedef float f2w __attribute__((ext_vector_type(2)));
+        [[maybe_unused]] h2v x0, x1, x2 = {(half_t)0.f, (half_t)0.f}, x3 = x2;
+        u2v p0;
         [[maybe_unused]] u2v p1s = {0u, 0u};
-        if constexpr (wide) p1s = __builtin_bit_cast(u2v, h4{(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]});
+        if constexpr (RS) {
+            x0 = __builtin_convertvector(f2w{v0[0], v0[1]}, h2v);
+            x1 = __builtin_convertvector(f2w{v0[2], v0[3]}, h2v);
+            p0 = u2v{__builtin_bit_cast(unsigned, x0), __builtin_bit_cast(unsigned, x1)};
+            if constexpr (wide) {
+                x2 = __builtin_convertvector(f2w{v1[0], v1[1]}, h2v);
+                x3 = __builtin_convertvector(f2w{v1[2], v1[3]}, h2v);
+                p1s = u2v{__builtin_bit_cast(unsigned, x2), __builtin_bit_cast(unsigned, x3)};
+            }
+        } else {
+            p0 = __builtin_bit_cast(u2v, h4{(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]});
+            if constexpr (wide) p1s = __builtin_bit_cast(u2v, h4{(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]});
+        }
         if constexpr (RS) {
             if constexpr (u == 0) {
-                // The shift of (row lr, this wave's strip), from the strip's first three values (lane lg = 0, fragment 0, columns 0 .. 2): their
-                // median where the row is OFFSET (|median| > 8 x their spread: then value - shift is exact in fp16, and sums of squares of
-                // the raw values would cancel), else 0 (the deviations are the values themselves: exact, and nothing to cancel).
-                const h4 f = __builtin_bit_cast(h4, p0);
-                const float fa = (float)f[0], fb = (float)f[1], fc = (float)f[2];
-                const float med = __builtin_amdgcn_fmed3f(fa, fb, fc);
-                const float spread = __builtin_fmaxf(__builtin_fmaxf(fa, fb), fc) - __builtin_fminf(__builtin_fminf(fa, fb), fc);
-                const half_t k3 = (half_t)(__builtin_fabsf(med) > 8.0f * spread ? med : 0.0f);      // (exact: one of the three, or 0)
+                // The shift of (row lr, this wave's strip), decided in the lane with lg = 0 from its eight values (fragments 0 and 1, columns
+                // 0 .. 3 of each): the median of three of them where the row is OFFSET (|median| > 4 x the spread of the eight: every
+                // value of such a row is within a factor 1.25 of the shift, so value - shift is exact in fp16, and the squares of the raw
+                // values would cancel), else 0 (the deviations are the values themselves: exact, and |mean| <= ~11 std loses < 2e-5 of the
+                // variance in fp32).  A shift that is neither - taken by accident in a row that is not offset - would round the
+                // deviations to fp16 (1e-4 of that row's variance): eight samples make the accident a 1e-6 event.
+                // (asm: __builtin_fmaxf puts a canonicalising v_max_f32 x, x in front of every operand)
+                float hi8, lo8;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(hi8) : "v"(v0[0]), "v"(v0[1]), "v"(v0[2]));
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(hi8) : "v"(v0[3]), "v"(v1[0]));
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(hi8) : "v"(v1[1]), "v"(v1[2]));
+                asm("v_max_f32 %0, %0, %1" : "+v"(hi8) : "v"(v1[3]));
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo8) : "v"(v0[0]), "v"(v0[1]), "v"(v0[2]));
+                asm("v_min3_f32 %0, %0, %1, %2" : "+v"(lo8) : "v"(v0[3]), "v"(v1[0]));
+                asm("v_min3_f32 %0, %0, %1, %2" : "+v"(lo8) : "v"(v1[1]), "v"(v1[2]));
+                asm("v_min_f32 %0, %0, %1" : "+v"(lo8) : "v"(v1[3]));
+                const float med = __builtin_amdgcn_fmed3f(v0[0], v0[1], v0[2]);
+                const half_t k3 = (half_t)(__builtin_fabsf(med) > 4.0f * (hi8 - lo8) ? med : 0.0f);      // (rounding is monotonic: the fp16 value of one of the three, or 0)
                 const unsigned kk = (unsigned)__builtin_bit_cast(unsigned short, k3) * 0x10001u;
                 rsK[b] = __builtin_bit_cast(h2v, (unsigned)__shfl((int)kk, lr));
             }
             const h2v k2 = rsK[b];
-            const h2v x0 = __builtin_bit_cast(h2v, p0[0]), x1 = __builtin_bit_cast(h2v, p0[1]), x2 = __builtin_bit_cast(h2v, p1s[0]), x3 = __builtin_bit_cast(h2v, p1s[1]);
+            // (never __builtin_bit_cast(h2v, p0[1]): a bit_cast of a vector ELEMENT reads element 0 with this hipcc - the finding of row_halves() in attention.hip)
             const h2v d0 = x0 - k2, d1 = x1 - k2;
             h2v d2 = {(half_t)0.f, (half_t)0.f}, d3 = d2;
             if constexpr (wide) { d2 = x2 - k2; d3 = x3 - k2; }

@@ -344,7 +344,9 @@ int64_t pick_pix_per_block(int n_outer, int64_t pixels) {
     // <= 1024 partials per n; >= 128 pixels per block on large images, 16 up to 4096 pixels: the 18 MB tensors of the 9 x 16-pixel level
     // (3600 pixels per video, n = 2) are 450 blocks instead of 58 - round 6: 24 -> ~8 us per pass.
     (void)n_outer;
+#ifndef VCX_GN_TWO_PHASE          // (tools/build_abl.sh gnold -DVCX_GN_TWO_PHASE: the round-5 statistics plumbing, for the same-box A/B)
     if (pixels <= 4096) return 16;
+#endif
     int64_t ppb = (pixels + 1023) / 1024;
     if (ppb < 128) ppb = 128;
     return ppb;
@@ -353,6 +355,9 @@ int64_t pick_pix_per_block(int n_outer, int64_t pixels) {
 // Direct form of the statistics pass (gn_stats_kernel with `stats`): one block per (n, slice of whole groups) sees all pixels.  Taken
 // up to 512 pixels when C splits into slices of Cs = the smallest multiple of a group AND of eight channels, doubled up to 64.
 bool gn_direct_geometry(int64_t pixels, int C, int groups, int& Cs, int& cw, int& pl) {
+#ifdef VCX_GN_TWO_PHASE
+    return false;
+#endif
     if (pixels > 512) return false;
     const int cpg = C / groups;
     Cs = cpg;
@@ -416,6 +421,9 @@ __global__ void __launch_bounds__(1024) gn_colstats_direct_kernel(const float2* 
 
 // geometry of the one-launch form: up to 1024 strips per n, groups of at most 256 columns
 bool gn_colstats_direct_geometry(int64_t strips, int C, int groups, int& gpb, int& L) {
+#ifdef VCX_GN_TWO_PHASE
+    return false;
+#endif
     const int cpg = C / groups;
     if (strips > 1024 || cpg > 256) return false;
     gpb = 80 / cpg;
