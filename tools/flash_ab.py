@@ -23,7 +23,7 @@ for N, G, heads in shapes:
     vt = torch.randn(C, G * N, device="cuda").half()
     variants = {"v1": (1, 0), "v2": (2, 0)}       # name: (FLASH_IMPL, EXP1); with tools/_abl/libvcx_abl.so also "v2-mfma-sum": (2, 2)
     if ABL:
-        variants.update({"var0": (2, 10), "var1": (2, 11), "var2": (2, 12), "var3": (2, 13)})
+        variants.update({"var0": (2, 10), "var1": (2, 11), "mfma-sum": (2, 2)})
     outs, times = {}, {k: [] for k in variants}
     for k in variants:
         outs[k] = torch.empty(G * N, C, device="cuda", dtype=torch.float16)

@@ -419,14 +419,19 @@ __global__ void __launch_bounds__(1024) gn_colstats_direct_kernel(const float2* 
     }
 }
 
-// geometry of the one-launch form: up to 1024 strips per n, groups of at most 256 columns
+// geometry of the one-launch form: up to 1024 strips per n, groups of at most 256 columns.  Strip lanes first - as many as give a
+// thread ONE batch of eight loads (the kernel is a latency chain: r06e, 11.4 us per launch with two batches per thread on 200 blocks) -
+// then as many whole groups per block as fit 1024 threads, 80 columns at most.  A function of (strips, C, groups) only.
 bool gn_colstats_direct_geometry(int64_t strips, int C, int groups, int& gpb, int& L) {
 #ifdef VCX_GN_TWO_PHASE
     return false;
 #endif
     const int cpg = C / groups;
     if (strips > 1024 || cpg > 256) return false;
-    gpb = 80 / cpg;
+    int lanes = (int)((strips + 7) / 8);
+    if (lanes > 1024 / cpg) lanes = 1024 / cpg;         // (one group per block at least)
+    gpb = 1024 / lanes / cpg;
+    if (gpb > 80 / cpg) gpb = 80 / cpg;
     if (gpb < 1) gpb = 1;
     if (gpb > groups) gpb = groups;
     const int cols = gpb * cpg;
