@@ -36,7 +36,8 @@ extern "C" {
  * vcx_rowstats_f16.  4: colstats (VCX_GEMM_COLSTATS), vcx_groupnorm_stats_from_colstats_f32.  5: vcx_gemm_desc starts with
  * struct_size - a descriptor of another layout is rejected instead of read past its end; ldcs; vcx_clip_preprocess_f32,
  * vcx_add_nchw_f32_to_nhwc_f16.  6: vcx_ddim_ws_bytes, ws_bytes argument of the DDIM steps.  7: vcx_groupnorm_fold_linear_f16,
- * vcx_gemm_units_f16, vcx_attn_flash_d512_f16.  8: vcx_gemm_desc grows rowstats / rowstats_eps (VCX_GEMM_ROWSTATS). */
+ * vcx_gemm_units_f16, vcx_attn_flash_d512_f16.  8: vcx_gemm_desc grows rowstats / rowstats_eps (VCX_GEMM_ROWSTATS) and
+ * tail_a0 / tail_a1 (K tail of a convolution from linear sources); vcx_groupnorm_apply2_f16. */
 #define VCX_ABI_VERSION 8
 
 int vcx_abi_version(void);
@@ -131,6 +132,18 @@ typedef struct vcx_gemm_desc {
     float* rowstats;        /* VCX_GEMM_ROWSTATS: out, fp32 [M][2] = (mean, rstd) of every output row, 8-byte aligned */
     float rowstats_eps;     /* VCX_GEMM_ROWSTATS: the LayerNorm's eps                                */
     int32_t reserved0;      /* 0                                                                     */
+    /* K tail of a convolution (mode 1, round 6): K = kh*kw*cin + tail_k0 + tail_k1, and the last tail_k0 + tail_k1 columns of every W
+     * row multiply, for output row m, the first tail_k0 elements of row m of tail_a0 and then the first tail_k1 of row m of tail_a1
+     * (fp16 [M][tail_lda*], row-for-row like a linear layer).  A ResBlock's 1x1 skip convolution folded into its second 3x3
+     * convolution - `return self.skip_connection(x) + h`, openaimodel3d.py:228-235 - with x in one piece or, on the up path, as the
+     * two halves of `torch.cat([h, hs.pop()], dim=1)` (:596) that are then never concatenated.  tail_k* % 64 == 0, DMA kernel only
+     * (cin % 64 == 0, 32-bit extents), fp16 output, no GEGLU.  0 / null: none. */
+    const void* tail_a0;
+    const void* tail_a1;
+    int64_t tail_lda0;
+    int64_t tail_lda1;
+    int32_t tail_k0;
+    int32_t tail_k1;
 } vcx_gemm_desc;
 
 int vcx_gemm_f16(const vcx_gemm_desc* desc_host, void* stream);
@@ -160,6 +173,11 @@ int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, int n_outer, 
 int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stats, const float* gamma,
                             const float* beta, int n_outer, int64_t pixels, int C, int groups,
                             float eps, int silu, void* stream);
+/* The same pass over a channel concat that is never materialised (round 6): channels [0, c1) of a pixel are read from x1
+ * [n_outer][pixels][c1], channels [c1, C) from x2 [n_outer][pixels][C - c1]; y [n_outer][pixels][C] as above.  The in_layers norm of
+ * an up-path ResBlock over `torch.cat([h, hs.pop()], dim=1)` (openaimodel3d.py:596 -> :174-186).  c1 % 8 == 0. */
+int vcx_groupnorm_apply2_f16(const void* x1, int c1, const void* x2, void* y, const float* stats, const float* gamma, const float* beta,
+                             int n_outer, int64_t pixels, int C, int groups, float eps, int silu, void* stream);
 /* stats[n_outer][groups][2] from the column moments a VCX_GEMM_COLSTATS convolution wrote (colstats[n_outer * pixels / 64][C][2];
  * pixels % 64 == 0): the strips and then the columns of a group are merged Chan-style in a fixed order (bit-reproducible,
  * independent of the batch size); ws as for vcx_groupnorm_stats_f16 (vcx_groupnorm_ws_bytes). */

@@ -22,10 +22,12 @@ def _view2d(t, rows, cols, ld, extra=0):
 
 def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, residual=None, ldr=None, rowadd=None, rowadd_div=0,
          geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None, ln_stats=None, ln_colsum=None, ln_t=False, colstats=None,
-         colstats_ld=None, colstats_col=0, rowstats=None, rowstats_eps=1e-5):
+         colstats_ld=None, colstats_col=0, rowstats=None, rowstats_eps=1e-5, tail=None):
     n_out = N // 2 if geglu else N
+    tail_k = sum(t.shape[1] for t in tail or ())
     ldw = K if ldw is None else ldw
     W = _view2d(w, N, K, ldw).float()
+    K -= tail_k          # the gather's part of K; the tail columns are appended below
     if conv is None:
         X = _view2d(a, M, K, lda).float()
     else:
@@ -48,6 +50,8 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
         if conv.get("slabk", conv_slab_major(cin, kh * kw)):
             X = X.view(n_img, g["out_h"], g["out_w"], kh * kw, cin // 64, 64).permute(0, 1, 2, 4, 3, 5)
         X = X.reshape(M, K)
+    if tail:
+        X = torch.cat([X] + [t.float() for t in tail], dim=1)
     acc = X @ W.t()
     if ln_stats is not None:
         st = ln_stats.float().view(-1, 2)
@@ -130,7 +134,9 @@ def group_norm_fold_linear(w32, bias, gamma, beta, stats, eps, groups=32):
     return wn, bn.float().contiguous()
 
 
-def group_norm(x, gamma, beta, eps, silu, groups=32, out=None, stats=None):
+def group_norm(x, gamma, beta, eps, silu, groups=32, out=None, stats=None, x2=None):
+    if x2 is not None:
+        x = torch.cat([x, x2], dim=2)
     n, pixels, C = x.shape
     xf = x.float().view(n, pixels, groups, C // groups)
     if stats is None:
@@ -144,6 +150,10 @@ def group_norm(x, gamma, beta, eps, silu, groups=32, out=None, stats=None):
         out = torch.empty_like(x)
     out.copy_(y.to(_f16))
     return out
+
+
+def conv_tail_ok(M, cin, cout, taps, tail_ks, in_rows=None):
+    return cin % 64 == 0 and cout % 8 == 0 and all(k % 64 == 0 and k > 0 for k in tail_ks) and 0 < len(tail_ks) <= 2
 
 
 def row_stats(x, eps=1e-5):
@@ -256,7 +266,7 @@ def install(monkeypatch):
     _TUNE.clear()
     table = dict(require_gpu=lambda: None, gemm=gemm, group_norm_stats_from_colstats=group_norm_stats_from_colstats, group_norm=group_norm,
                  group_norm_stats=group_norm_stats, group_norm_fold_linear=group_norm_fold_linear, gemm_units=gemm_units,
-                 row_stats=row_stats, layer_norm=layer_norm, flash_attn=flash_attn, flash_attn_d512=flash_attn_d512, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn,
+                 row_stats=row_stats, layer_norm=layer_norm, conv_tail_ok=conv_tail_ok, flash_attn=flash_attn, flash_attn_d512=flash_attn_d512, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn,
                  softmax_rows_=softmax_rows_, copy2d=copy2d, add_nchw_=add_nchw_, ncthw_to_nthwc=ncthw_to_nthwc, nthwc_to_ncthw=nthwc_to_ncthw,
                  timestep_embedding=timestep_embedding, silu_f32=lambda x: F.silu(x.float()), gelu_=lambda x: x.copy_(F.gelu(x.float()).to(_f16)),
                  to_f16=lambda x: x.to(_f16).contiguous(), to_f32=lambda x: x.float().contiguous(),

@@ -69,11 +69,11 @@ def header_gemm_desc_fields():
 
 def test_gemm_desc_layout_matches_header():
     """The ctypes mirror follows the C struct of include/vcx.h field by field (names and order parsed from the header; C types
-    mapped to ctypes) and in total size: size_t, 10 pointers, two int64, 22 int32, two floats - 200 bytes, no padding."""
+    mapped to ctypes) and in total size: size_t, 12 pointers, four int64, 24 int32, two floats - 240 bytes, no padding."""
     want = header_gemm_desc_fields()
     assert [(f[0], f[1]) for f in _lib.GemmDesc._fields_] == want
-    assert ctypes.sizeof(_lib.GemmDesc) == 8 + 10 * 8 + 2 * 8 + 22 * 4 + 2 * 4 == 200
-    assert _lib.GemmDesc().struct_size == 200 and _lib.GemmDesc(M=3).struct_size == 200
+    assert ctypes.sizeof(_lib.GemmDesc) == 8 + 12 * 8 + 4 * 8 + 24 * 4 + 2 * 4 == 240
+    assert _lib.GemmDesc().struct_size == 240 and _lib.GemmDesc(M=3).struct_size == 240
 
 
 def test_integration_md_stub_matches_header():

@@ -803,6 +803,86 @@ def test_gemm_rowstats_rejects_what_the_kernel_cannot_do():
     assert not ops.rowstats_ok(9000, 640, 320) and not ops.rowstats_ok(4096, 320, 320) and ops.rowstats_ok(9000, 320, 320)
 
 
+@pytest.mark.parametrize("n,H,W,cin,cout,tails,lda_pad,colstats", [
+    (2, 16, 32, 64, 128, (64,), 0, False),              # one source, small tiles
+    (3, 24, 40, 128, 320, (192, 64), 0, True),          # two sources (the halves of a concat), 128 x 160 tiles, column moments
+    (50, 32, 64, 64, 320, (320, 320), 0, True),         # 400 tiles: the 256 x 320 configuration + its small-tile tail
+    (2, 9, 16, 320, 320, (640, 320), 64, False),        # the 9 x 16 level; sources with a row stride beyond their width
+    (4, 36, 64, 64, 256, (128,), 8, True),              # 256 x 256 tiles
+    (1, 8, 8, 64, 64, (64, 64), 0, False)])             # a single tile
+def test_conv3x3_with_a_k_tail_is_the_folded_skip_convolution(n, H, W, cin, cout, tails, lda_pad, colstats):
+    """Round 6, include/vcx.h tail_a0 / tail_a1: conv3x3(a) + conv1x1([x1 | x2]) as ONE launch - the last K-steps of a tile read rows of
+    x1 / x2 instead of pixels (reference ResBlock: `return self.skip_connection(x) + h`, openaimodel3d.py:228-235, with x the concat of
+    :596 on the up path).  Against fp32 of the two convolutions; against the two-launch form it replaces (1x1 convolution, then the
+    3x3 with its result as the residual) to fp16 rounding; column moments of the result; untouched guard rows."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import pack_conv
+    M = n * H * W
+    a = rnd(n, H, W, cin, seed=871).to(DEV).half()
+    w3 = rnd(cout, cin, 3, 3, seed=872) / math.sqrt(9 * cin)
+    b3 = rnd(cout, seed=873) * 0.1
+    srcs, w1s = [], []
+    for j, k in enumerate(tails):
+        buf = rnd(M, k + lda_pad, seed=874 + j).to(DEV).half()
+        srcs.append(buf[:, :k])
+        w1s.append(rnd(cout, k, seed=880 + j) / math.sqrt(sum(tails)))
+    b1 = rnd(cout, seed=890) * 0.1
+    assert ops.conv_tail_ok(M, cin, cout, 9, list(tails))
+    wcat = torch.cat([pack_conv(w3)] + w1s, dim=1).to(DEV).half().contiguous()
+    guard = torch.full((M + 64, cout), 7.0, device=DEV, dtype=torch.float16)
+    cs = ops.colstats_buffer(M, cout, DEV) if colstats else None
+    kw = dict(colstats=cs) if colstats else {}
+    y = ops.conv2d(a, wcat, (b3 + b1).to(DEV), kh=3, kw=3, tail=srcs, out=guard[:M], **kw)
+    assert bool((guard[M:] == 7.0).all())
+    # fp32 reference of both convolutions on the fp16-rounded operands
+    ref = F.conv2d(a.float().permute(0, 3, 1, 2), w3.to(DEV).half().float(), b3.to(DEV), padding=1).permute(0, 2, 3, 1).reshape(M, cout)
+    ref = ref + torch.cat([s_.float() for s_ in srcs], dim=1) @ torch.cat(w1s, dim=1).to(DEV).half().float().t() + b1.to(DEV)
+    check(y.reshape(M, cout), ref, name="conv3x3 + K tail")
+    # the two launches it replaces
+    xcat = torch.cat(srcs, dim=1).contiguous()
+    skip = ops.linear(xcat, torch.cat(w1s, dim=1).to(DEV).half().contiguous(), b1.to(DEV))
+    two = ops.conv2d(a, pack_conv(w3).to(DEV).half(), b3.to(DEV), kh=3, kw=3, residual=skip)
+    assert rel_l2(y.reshape(M, cout), two.reshape(M, cout).float()) <= 1e-3
+    if colstats:
+        st = ops.group_norm_stats_from_colstats(cs, n, H * W, cout)
+        yd = y.double().reshape(n, H * W, 32, cout // 32)
+        mu, var = yd.mean(dim=(1, 3)), yd.var(dim=(1, 3), unbiased=False)
+        assert float((st[..., 0].double() - mu).abs().max()) <= 2e-6 * float(mu.abs().max() + 1) and rel_l2(st[..., 1], var) <= 2e-5
+    assert torch.equal(ops.conv2d(a, wcat, (b3 + b1).to(DEV), kh=3, kw=3, tail=srcs), y.view(n, H, W, cout)), "not bit-reproducible"
+
+
+def test_conv_k_tail_rejects_what_the_kernel_cannot_do():
+    from viewcrafter_amd import ops
+    from viewcrafter_amd._lib import VcxError
+    a = rnd(1, 8, 8, 64, seed=895).to(DEV).half()
+    w = rnd(64, 9 * 64 + 48, seed=896).to(DEV).half()
+    with pytest.raises(VcxError, match="tail"):               # a tail width that is not a whole number of K-steps
+        ops.conv2d(a, w, None, kh=3, kw=3, tail=[rnd(64, 48, seed=897).to(DEV).half()])
+    a8 = rnd(1, 8, 8, 8, seed=898).to(DEV).half()
+    with pytest.raises(VcxError, match="tail"):               # cin % 64 != 0: the register-staged kernel has no tail
+        ops.conv2d(a8, rnd(64, 72 + 64, seed=899).to(DEV).half(), None, kh=3, kw=3, tail=[rnd(64, 64, seed=900).to(DEV).half()])
+    assert not ops.conv_tail_ok(64, 8, 64, 9, [64]) and not ops.conv_tail_ok(64, 64, 64, 9, [48]) and ops.conv_tail_ok(64, 64, 64, 9, [64, 128])
+
+
+@pytest.mark.parametrize("n,pix,c1,c2,silu", [(2, 1000, 320, 640, True), (50, 144, 1280, 1280, True), (3, 77, 64, 32, False), (1, 9216, 640, 320, True)])
+def test_groupnorm_over_a_split_concat(n, pix, c1, c2, silu):
+    """vcx_groupnorm_apply2_f16: the norm over [x1 | x2] reading the halves in place - the same bits as the norm of the materialised
+    concat (one kernel, a per-thread source select)."""
+    from viewcrafter_amd import ops
+    x1 = (rnd(n, pix, c1, seed=901) * 2 + 0.3).to(DEV).half()
+    x2 = (rnd(n, pix, c2, seed=902) * 0.5 - 1.0).to(DEV).half()
+    C = c1 + c2
+    g, b = (1 + 0.2 * rnd(C, seed=903)).to(DEV), (0.1 * rnd(C, seed=904)).to(DEV)
+    xc = torch.cat([x1, x2], dim=2).contiguous()
+    st = ops.group_norm_stats(xc)
+    want = ops.group_norm(xc, g, b, 1e-5, silu, stats=st)
+    guard = torch.full((n * pix + 8, C), 7.0, device=DEV, dtype=torch.float16)
+    got = ops.group_norm(x1, g, b, 1e-5, silu, stats=st, x2=x2, out=guard[:n * pix].view(n, pix, C))
+    assert torch.equal(got, want) and bool((guard[n * pix:] == 7.0).all())
+    ref = F.group_norm(xc.float().permute(0, 2, 1), 32, g, b, 1e-5)
+    check(got, (F.silu(ref) if silu else ref).permute(0, 2, 1), name="groupnorm over a split concat")
+
+
 @pytest.mark.parametrize("n,strips,C", [(3, 1, 320), (50, 144, 320), (7, 36, 640), (5, 9, 1280), (2, 900, 640), (2, 225, 1280), (2, 1024, 64), (3, 37, 960),
                                         (2, 17, 2560), (2, 100, 1920), (2, 3600, 320)])
 def test_groupnorm_statistics_from_column_moments_in_one_launch(n, strips, C):

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libvcx.so")
 # every symbol include/vcx.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
     "vcx_abi_version", "vcx_last_error", "vcx_device_arch", "vcx_gemm_f16", "vcx_gemm_units_f16",
-    "vcx_groupnorm_ws_bytes", "vcx_groupnorm_stats_f16", "vcx_groupnorm_apply_f16", "vcx_groupnorm_stats_from_colstats_f32", "vcx_groupnorm_fold_linear_f16", "vcx_layernorm_f16", "vcx_rowstats_f16",
+    "vcx_groupnorm_ws_bytes", "vcx_groupnorm_stats_f16", "vcx_groupnorm_apply_f16", "vcx_groupnorm_apply2_f16", "vcx_groupnorm_stats_from_colstats_f32", "vcx_groupnorm_fold_linear_f16", "vcx_layernorm_f16", "vcx_rowstats_f16",
     "vcx_attn_flash_d64_f16", "vcx_attn_flash_d512_f16", "vcx_attn_flash_dual_d64_f16", "vcx_attn_temporal_d64_f16", "vcx_softmax_rows_f16",
     "vcx_silu_f32", "vcx_gelu_f16", "vcx_clip_preprocess_f32", "vcx_add_nchw_f32_to_nhwc_f16", "vcx_timestep_embedding_f32", "vcx_cast_f32_to_f16", "vcx_cast_f16_to_f32",
     "vcx_copy2d_f16", "vcx_ncthw_f32_to_nthwc_f16", "vcx_nthwc_to_ncthw_f32", "vcx_ddim_ws_bytes", "vcx_ddim_step_f32", "vcx_ddim_step3_f32",
@@ -41,6 +41,7 @@ class GemmDesc(ctypes.Structure):
         ("ups", c_int32), ("rowadd_div", c_int32), ("flags", c_int32), ("alpha", c_float),
         ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("colstats", c_void_p), ("ldcs", c_int64),
         ("rowstats", c_void_p), ("rowstats_eps", c_float), ("reserved0", c_int32),
+        ("tail_a0", c_void_p), ("tail_a1", c_void_p), ("tail_lda0", c_int64), ("tail_lda1", c_int64), ("tail_k0", c_int32), ("tail_k1", c_int32),
     ]
 
     def __init__(self, *args, **kw):
@@ -80,6 +81,8 @@ def lib():
     L.vcx_groupnorm_stats_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]
     L.vcx_groupnorm_apply_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
                                           c_int, c_float, c_int, c_void_p]
+    L.vcx_groupnorm_apply2_f16.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
+                                           c_int, c_float, c_int, c_void_p]
     L.vcx_layernorm_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]
     L.vcx_rowstats_f16.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]
     L.vcx_groupnorm_stats_from_colstats_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]

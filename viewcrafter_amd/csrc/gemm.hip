@@ -438,12 +438,21 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
         VCX_REQUIRE(d->ldcs == 0 || (d->ldcs >= d->N && d->ldcs % 2 == 0), "vcx_gemm_f16: COLSTATS ldcs (%lld) must be 0 or an even number >= N", (long long)d->ldcs);
     }
     if (conv) {
-        VCX_REQUIRE(d->cin > 0 && d->cin % 8 == 0 && d->kh > 0 && d->kw > 0 && d->K == d->kh * d->kw * d->cin,
-                    "vcx_gemm_f16: conv needs cin %% 8 == 0 and K == kh*kw*cin (cin=%d kh=%d kw=%d K=%d)", d->cin,
-                    d->kh, d->kw, d->K);
+        VCX_REQUIRE(d->cin > 0 && d->cin % 8 == 0 && d->kh > 0 && d->kw > 0 && d->tail_k0 >= 0 && d->tail_k1 >= 0 &&
+                        d->K == d->kh * d->kw * d->cin + d->tail_k0 + d->tail_k1,
+                    "vcx_gemm_f16: conv needs cin %% 8 == 0 and K == kh*kw*cin + tail (cin=%d kh=%d kw=%d K=%d tail=%d+%d)", d->cin,
+                    d->kh, d->kw, d->K, d->tail_k0, d->tail_k1);
         VCX_REQUIRE(d->out_h > 0 && d->out_w > 0 && d->in_h > 0 && d->in_w > 0 && d->stride > 0 &&
                         (d->ups == 0 || d->ups == 1) && d->M % (d->out_h * d->out_w) == 0,
                     "vcx_gemm_f16: bad conv geometry");
+    }
+    const int tail = conv ? d->tail_k0 + d->tail_k1 : 0;
+    VCX_REQUIRE(conv || (d->tail_k0 == 0 && d->tail_k1 == 0), "vcx_gemm_f16: a K tail (tail_k0 / tail_k1) belongs to a convolution (mode 1)");
+    if (tail) {
+        VCX_REQUIRE(d->tail_k0 % 64 == 0 && d->tail_k1 % 64 == 0 && (d->tail_k0 == 0 || (d->tail_a0 && d->tail_lda0 >= d->tail_k0 && d->tail_lda0 % 8 == 0)) &&
+                        (d->tail_k1 == 0 || (d->tail_a1 && d->tail_lda1 >= d->tail_k1 && d->tail_lda1 % 8 == 0)) && !(d->tail_k0 == 0 && d->tail_k1 != 0),
+                    "vcx_gemm_f16: K tail: tail_k %% 64 == 0, sources with tail_lda >= tail_k, tail_lda %% 8 == 0, tail_a0 first (tail=%d+%d)", d->tail_k0, d->tail_k1);
+        VCX_REQUIRE((((uintptr_t)d->tail_a0 | (uintptr_t)d->tail_a1) & 15) == 0 && !geglu && !f32 && !lnf, "vcx_gemm_f16: K tail: 16-byte aligned sources, fp16 output, no GEGLU / LNFOLD");
     }
     // vector epilogue alignment
     if (!geglu) {
@@ -482,6 +491,8 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.ldcs = d->ldcs > 0 ? d->ldcs : d->N;
     a.unit_rows = 0; a.units = 1; a.w_unit_stride = 0; a.bias_unit_stride = 0;
     a.rowstats = d->rowstats; a.rowstats_eps = d->rowstats_eps;
+    a.A2 = (const half_t*)d->tail_a0; a.A3 = (const half_t*)d->tail_a1; a.lda2 = d->tail_lda0; a.lda3 = d->tail_lda1;
+    a.k2 = conv ? d->tail_k0 : 0; a.k3 = conv ? d->tail_k1 : 0; a.a2_bytes = a.a3_bytes = 0;
     if (flags & VCX_GEMM_ROWSTATS)
         VCX_REQUIRE(d->rowstats && ((uintptr_t)d->rowstats & 7) == 0 && d->rowstats_eps >= 0.f, "vcx_gemm_f16: ROWSTATS needs an 8-byte aligned rowstats buffer and eps >= 0");
     hipStream_t s = (hipStream_t)stream;
@@ -500,8 +511,12 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     const unsigned long long c_ext = esz * ((unsigned long long)(d->M - 1) * d->ldc + (geglu ? d->N / 2 : d->N));
     const unsigned long long r_ext = d->residual ? 2ull * ((unsigned long long)(d->M - 1) * d->ldr + d->N) : 0;
     const bool out_ok = esz * (unsigned long long)(d->M + 256) * d->ldc < lim && 2ull * (unsigned long long)(d->M + 256) * d->ldr < lim;
+    const unsigned long long a2_ext = a.k2 ? 2ull * ((unsigned long long)(d->M - 1) * d->tail_lda0 + a.k2) : 0;
+    const unsigned long long a3_ext = a.k3 ? 2ull * ((unsigned long long)(d->M - 1) * d->tail_lda1 + a.k3) : 0;
     const bool dma_ok = dma_enabled && d->K % 64 == 0 && d->N % ((geglu || f32) ? 4 : 8) == 0 && (!conv || d->cin % 64 == 0) &&   // fp16 output goes out in dwordx4 pieces of 8 columns
-                        a_ext < lim && w_ext < lim && (!geglu || d->N >= 64) && out_ok;
+                        a_ext < lim && w_ext < lim && (!geglu || d->N >= 64) && out_ok && a2_ext < lim && a3_ext < lim;
+    a.a2_bytes = (unsigned)a2_ext; a.a3_bytes = (unsigned)a3_ext;
+    VCX_REQUIRE(!tail || dma_ok, "vcx_gemm_f16: a K tail needs the DMA kernel (cin %% 64 == 0, K %% 64 == 0, N %% 8 == 0, extents < 4 GiB); cin=%d K=%d N=%d", d->cin, d->K, d->N);
     a.a_bytes = (unsigned)a_ext;
     a.w_bytes = (unsigned)w_ext;
     a.c_bytes = (unsigned)c_ext;

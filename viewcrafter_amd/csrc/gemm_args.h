@@ -35,6 +35,12 @@ struct GemmArgs {
     int64_t w_unit_stride, bias_unit_stride;      // elements between consecutive units' weights / biases
     float* rowstats;          // VCX_GEMM_ROWSTATS (gemm_ws320_pipe_kernel only): (mean, rstd) of every output row
     float rowstats_eps;
+    // K tail of a convolution (gemm_dma_kernel<..., TAIL>): the last (k2 + k3) / 64 K-steps read rows of A2, then A3, linearly
+    const half_t* A2;
+    const half_t* A3;
+    int64_t lda2, lda3;
+    int k2, k3;
+    unsigned a2_bytes, a3_bytes;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -133,7 +139,7 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
 }
 
 int persistent_grid(int ntiles, int blocks_per_cu = 2);
-int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);
+int launch_dma(GemmArgs& a, int cfg, bool conv, bool geglu, bool f32, hipStream_t s);      // (a.k2 + a.k3 > 0: the K-tail instantiations)
 int launch_ws320_geglu(GemmArgs& a, hipStream_t s);  // ... GEGLU projection, K = 320, N % 256 == 0
 int launch_ws320_lnfold(GemmArgs& a, hipStream_t s); // ... LayerNorm-folded projection (VCX_GEMM_LNFOLD), K = 320, N % 64 == 0
 int launch_ws320_units(GemmArgs& a, hipStream_t s);  // ... with one weight / bias set per unit of rows (vcx_gemm_units_f16)

@@ -48,7 +48,10 @@ struct TileCfg {
 
 // LNF: 0 = plain epilogue, 1 = VCX_GEMM_LNFOLD, 2 = VCX_GEMM_LNFOLD_T (linear mode only), 3 = VCX_GEMM_COLSTATS (convolutions and, round 4, linear layers);
 // separate instantiations, so the plain kernels keep their register allocation
-template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32, int LNF = 0>
+// TAIL (round 6, convolutions only): the last (p.k2 + p.k3) / 64 K-steps of a tile read, for output row m, row m of p.A2 and then of p.A3
+// - linear sources - instead of an input pixel: the 1x1 skip convolution of a ResBlock rides in the K loop of its second 3x3
+// convolution (include/vcx.h tail_a0 / tail_a1).  Own instantiations: the kernels without a tail keep their listing.
+template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32, int LNF = 0, bool TAIL = false>
 __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the body uses device-only types)
     constexpr int TBM = Cfg::TBM, BN = Cfg::TBN;
@@ -60,6 +63,10 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
 
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, (int)a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.W), 0, (int)w_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t srd_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(TAIL ? p.A2 : p.A), 0, TAIL ? (int)p.a2_bytes : 0, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t srd_a3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(TAIL && p.A3 ? p.A3 : p.A), 0, TAIL ? (int)p.a3_bytes : 0, 0x00020000);
+    [[maybe_unused]] const int nk_main = (p.K - (TAIL ? p.k2 + p.k3 : 0)) / BK, nk_a2 = TAIL ? p.k2 / BK : 0;      // K-steps of the gather / of the first linear source
+    [[maybe_unused]] int lrow0 = 0;                            // first output row of the tile being loaded
 
     const int ntiles = p.tiles_m * p.tiles_n;
     const int G = gridDim.x;
@@ -79,6 +86,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
     auto init_load = [&](int t) {
         int tile_m, tile_n;
         tile_coords(t, ntiles, p.tiles_n, tile_m, tile_n);
+        if (TAIL) lrow0 = p.m_begin + tile_m * TBM;
 #pragma unroll
         for (int i = 0; i < XROWS; ++i) {
             const int r = r0 + RSTEP * i;
@@ -125,7 +133,21 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
     auto load_tile = [&](int kt, int buf, int parts = 3) {       // parts: bit 0 = activation rows, bit 1 = weight rows
         half_t* dx = sX + buf * TBM * BK + wave * 8 * BK;
         half_t* dw = sW + buf * BN * BK + wave * 8 * BK;
-        if (CONV && (parts & 1)) {
+        if (TAIL && CONV && (parts & 1) && kt >= nk_main) {
+            // K tail: row m of a linear source (the descriptor's range check drops rows >= M and anything beyond the source); the K
+            // walker of the gather rests - it is reset by the next tile's init_load
+            const bool first = kt - nk_main < nk_a2;
+            const __amdgpu_buffer_rsrc_t src = first ? srd_a2 : srd_a3;
+            const long long ld2 = (first ? p.lda2 : p.lda3) * 2;
+            const unsigned soff = (unsigned)(first ? kt - nk_main : kt - nk_main - nk_a2) * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < XROWS; ++i) {
+                const int r = r0 + RSTEP * i;
+                const int m = lrow0 + r;
+                const unsigned v = m < p.M ? (unsigned)((long long)m * ld2) + (unsigned)(chunk ^ ((r >> 1) & 7)) * 16u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_ptr_t)(dx + RSTEP * i * BK), 16, v, soff, 0, 0);
+            }
+        } else if (CONV && (parts & 1)) {
             if (p.ups) {
                 // source offset of tap (ky,kx) relative to tap (0,0): ((by+ky)>>1, (bx+kx)>>1) pixels, by/bx = parity of iy0/ix0
                 const unsigned cb = (unsigned)ci0 * 2u, rowb = (unsigned)(p.in_w * (int)p.lda * 2), pixb = (unsigned)((int)p.lda * 2);
@@ -281,10 +303,10 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
 #endif
 }
 
-template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32, int LNF = 0>
+template <class Cfg, bool CONV, bool GEGLU, bool OUT_F32, int LNF = 0, bool TAIL = false>
 int launch(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
-    auto kern = gemm_dma_kernel<Cfg, CONV, GEGLU, OUT_F32, LNF>;
+    auto kern = gemm_dma_kernel<Cfg, CONV, GEGLU, OUT_F32, LNF, TAIL>;
     constexpr size_t smem = LNF ? Cfg::SMEM_LNF : Cfg::SMEM;
     if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)smem, "vcx_gemm_f16(dma)")) return VCX_ELAUNCH;
     const int blocks_per_cu = Cfg::SMEM > 80 * 1024 ? 1 : 2;
@@ -295,6 +317,8 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 template <class Cfg>
 int dispatch(const GemmArgs& a, bool conv, bool geglu, bool f32, hipStream_t s) {
+    if (a.k2 + a.k3 > 0)       // K tail: convolutions with fp16 output, plain or column-moment epilogue (checked by vcx_gemm_f16)
+        return (a.flags & VCX_GEMM_COLSTATS) ? launch<Cfg, true, false, false, 3, true>(a, s) : launch<Cfg, true, false, false, 0, true>(a, s);
     if (a.flags & (VCX_GEMM_LNFOLD | VCX_GEMM_LNFOLD_T)) {      // linear, fp16 output (checked by vcx_gemm_f16)
         if (a.flags & VCX_GEMM_LNFOLD_T) return launch<Cfg, false, false, false, 2>(a, s);
         if (!geglu) return launch<Cfg, false, false, false, 1>(a, s);

@@ -184,7 +184,9 @@ __global__ void __launch_bounds__(256) gn_finalize_small_kernel(const float* __r
     }
 }
 
-__global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ stats,
+// x2 != nullptr (vcx_groupnorm_apply2_f16): the channels [0, c1) of a pixel come from x [n][pixels][c1], the channels [c1, C) from
+// x2 [n][pixels][C - c1] - the two halves of a channel concat that is never materialised (c1 % 8 == 0: a thread's chunk lies in one half)
+__global__ void gn_apply_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2, int c1, half_t* __restrict__ y, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int64_t pixels, int C,
                                 int groups, float eps, int silu, int64_t pix_per_block, int cw, int pl) {
     const int tid = threadIdx.x;
@@ -204,14 +206,20 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
     }
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = (p0 + pix_per_block < pixels) ? p0 + pix_per_block : pixels;
+    int64_t Cx = C;                  // row stride of this thread's source
     const half_t* xp = x + ((int64_t)n * pixels) * C + c8 * 8;
+    if (x2) {
+        const bool right = c8 * 8 >= c1;
+        Cx = right ? C - c1 : c1;
+        xp = (right ? x2 - c1 : x) + ((int64_t)n * pixels) * Cx + c8 * 8;
+    }
     half_t* yp = y + ((int64_t)n * pixels) * C + c8 * 8;
     const int64_t step = pl;
     int64_t pix = p0 + plane;
     for (; pix + 3 * step < p1; pix += 4 * step) {
         h8 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8*>(xp + (pix + u * step) * C);
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8*>(xp + (pix + u * step) * Cx);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -224,7 +232,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
         }
     }
     for (; pix < p1; pix += step) {
-        h8 v = *reinterpret_cast<const h8*>(xp + pix * C);
+        h8 v = *reinterpret_cast<const h8*>(xp + pix * Cx);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float f = (float)v[e] * sc[e] + sh[e];
@@ -577,8 +585,8 @@ extern "C" int vcx_groupnorm_stats_f16(const void* x, float* stats, void* ws, in
     return vcx_check_launch("vcx_groupnorm_stats_f16(finalize)");
 }
 
-extern "C" int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stats, const float* gamma, const float* beta,
-                                       int n_outer, int64_t pixels, int C, int groups, float eps, int silu, void* stream) {
+static int gn_apply_launch(const void* x, const void* x2, int c1, void* y, const float* stats, const float* gamma, const float* beta,
+                           int n_outer, int64_t pixels, int C, int groups, float eps, int silu, void* stream) {
     VCX_REQUIRE(x && y && stats && gamma && beta, "vcx_groupnorm_apply_f16: null pointer");
     VCX_REQUIRE(n_outer > 0 && pixels > 0 && C > 0 && C <= MAXC && groups > 0 && C % groups == 0 && C % 8 == 0,
                 "vcx_groupnorm_apply_f16: need C %% 8 == 0, C <= %d (C=%d groups=%d)", MAXC, C, groups);
@@ -600,9 +608,20 @@ extern "C" int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stat
     dim3 grid((unsigned)((pixels + ppb - 1) / ppb), n_outer);
     int cw, pl;
     gn_geometry(C, cw, pl);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(cw * pl), 0, s, (const half_t*)x, (half_t*)y, stats, gamma, beta, pixels, C,
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(cw * pl), 0, s, (const half_t*)x, (const half_t*)x2, c1, (half_t*)y, stats, gamma, beta, pixels, C,
                        groups, eps, silu, ppb, cw, pl);
     return vcx_check_launch("vcx_groupnorm_apply_f16");
+}
+
+extern "C" int vcx_groupnorm_apply_f16(const void* x, void* y, const float* stats, const float* gamma, const float* beta,
+                                       int n_outer, int64_t pixels, int C, int groups, float eps, int silu, void* stream) {
+    return gn_apply_launch(x, nullptr, 0, y, stats, gamma, beta, n_outer, pixels, C, groups, eps, silu, stream);
+}
+
+extern "C" int vcx_groupnorm_apply2_f16(const void* x1, int c1, const void* x2, void* y, const float* stats, const float* gamma, const float* beta,
+                                        int n_outer, int64_t pixels, int C, int groups, float eps, int silu, void* stream) {
+    VCX_REQUIRE(x2 && c1 > 0 && c1 < C && c1 % 8 == 0 && ((uintptr_t)x2 & 15) == 0, "vcx_groupnorm_apply2_f16: need 0 < c1 < C, c1 %% 8 == 0, x2 16-byte aligned (c1=%d C=%d)", c1, C);
+    return gn_apply_launch(x1, x2, c1, y, stats, gamma, beta, n_outer, pixels, C, groups, eps, silu, stream);
 }
 
 extern "C" int vcx_groupnorm_fold_linear_f16(const float* W, const float* bias, const float* gamma, const float* beta, const float* stats,

@@ -17,16 +17,26 @@ GN_STATS_LEVEL = int(os.environ.get("VCX_GN_EPILOGUE_STATS", "2"))
 GN_EPILOGUE_STATS = GN_STATS_LEVEL >= 1
 
 
+# Round 6: the channel concat of the up path (reference openaimodel3d.py:596) is not materialised where the consuming ResBlock can read
+# its two halves in place - the in_layers norm through vcx_groupnorm_apply2_f16, the 1x1 skip convolution as a K tail of the block's
+# second 3x3 convolution (SKIP_FOLD in openaimodel3d.py) - so the copy of the skip tensor behind the producer's columns disappears; the
+# MOMENTS of the two halves still meet in one buffer (8 bytes per strip and column).  VCX_CAT_SPLIT=0: the round-4 concat buffer (A/B runs).
+CAT_SPLIT = os.environ.get("VCX_CAT_SPLIT", "1") != "0"
+
+
 class CatTarget:
     """Where the last layer of a block writes when its output is the LEFT part of the next block's channel concat: `data`
-    [M, ld] fp16 (columns [0, c_left) are this block's output, the skip tensor is copied behind them) and, when the shapes allow
-    it, `moments` [M / 64, ld, 2] fp32 for the column moments of those columns."""
-    __slots__ = ("data", "moments", "ld", "c_left")
+    [M, data_ld] fp16 (columns [0, c_left) are this block's output; data_ld = ld = c_left + c_right with the skip tensor copied
+    behind them, or - `split` - data_ld = c_left: a plain tensor, the skip stays where it is) and, when the shapes allow it,
+    `moments` [M / 64, ld, 2] fp32 for the column moments of those columns."""
+    __slots__ = ("data", "moments", "ld", "c_left", "data_ld", "split")
 
-    def __init__(self, M, c_left, c_right, device, with_moments):
+    def __init__(self, M, c_left, c_right, device, with_moments, split=False):
         self.c_left = c_left
         self.ld = c_left + c_right
-        self.data = torch.empty((M, self.ld), dtype=torch.float16, device=device)
+        self.split = bool(split and with_moments)
+        self.data_ld = c_left if self.split else self.ld
+        self.data = torch.empty((M, self.data_ld), dtype=torch.float16, device=device)
         self.moments = torch.empty((M // 64, self.ld, 2), dtype=torch.float32, device=device) if with_moments else None
 
     def kwargs(self, k, in_rows):
@@ -35,7 +45,7 @@ class CatTarget:
         buffer is dropped and the consumer makes its statistics pass."""
         if self.moments is not None and (k % 64 != 0 or 2 * in_rows * k >= 0xFFFF0000 or ops.tune_get("GEMM_DMA") == 0):
             self.moments = None
-        kw = dict(out=self.data, ldc=self.ld)
+        kw = dict(out=self.data, ldc=self.data_ld)
         if self.moments is not None:
             kw.update(colstats=self.moments, colstats_ld=self.ld, colstats_col=0)
         return kw

@@ -21,7 +21,11 @@ from torch import nn
 from .... import ops
 from ....packing import pack_conv
 from ..attention import PackedModule, SpatialTransformer, TemporalTransformer, _f16, _f32
-from ..flow import GN_EPILOGUE_STATS, GN_STATS_LEVEL, CatTarget, Flow, out_kwargs as _out_kwargs
+from ..flow import CAT_SPLIT, GN_EPILOGUE_STATS, GN_STATS_LEVEL, CatTarget, Flow, out_kwargs as _out_kwargs
+
+# A ResBlock's 1x1 skip convolution as a K tail of its second 3x3 convolution (round 6, include/vcx.h tail_a0 / tail_a1).  VCX_SKIP_FOLD=0: the
+# separate convolution + residual of rounds 1-5 (A/B runs; also switches the split concat off, which needs the fold).
+SKIP_FOLD = os.environ.get("VCX_SKIP_FOLD", "1") != "0"
 
 class TimestepBlock(nn.Module):
     """Marker: modules whose forward takes the timestep embedding (reference openaimodel3d.py:19-28)."""
@@ -31,8 +35,9 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """Reference openaimodel3d.py:30-48: routes (emb | context | 5-D view) to each child by type.
     x is channels-last [n = b*t, H, W, C]."""
 
-    def forward(self, x, emb, context=None, batch_size=None, cfg_repeat=1, flow=None):
-        """cfg_repeat = r > 1 (only for a block that holds the first SpatialTransformer of the graph): the input is one copy
+    def forward(self, x, emb, context=None, batch_size=None, cfg_repeat=1, flow=None, x2=None):
+        """x2: the skip half of a channel concat [x | x2] that the first layer (a ResBlock) reads in place (lvdm/modules/flow.py).
+        cfg_repeat = r > 1 (only for a block that holds the first SpatialTransformer of the graph): the input is one copy
         of an r-fold replicated batch; the transformer replicates it where the conditionings start to differ and the
         layers after it see batch_size * r videos.  flow (Flow): moments of x in, moments of the result out, and the concat
         target of the last layer; with a target the returned tensor is a strided view of its left columns."""
@@ -47,7 +52,7 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 want = isinstance(layer, ResBlock) and isinstance(nxt, SpatialTransformer)
             target = flow.target if (last and flow is not None) else None
             if isinstance(layer, ResBlock):
-                x, colstats = layer(x, emb, batch_size=batch_size, want_colstats=want, colstats=colstats, target=target)
+                x, colstats = layer(x, emb, batch_size=batch_size, want_colstats=want, colstats=colstats, target=target, x2=x2 if i == 0 else None)
             elif isinstance(layer, SpatialTransformer):
                 x, colstats = layer(x, context_kv=context[id(layer)], frames_per_video=x.shape[0] // batch_size, cfg_repeat=cfg_repeat,
                                     colstats=colstats, want_colstats=want and GN_STATS_LEVEL >= 2)
@@ -68,9 +73,9 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 # a last layer that cannot write into a concat target (a SpatialTransformer in a graph without temporal attention, a
                 # bare convolution): its result is copied into the target's left columns, and the next norm makes its statistics pass
                 n_, H_, W_, C_ = x.shape
-                ops.copy2d(x.reshape(n_ * H_ * W_, C_), target.data, n_ * H_ * W_, C_, C_, target.ld)
+                ops.copy2d(x.reshape(n_ * H_ * W_, C_), target.data, n_ * H_ * W_, C_, C_, target.data_ld)
                 target.moments, colstats = None, None
-                x = target.data.view(n_, H_, W_, target.ld)
+                x = target.data.view(n_, H_, W_, target.data_ld)
         if flow is not None:
             flow.colstats = colstats
         if flow is not None and flow.target is not None:      # x is the whole concat buffer: hand back the block's own columns
@@ -234,10 +239,17 @@ class ResBlock(PackedModule, TimestepBlock):
         if not isinstance(self.skip_connection, nn.Identity):
             pk["ws"] = _f16(pack_conv(self.skip_connection.weight.detach()))
             pk["bs"] = _f32(self.skip_connection.bias)
+            # the 1x1 skip convolution as a K tail of the second 3x3 convolution (include/vcx.h tail_a0 / tail_a1): its weight columns behind
+            # that convolution's, the two biases summed - `return self.skip_connection(x) + h` (reference openaimodel3d.py:228-235) in one
+            # launch: neither the skip tensor nor its re-read as a residual exist, and the matrix work runs at the long-K rate
+            pk["w2s"] = torch.cat([pk["w2"], pk["ws"]], dim=1).contiguous()
+            pk["b2s"] = (pk["b2"] + pk["bs"]).contiguous()
         return pk
 
-    def forward(self, x, emb, batch_size=None, want_colstats=False, colstats=None, target=None):
-        """x [n, H, W, Cin] fp16; emb = SiLU(time+fs embedding) as fp16 [B, emb_channels] (one row per video: the
+    def forward(self, x, emb, batch_size=None, want_colstats=False, colstats=None, target=None, x2=None):
+        """x2 [n, H, W, C2]: the input is the channel concat [x | x2] (up path: h and the skip, reference openaimodel3d.py:596), read in place
+        where the kernels can (statistics from `colstats`, the skip convolution folded: SKIP_FOLD) and materialised otherwise.
+        x [n, H, W, Cin] fp16; emb = SiLU(time+fs embedding) as fp16 [B, emb_channels] (one row per video: the
         reference repeats it over the T frames, openaimodel3d.py:563).  colstats: column moments of x (the in_layers norm then
         needs no statistics pass); want_colstats: produce the moments of the output for a per-frame GroupNorm behind this block
         (SpatialTransformer.norm, the next block's in_layers); target: write output and moments into a concat buffer.
@@ -246,13 +258,20 @@ class ResBlock(PackedModule, TimestepBlock):
         pk = self.packed()
         cout = self.out_channels
         B = emb.shape[0]
+        M = n * H * W
+        tail_ks = [cin] if x2 is None else [cin, x2.shape[-1]]
+        fold_skip = SKIP_FOLD and "ws" in pk and ops.conv_tail_ok(M, cout, cout, 9, tail_ks)
+        if x2 is not None and not (fold_skip and colstats is not None and cin % 8 == 0 and x.is_contiguous() and x2.is_contiguous()):
+            x, x2 = ops.concat_channels(x.reshape(M, cin), x2.reshape(M, x2.shape[-1])).view(n, H, W, -1), None      # the materialised concat
+            tail_ks = [x.shape[-1]]
+            fold_skip = SKIP_FOLD and "ws" in pk and ops.conv_tail_ok(M, cout, cout, 9, tail_ks)
+        c1, cin = cin, sum(tail_ks) if x2 is not None else x.shape[-1]
         stats_in = None if colstats is None else ops.group_norm_stats_from_colstats(colstats, n, H * W, cin)
-        a = ops.group_norm(x.view(n, H * W, cin), *pk["g1"], True, stats=stats_in)
+        a = ops.group_norm(x.view(n, H * W, c1 if x2 is not None else cin), *pk["g1"], True, stats=stats_in, x2=None if x2 is None else x2.view(n, H * W, -1))
         emb_out = ops.linear(emb, pk["we"], pk["be"], out_f32=True)                           # [B, Cout] fp32
         # The norms behind this block's own convolutions take their statistics from those convolutions' epilogues (column moments
         # per 64-row strip, VCX_GEMM_COLSTATS) instead of a pass over the tensor: out_layers' norm (per frame) from conv 1, the
         # first norm of the temporal block (per video) from conv 2 - where frames are whole strips (not at 9x16 = 144 pixels).
-        M = n * H * W
         cs1 = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and ops.colstats_ok(M, H * W, cin, cout)) else None
         if not self.use_scale_shift_norm:
             h = ops.conv2d(a.view(n, H, W, cin), pk["w1"], pk["b1"], kh=3, kw=3, rowadd=emb_out, rowadd_div=(n // B) * H * W, colstats=cs1)
@@ -270,15 +289,17 @@ class ResBlock(PackedModule, TimestepBlock):
                 sc1 = 1.0 + emb_out[v, :cout]
                 ops.group_norm(h3[v * fpv:(v + 1) * fpv], (gam * sc1).contiguous(), (bet * sc1 + emb_out[v, cout:]).contiguous(), eps, True,
                                stats=None if stats is None else stats[v * fpv:(v + 1) * fpv], out=a[v * fpv:(v + 1) * fpv])
-        if "ws" in pk:
-            skip = ops.conv2d(x, pk["ws"], pk["bs"], kh=1, kw=1).view(n * H * W, cout)
+        if fold_skip:       # skip_connection(x) rides in the K loop of the second convolution: x (both halves of a split concat) is its K tail
+            w2, b2 = pk["w2s"], pk["b2s"]
+            skip_kw = dict(tail=[x.reshape(M, -1)] + ([] if x2 is None else [x2.reshape(M, -1)]))
         else:
-            skip = x.reshape(n * H * W, cout)
+            w2, b2 = pk["w2"], pk["b2"]
+            skip_kw = dict(residual=ops.conv2d(x, pk["ws"], pk["bs"], kh=1, kw=1).view(M, cout) if "ws" in pk else x.reshape(M, cout))
         temporal = self.use_temporal_conv and batch_size
         if temporal:
             need2 = ops.colstats_ok(M, (n // batch_size) * H * W, cout, cout)
             cs2 = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and need2) else None
-            h = ops.conv2d(a.view(n, H, W, cout), pk["w2"], pk["b2"], kh=3, kw=3, residual=skip, colstats=cs2)
+            h = ops.conv2d(a.view(n, H, W, cout), w2, b2, kh=3, kw=3, colstats=cs2, **skip_kw)
             h, cs_out = self.temopral_conv(h.view(batch_size, n // batch_size, H * W, cout), colstats=cs2, want_colstats=want_colstats,
                                            target=target)
             return h.view(n, H, W, -1), cs_out
@@ -288,7 +309,7 @@ class ResBlock(PackedModule, TimestepBlock):
         else:
             cs_out = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and want_colstats and ops.colstats_ok(M, H * W, cout, cout)) else None
             kw = {} if cs_out is None else dict(colstats=cs_out)
-        h = ops.conv2d(a.view(n, H, W, cout), pk["w2"], pk["b2"], kh=3, kw=3, residual=skip, **kw)
+        h = ops.conv2d(a.view(n, H, W, cout), w2, b2, kh=3, kw=3, **skip_kw, **kw)
         return h, cs_out
 
 
@@ -588,7 +609,7 @@ class UNetModel(PackedModule):
                 skip, skip_cs = hs[-1]
                 M_ = n_ * H_ * W_
                 ok = skip_cs is not None and ops.colstats_ok(M_, H_ * W_, 64, c_left + skip.shape[-1])
-                return CatTarget(M_, c_left, skip.shape[-1], device, with_moments=ok)
+                return CatTarget(M_, c_left, skip.shape[-1], device, with_moments=ok, split=CAT_SPLIT and SKIP_FOLD and c_left % 64 == 0 and skip.shape[-1] % 64 == 0)
             n, H, W, _ = h.shape
             tgt = target_for(n, H, W, _out_channels_of(self.middle_block))
             flow = Flow(colstats=cs, target=tgt)
@@ -597,17 +618,19 @@ class UNetModel(PackedModule):
                 skip, skip_cs = hs.pop()
                 n, H, W, c1 = h.shape
                 M, c2 = n * H * W, skip.shape[-1]
-                ops.copy2d(skip.view(M, c2), tgt.data[:, c1:], M, c2, c2, tgt.ld)
+                if not tgt.split:
+                    ops.copy2d(skip.view(M, c2), tgt.data[:, c1:], M, c2, c2, tgt.ld)
                 if tgt.moments is not None:      # the skip's moments behind the producer's: 8 bytes per (strip, column), as fp16 quads
                     ops.copy2d(skip_cs.view(torch.float16).view(M // 64, c2 * 4), tgt.moments.view(torch.float16).view(M // 64, tgt.ld * 4)[:, c1 * 4:],
                                M // 64, c2 * 4, c2 * 4, tgt.ld * 4)
-                hcat, cat_cs = tgt.data.view(n, H, W, tgt.ld), tgt.moments
+                hcat, cat_cs = tgt.data.view(n, H, W, tgt.data_ld), tgt.moments
+                x2 = skip if tgt.split else None          # split: the ResBlock reads [h | skip] in place
                 tgt = None
                 if j + 1 < len(self.output_blocks):
                     up = 2 if isinstance(list(module)[-1], Upsample) else 1
                     tgt = target_for(n, H * up, W * up, _out_channels_of(module))
                 flow = Flow(colstats=cat_cs, want=tgt is None, target=tgt)
-                h = module(hcat, emb, context=ckv, batch_size=b, flow=flow)
+                h = module(hcat, emb, context=ckv, batch_size=b, flow=flow, x2=x2)
             cs = flow.colstats
         n, H, W, c = h.shape
         stats = None if cs is None else ops.group_norm_stats_from_colstats(cs, n, H * W, c)

@@ -57,14 +57,16 @@ def require_gpu():
 # ------------------------------------------------------------------------------------------
 def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, residual=None, ldr=None, rowadd=None,
          rowadd_div=0, geglu=False, out_f32=False, alpha=1.0, conv=None, ldw=None, ln_stats=None, ln_colsum=None, ln_t=False, colstats=None,
-         colstats_ld=None, colstats_col=0, rowstats=None, rowstats_eps=1e-5):
+         colstats_ld=None, colstats_col=0, rowstats=None, rowstats_eps=1e-5, tail=None):
     """out[M, N] = epilogue(alpha * X W^T); see include/vcx.h.  `conv` = dict(in_h, in_w, out_h, out_w, cin, kh, kw,
     stride, pad_h, pad_w, ups) switches X to the im2col gather of a channels-last image.  `ln_stats` (from row_stats) +
     `ln_colsum` select the folded-LayerNorm epilogue (VCX_GEMM_LNFOLD; `ln_t`: the normalised rows are the W operand).
     `colstats` (fp32 [M / 64, N, 2], see colstats_buffer) makes the layer write the column moments of its output for the
     GroupNorm behind it (VCX_GEMM_COLSTATS); with `colstats_ld` / `colstats_col` the buffer is [M / 64, colstats_ld, 2] and this
     call fills the columns [colstats_col, colstats_col + N) - the moments of a tensor that is one part of a channel concat.
-    `rowstats` (fp32 [M, 2], see rowstats_ok) makes the layer write LayerNorm's (mean, rstd) of its output rows (VCX_GEMM_ROWSTATS)."""
+    `rowstats` (fp32 [M, 2], see rowstats_ok) makes the layer write LayerNorm's (mean, rstd) of its output rows (VCX_GEMM_ROWSTATS).
+    `tail` (convolutions): one or two fp16 tensors [M, k_j] whose rows are the last sum(k_j) K columns of the problem - K then counts
+    them (include/vcx.h tail_a0 / tail_a1; see conv_tail_ok)."""
     n_out = N // 2 if geglu else N
     _dev16(a, w, residual)
     _dev32(bias, rowadd)
@@ -109,6 +111,17 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
             raise VcxError(f"rowstats must hold [M = {M}, 2] floats, got {tuple(rowstats.shape)}")
         d.rowstats, d.rowstats_eps = rowstats.data_ptr(), float(rowstats_eps)
         flags |= GEMM_ROWSTATS
+    if tail:
+        if conv is None or len(tail) > 2:
+            raise VcxError("gemm: a K tail belongs to a convolution and has one or two sources")
+        _dev16(*tail)
+        for j, t in enumerate(tail):
+            if t.dim() != 2 or t.shape[0] != M or t.stride(1) != 1:
+                raise VcxError(f"gemm: tail source {j} must be [M = {M}, k] with unit column stride, got {tuple(t.shape)}")
+            if j == 0:
+                d.tail_a0, d.tail_lda0, d.tail_k0 = t.data_ptr(), t.stride(0), t.shape[1]
+            else:
+                d.tail_a1, d.tail_lda1, d.tail_k1 = t.data_ptr(), t.stride(0), t.shape[1]
     d.lda, d.M, d.N, d.K = lda, M, N, K
     d.ldw = ldw if ldw is not None else K
     d.ldc = ldc
@@ -204,8 +217,19 @@ def conv2d(x, w, bias, *, kh, kw, stride=1, pad_h=None, pad_w=None, ups=0, out_h
     cout = w.shape[0]
     geom = dict(in_h=H, in_w=W, out_h=Ho, out_w=Wo, cin=cin, kh=kh, kw=kw, stride=stride, pad_h=pad_h, pad_w=pad_w,
                 ups=ups)
-    out = gemm(x, w, M=n * Ho * Wo, N=cout, K=kh * kw * cin, lda=x.stride(2), bias=bias, conv=geom, **kwargs)
+    tail_k = sum(t.shape[1] for t in kwargs.get("tail") or ())
+    out = gemm(x, w, M=n * Ho * Wo, N=cout, K=kh * kw * cin + tail_k, lda=x.stride(2), bias=bias, conv=geom, **kwargs)
     return out.view(n, Ho, Wo, -1)
+
+
+def conv_tail_ok(M, cin, cout, taps, tail_ks, in_rows=None):
+    """Will vcx_gemm_f16 take a convolution over a cin-channel image with a K tail of widths tail_ks (the 1x1 skip convolution of a
+    ResBlock folded into its second convolution)?  The DMA kernel only: a mirror of `dma_ok` in csrc/gemm.hip."""
+    lim = 0xFFFF0000
+    K = taps * cin + sum(tail_ks)
+    return (tune_get("GEMM_DMA") != 0 and cin % 64 == 0 and cout % 8 == 0 and all(k % 64 == 0 and k > 0 for k in tail_ks) and 0 < len(tail_ks) <= 2
+            and 2 * (in_rows if in_rows is not None else M) * cin < lim and 2 * (cout - 1) * K + 2 * K < lim and 2 * (M + 256) * cout < lim
+            and all(2 * M * k < lim for k in tail_ks))
 
 
 def temporal_conv3(x, w, bias, **kwargs):
@@ -275,9 +299,12 @@ def group_norm_fold_linear(w32, bias, gamma, beta, stats, eps, groups=32):
     return wn, bn
 
 
-def group_norm(x, gamma, beta, eps, silu, groups=32, out=None, stats=None):
+def group_norm(x, gamma, beta, eps, silu, groups=32, out=None, stats=None, x2=None):
     """x [n_outer, pixels, C] fp16 (contiguous).  Statistics over (pixels, C/groups) - computed here, or handed in (`stats`
-    [n_outer, groups, 2] = (mean, variance), from group_norm_stats_from_colstats)."""
+    [n_outer, groups, 2] = (mean, variance), from group_norm_stats_from_colstats).  x2 [n_outer, pixels, C2]: the norm runs over the
+    channel concat [x | x2] without materialising it (vcx_groupnorm_apply2_f16; `stats` required)."""
+    if x2 is not None:
+        return _group_norm2(x, x2, gamma, beta, eps, silu, groups, out, stats)
     n_outer, pixels, C = x.shape
     _dev16(x, out)
     _dev32(gamma, beta)
@@ -293,6 +320,20 @@ def group_norm(x, gamma, beta, eps, silu, groups=32, out=None, stats=None):
         out = torch.empty_like(x)
     check(L.vcx_groupnorm_apply_f16(x.data_ptr(), out.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                     n_outer, pixels, C, groups, eps, 1 if silu else 0, s), "groupnorm_apply")
+    return out
+
+
+def _group_norm2(x1, x2, gamma, beta, eps, silu, groups, out, stats):
+    n_outer, pixels, c1 = x1.shape
+    C = c1 + x2.shape[2]
+    _dev16(x1, x2, out)
+    _dev32(gamma, beta, stats)
+    if stats is None or tuple(x2.shape[:2]) != (n_outer, pixels) or c1 % 8 != 0 or not x1.is_contiguous() or not x2.is_contiguous():
+        raise VcxError(f"group_norm over a split concat needs statistics, contiguous halves and c1 % 8 == 0 (x1 {tuple(x1.shape)}, x2 {tuple(x2.shape)})")
+    if out is None:
+        out = torch.empty((n_outer, pixels, C), dtype=_f16, device=x1.device)
+    check(lib().vcx_groupnorm_apply2_f16(x1.data_ptr(), c1, x2.data_ptr(), out.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                         n_outer, pixels, C, groups, eps, 1 if silu else 0, _stream()), "groupnorm_apply2")
     return out
 
 
