@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B builds of libvcx.so with one compile-time switch changed (git-ignored, tools/_abl/): same sources, same flags, same ABI.
-#   tools/build_abl.sh gelu_select -DVCX_GELU_SELECT_TAIL      -> tools/_abl/libvcx_gelu_select.so
+#   tools/build_abl.sh gnold -DVCX_GN_TWO_PHASE      -> tools/_abl/libvcx_gnold.so     (the switches: csrc/vcx_ablate.h)
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../viewcrafter_amd/csrc"

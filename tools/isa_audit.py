@@ -250,6 +250,24 @@ def agpr_ownership(listing):
     return found
 
 
+# Kernels whose hand-written vector-memory wait counts ASSUME how many stores the compiled epilogue of a tile issues (gemm_ws320_kernel:
+# `S = 12`, 22 with column moments - gemm_ws.hip; a compiler that split or merged those stores would leave DMA pieces in flight behind
+# the wait and the MFMAs would read a stale LDS stage - ADVICE r5): kernel name fragment -> vector-memory stores in the whole kernel body.
+STORE_COUNTS = {"gemm_ws320_kernelILi2E": 12, "gemm_ws320_kernelILi3E": 22}
+
+
+def assumed_store_counts(listing):
+    found = []
+    for frag, want in STORE_COUNTS.items():
+        m = re.search(r"^(_Z\w*" + frag + r"\w*):[^\n]*\n(.*?)^\.Lfunc_end", listing, re.S | re.M)
+        if not m:
+            continue
+        n = len(re.findall(r"^\s*(?:buffer|global|flat)_store_", m.group(2), re.M))
+        if n != want:
+            found.append((m.group(1), "", f"{n} vector-memory stores in the kernel, its vmcnt immediates assume {want} per tile", 0))
+    return found
+
+
 def audit_library_store_hazards():
     out = []
     with tempfile.TemporaryDirectory(prefix="vcx_isa_") as tmpdir:
@@ -262,6 +280,7 @@ def audit_library_store_hazards():
                 raise RuntimeError("hipcc failed on " + name + ":\n" + r.stderr[-2000:])
             out += [(name,) + h for h in store_data_hazards(open(tmp).read())]
             out += [(name,) + h for h in agpr_ownership(open(tmp).read())]
+            out += [(name,) + h for h in assumed_store_counts(open(tmp).read())]
     return out
 
 

@@ -557,9 +557,7 @@ __device__ __forceinline__ void row_halves(float x, float& lo, float& hi) {
     hi = __builtin_bit_cast(float, r1);
 }
 
-#ifndef XABL
-#define XABL 0        // timing-only ablations (tools/xattn_ablate.py; garbage results): 1 no exp2, 2 no softmax arithmetic at all, 4 no MFMAs, 8 no Q loads / O stores, 16 no fragment reads in the loop, 32 no max / rescale branch
-#endif
+// (XABL: timing-only ablation bits of this kernel, 0 in the product - vcx_ablate.h)
 __global__ void __launch_bounds__(512, 1) xattn_resident2_d64_kernel(XAttnArgs p, unsigned q_bytes, unsigned o_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int T1 = 2, T2 = 4, NT = T1 + T2;

@@ -53,18 +53,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 // scipy's erfc; beyond 9 the tail is < 1e-19 and |x| is clamped): evaluated in fp32, max |gelu error| is 3.7e-7 over EVERY finite
 // fp16 input and the fp16 result is within one unit in the last place of the correctly rounded value everywhere
 // (tests/test_kernels_gpu.py::test_gelu_every_fp16_input...) - the accuracy of the Abramowitz-Stegun 7.1.26 form used in rounds
-// 1-2 (4.5e-7), with ONE transcendental (v_exp) instead of two (v_rcp + v_exp), 10 instead of 14 VALU operations and no
+// 1-2 (4.5e-7; the A/B builds of rounds 3-5 - that form, the compare / select tail, other panel heights of the tile walk - are in the
+// history: commit e530759 and before), with ONE transcendental (v_exp) instead of two (v_rcp + v_exp), 10 instead of 14 VALU operations and no
 // reciprocal at the head of the dependent chain.  The GEGLU epilogue runs this once per output element and was 28 % of the
 // level-0 GEGLU layer (profiles/r02_experiments.md section 9); same-box effect: GEGLU layers -4 ... -6 % (profiles/r03_experiments.md).
-#ifdef VCX_GELU_AS7126      // the round 1-2 form, kept for the A/B build of tools/gelu_ab.py only
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
-}
-#else
 // in pieces, so that a caller can spread them over several MFMA shadows (gemm_ws320_geglu_kernel); gelu_erf() below is their
 // composition - ONE definition of the arithmetic
 constexpr float GELU_Q[7] = {3.3093042e-05f, -7.6922239e-04f, 8.0807274e-03f, -5.3412125e-02f, -4.5877096e-01f, -1.1512017e+00f, -9.9999309e-01f};
@@ -72,14 +64,10 @@ template <int I>
 __device__ __forceinline__ float gelu_q_step(float q, float a) { return __builtin_fmaf(q, a, GELU_Q[I]); }       // Horner step I = 1 .. 6, q0 = GELU_Q[0]
 __device__ __forceinline__ float gelu_clamp(float x) { return fminf(fabsf(x), 9.0f); }
 __device__ __forceinline__ float gelu_finish(float x, float a, float mx, float e) {       // e = exp2(q6) = Phi(-|x|), mx = max(x, 0)
-#ifdef VCX_GELU_SELECT_TAIL       // the round 3-4 tail, kept for the A/B build of tools/step_ab.py only (tools/_abl/libvcx_gelu_select.so)
-    return x * (x > 0.f ? 1.0f - e : e);
-#else
     // x Phi(x) = max(x, 0) - |x| Phi(-|x|): one max and one multiply-add instead of subtract / compare / select / multiply - three
     // VALU issue slots fewer per GEGLU output and one rounding instead of two (max error over every fp16 input 2.8e-7 against
     // 3.7e-7, still within one fp16 unit in the last place everywhere).  The clamped |x| serves: beyond 9 the product is < 1e-17.
     return __builtin_fmaf(-a, e, mx);
-#endif
 }
 __device__ __forceinline__ void gelu_erf_head(float x, float& a, float& mx, float& q) {
     a = gelu_clamp(x);
@@ -95,7 +83,6 @@ __device__ __forceinline__ float gelu_erf(float x) {
     gelu_erf_head(x, a, mx, q);
     return gelu_erf_tail(x, a, mx, q);
 }
-#endif
 
 
 // XCD-aware persistent tile walk: tile ids congruent mod 8 form a contiguous band of (tile_m, tile_n).
@@ -112,19 +99,6 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
         tm = vid / tiles_n;
         return;
     }
-#ifdef VCX_TILE_PANEL      // tools/panel_ab.py only: other panel heights, built into tools/_abl/ (the product code below is untouched)
-    constexpr int PNL = VCX_TILE_PANEL;
-    const int tiles_m = ntiles / tiles_n, full = tiles_m / PNL, split = full * PNL * tiles_n;
-    if (vid < split) {
-        const int pnl = vid / (PNL * tiles_n), r = vid - pnl * PNL * tiles_n;
-        tn = r / PNL;
-        tm = pnl * PNL + r % PNL;
-    } else {
-        const int rem = tiles_m - full * PNL, r = vid - split;
-        tn = r / rem;
-        tm = full * PNL + r % rem;
-    }
-#else
     const int tiles_m = ntiles / tiles_n, full = tiles_m >> 3, split = full * 8 * tiles_n;
     if (vid < split) {
         const int pnl = vid / (8 * tiles_n), r = vid - pnl * 8 * tiles_n;
@@ -135,7 +109,6 @@ __device__ __forceinline__ void tile_coords(int t, int ntiles, int tiles_n, int&
         tn = r / rem;
         tm = full * 8 + r % rem;
     }
-#endif
 }
 
 int persistent_grid(int ntiles, int blocks_per_cu = 2);

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
         // two oldest stores to be acknowledged here costs their full write latency in every iteration.
         __builtin_amdgcn_sched_barrier(0);
         {
-#if defined(VCX_WS_ABL) && VCX_WS_ABL == 2
+#if VCX_WS_ABL == 2
             constexpr int S = 0;
 #else
             constexpr int S = LNF == 3 ? 22 : 12;
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
         h8 xf[MF], xn[MF];
 #pragma unroll
         for (int b = 0; b < MF; ++b) xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(b * 16 + lr, lg));
-#if defined(VCX_WS_ABL) && VCX_WS_ABL == 1        // tools/ws_ablate.py: no MFMA work (timing only)
+#if VCX_WS_ABL == 1        // tools/ws_ablate.py: no MFMA work (timing only)
         for (int kk = 0; kk < 0; ++kk) {
 #else
 #pragma unroll
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
 #pragma unroll
             for (int b = 0; b < MF; ++b) xf[b] = xn[b];
         }
-#if defined(VCX_WS_ABL) && VCX_WS_ABL == 2        // tools/ws_ablate.py: no epilogue (timing only; one store keeps the MFMAs alive)
+#if VCX_WS_ABL == 2        // tools/ws_ablate.py: no epilogue (timing only; one store keeps the MFMAs alive)
         if (acc[0][0][0] == 12345.678f) *reinterpret_cast<float*>(p.C) = acc[1][1][1] + acc[4][3][2];
 #else
         {
@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_geglu_kernel(Gem
         constexpr bool PEND = decltype(PEND_)::value != 0;
         const int buf = i % WG_RING;
         __builtin_amdgcn_sched_barrier(0);
-#if !(defined(VCX_WG_ABL) && (VCX_WG_ABL & 4))        // timing-only ablations (tools/ws_geglu_scan.py): 1 no epilogue chunks, 2 no MFMAs, 4 no per-tile barrier / wait
+#if !(VCX_WG_ABL & 4)        // timing-only ablations (tools/ws_geglu_scan.py): 1 no epilogue chunks, 2 no MFMAs, 4 no per-tile barrier / wait
         ws_wait_vmcnt(issued - mark[buf]);
         __builtin_amdgcn_s_barrier();
 #endif
@@ -857,7 +857,7 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_geglu_kernel(Gem
             static_for_ws<4>([&](auto J_) __attribute__((always_inline)) {
                 constexpr int j = decltype(J_)::value, ab = j & 1, mb = j >> 1, n = 4 * kk + j;
                 __builtin_amdgcn_sched_barrier(0);
-#if defined(VCX_WG_ABL) && (VCX_WG_ABL & 2)
+#if VCX_WG_ABL & 2
                 if constexpr (kk == 0) acc[PAR][ab][mb] = binit[ab]; else acc[PAR][ab][mb][n & 15] += (float)xr[kk % XR][mb][0] * (float)xr[kk % XR][mb][1];
 #else
                 if constexpr (kk == 0) wg_mfma_first<WG_KS * ab>(acc[PAR][ab][mb], xr[kk % XR][mb], binit[ab]);
@@ -865,7 +865,7 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_geglu_kernel(Gem
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ab == 1 && kk + XR < WG_KS) xr[kk % XR][mb] = frag(kk + XR, mb);
-#if defined(VCX_WG_ABL) && (VCX_WG_ABL & 1)
+#if VCX_WG_ABL & 1
                 if constexpr (PEND && n >= 6 && n < 74 && (n - 6) % 34 >= 32) chunk(WInt<PAR ^ 1>{}, WInt<n - 6>{});
 #else
                 if constexpr (PEND && n >= 6 && n < 74) chunk(WInt<PAR ^ 1>{}, WInt<n - 6>{});
@@ -1184,7 +1184,7 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_lnf_kernel(GemmA
             const auto s0 = __builtin_amdgcn_permlane32_swap(pk[mb][2 * k][0], pk[mb][2 * k + 1][0], false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(pk[mb][2 * k][1], pk[mb][2 * k + 1][1], false, false);
             const epi_u4v w = {s0[0], s1[0], s0[1], s1[1]};
-#if !(defined(VCX_WL_ABL) && (VCX_WL_ABL & 8))
+#if !(VCX_WL_ABL & 8)
             __builtin_amdgcn_raw_buffer_store_b128(w, srd_c, coff[PAR][mb], ab * 64 + k * 32, 0);
 #endif
             asm volatile("s_nop 1" : : "v"(w));          // (the wide-store rule of tools/isa_audit.py)
@@ -1239,7 +1239,7 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_lnf_kernel(GemmA
             static_for_ws<4>([&](auto J_) __attribute__((always_inline)) {
                 constexpr int j = decltype(J_)::value, ab = j & 1, mb = j >> 1, n = 4 * kk + j;
                 __builtin_amdgcn_sched_barrier(0);
-#if defined(VCX_WL_ABL) && (VCX_WL_ABL & 2)
+#if VCX_WL_ABL & 2
                 if constexpr (kk == 0) acc[PAR][ab][mb] = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; else acc[PAR][ab][mb][n & 15] += (float)xr[kk % XR][mb][0] * (float)xr[kk % XR][mb][1];
 #else
                 if constexpr (kk == 0) wl_mfma_zero<WG_KS * ab>(acc[PAR][ab][mb], xr[kk % XR][mb]);
@@ -1247,7 +1247,7 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_lnf_kernel(GemmA
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ab == 1 && kk + XR < WG_KS) xr[kk % XR][mb] = frag(kk + XR, mb);
-#if defined(VCX_WL_ABL) && (VCX_WL_ABL & 1)        // timing-only builds (tools/ws_lnf_ab.py <library>): 1 no arithmetic chunks, 2 no MFMAs, 8 no stores
+#if VCX_WL_ABL & 1        // timing-only builds (tools/ws_lnf_ab.py <library>): 1 no arithmetic chunks, 2 no MFMAs, 8 no stores
                 if constexpr (PEND && n >= 6 && n < 46 && (n - 6) % 20 >= 16) chunk(WInt<PAR ^ 1>{}, WInt<n - 6>{});
 #else
                 if constexpr (PEND && n >= 6 && n < 46) chunk(WInt<PAR ^ 1>{}, WInt<n - 6>{});

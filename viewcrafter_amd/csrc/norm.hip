@@ -597,14 +597,8 @@ static int gn_apply_launch(const void* x, const void* x2, int c1, void* y, const
     // The apply pass has no reduction, so its block size is free (the statistics kernels' is not - it fixes their summation order).
     // Many small blocks win: 32 pixels per block (16 for wide rows) = one or two 4-deep batches of 16-byte loads per thread, against
     // the statistics kernel's >= 128 that round 1-3 used here too: -12 % over the apply passes of a step, 5.8 TB/s on the level-0
-    // tensors (profiles/r04k_gn_apply_ppb_*.txt; larger blocks lose badly: 512 pixels +37 %).  In a -DVCX_EXPERIMENT_KNOBS build
-    // knob EXP0 overrides it: n > 0 = n pixels per block, -1 = the old rule (the A/B runs of that record).
-    int64_t ppb = C <= 640 ? 32 : 16;
-#ifdef VCX_EXPERIMENT_KNOBS      // tools/gn_apply_ppb.py / gn_apply_ab.sh builds only: the product reads no scratch knob on a launch path
-    const int exp_ppb = vcx_tune(VCX_TUNE_EXP0);
-    if (exp_ppb > 0) ppb = exp_ppb;
-    else if (exp_ppb == -1) ppb = pick_pix_per_block(n_outer, pixels);
-#endif
+    // tensors (profiles/r04k_gn_apply_ppb_*.txt; larger blocks lose badly: 512 pixels +37 %).
+    const int64_t ppb = C <= 640 ? 32 : 16;
     dim3 grid((unsigned)((pixels + ppb - 1) / ppb), n_outer);
     int cw, pl;
     gn_geometry(C, cw, pl);

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <atomic>
 #include "../../include/vcx.h"
+#include "vcx_ablate.h"
 
 typedef _Float16 half_t;
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
