@@ -51,6 +51,53 @@ constexpr int WS_RING = 3;
 constexpr size_t WS_STRIP = (size_t)WsCfg::TBN * sizeof(float);
 constexpr size_t WS_SMEM = (size_t)WS_RING * WS_STAGE + 2 * WS_STRIP;
 
+__device__ __forceinline__ void ws_wait_vmcnt(int n) {        // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the count is an immediate)
+    switch (n < 63 ? n : 63) {
+#define VCX_WS_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define VCX_WS_W8(k) VCX_WS_W(k) VCX_WS_W(k + 1) VCX_WS_W(k + 2) VCX_WS_W(k + 3) VCX_WS_W(k + 4) VCX_WS_W(k + 5) VCX_WS_W(k + 6) VCX_WS_W(k + 7)
+        VCX_WS_W8(0) VCX_WS_W8(8) VCX_WS_W8(16) VCX_WS_W8(24) VCX_WS_W8(32) VCX_WS_W8(40) VCX_WS_W8(48) VCX_WS_W8(56)
+#undef VCX_WS_W8
+#undef VCX_WS_W
+    }
+}
+
+template <int I> using WInt = std::integral_constant<int, I>;
+
+// ---- shared by the four kernels of this file (review r5 item 8: one place for the block map, the stream walk and the grid)
+// The block -> (column block cb, row stream) map.  G = gridDim.x / tiles_n row streams of tiles_n column blocks each; a stream walks the
+// row tiles t_first, t_first + G, ...  Block id = 8 slot + xcd (ids are dealt round-robin over the 8 XCDs), slot = tiles_n x (row stream
+// of the XCD) + column block: the column blocks of a stream share an XCD, i.e. its L2 holds the stream's activation tiles.  SPARE: G need
+// not be a multiple of 8 - the last G & 7 streams take the CUs that division leaves over, their blocks spread across XCDs.
+template <bool SPARE>
+__device__ __forceinline__ void ws_block_map(int tiles_n, int& cb, int& G, int& t_first) {
+    G = gridDim.x / tiles_n;
+    const int nb_main = SPARE ? (G >> 3) * 8 * tiles_n : (int)gridDim.x;
+    const int spare = (int)blockIdx.x - nb_main;
+    cb = spare < 0 ? (int)(blockIdx.x >> 3) % tiles_n : spare % tiles_n;
+    t_first = spare < 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) / tiles_n : (G & ~7) + spare / tiles_n;
+}
+// The walk of a row stream by the pipelined kernels: AHEAD + 1 tiles in flight before the first one is consumed, then tiles alternate
+// between the two accumulator sets - tile(set, a finished tile is pending in the other set, t, i) - and last(set, i) finishes the set
+// that holds the stream's final tile.
+template <int AHEAD, class Issue, class Tile, class Last>
+__device__ __forceinline__ void ws_walk(int t_first, int G, int ntiles, Issue&& issue_tile, Tile&& tile, Last&& last) {
+    int t = t_first, i = 0;
+#pragma unroll
+    for (int k = 0; k <= AHEAD; ++k)
+        if (t + k * G < ntiles) issue_tile(t + k * G, k);
+    if (t >= ntiles) return;
+    tile(WInt<0>{}, WInt<0>{}, t, i);
+    t += G; ++i;
+    for (;;) {
+        if (t >= ntiles) { last(WInt<0>{}, i); break; }
+        tile(WInt<1>{}, WInt<1>{}, t, i);
+        t += G; ++i;
+        if (t >= ntiles) { last(WInt<1>{}, i); break; }
+        tile(WInt<0>{}, WInt<1>{}, t, i);
+        t += G; ++i;
+    }
+}
+
 // Serial form, for the epilogues that only gemm_epilogue.h implements.  MODE 2: per-image addend (VCX_GEMM_ROWADD);  MODE 3: column
 // moments (VCX_GEMM_COLSTATS).  The plain modes (bias, residual) run on gemm_ws320_pipe_kernel below.
 template <int MODE>
@@ -63,9 +110,8 @@ __global__ void __launch_bounds__(WsCfg::THREADS, 1) gemm_ws320_kernel(GemmArgs 
 
     const int ntiles = p.tiles_m;
     // block id = 8 slot + xcd (blocks are dealt round-robin over the 8 XCDs); slot = tiles_n * (row stream of the XCD) + column block
-    const int cb = (blockIdx.x >> 3) % p.tiles_n;
-    const int G = gridDim.x / p.tiles_n;                                          // row streams: stream s walks tiles s, s + G, ...
-    const int t_first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) / p.tiles_n;
+    int cb, G, t_first;
+    ws_block_map<false>(p.tiles_n, cb, G, t_first);
     const int ncol0 = cb * WsCfg::TBN;                                            // first output column of the block
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,17 +259,6 @@ constexpr size_t WP_SMEM = (size_t)WP_RING * WP_STAGE;
 constexpr size_t WP_RS_SLOT = (size_t)WpCfg::TBM * 4 * 2 * sizeof(float);
 constexpr size_t WP_SMEM_RS = WP_SMEM + 2 * WP_RS_SLOT;
 
-__device__ __forceinline__ void ws_wait_vmcnt(int n) {        // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the count is an immediate)
-    switch (n < 63 ? n : 63) {
-#define VCX_WS_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-#define VCX_WS_W8(k) VCX_WS_W(k) VCX_WS_W(k + 1) VCX_WS_W(k + 2) VCX_WS_W(k + 3) VCX_WS_W(k + 4) VCX_WS_W(k + 5) VCX_WS_W(k + 6) VCX_WS_W(k + 7)
-        VCX_WS_W8(0) VCX_WS_W8(8) VCX_WS_W8(16) VCX_WS_W8(24) VCX_WS_W8(32) VCX_WS_W8(40) VCX_WS_W8(48) VCX_WS_W8(56)
-#undef VCX_WS_W8
-#undef VCX_WS_W
-    }
-}
-
-template <int I> using WInt = std::integral_constant<int, I>;
 
 // RS (VCX_GEMM_ROWSTATS, round 6): the block owns whole output rows, so it also writes LayerNorm's (mean, rstd) of every ROUNDED output
 // row - the statistics pass in front of the LayerNorm-folded projection behind this layer (vcx_rowstats_f16: one read of the tensor,
@@ -244,9 +279,8 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t srd_s = __builtin_amdgcn_make_buffer_rsrc(p.rowstats, 0, RS ? (int)(8u * (unsigned)p.M) : 0, 0x00020000);
 
     int ntiles = p.tiles_m;
-    const int cb = (blockIdx.x >> 3) % p.tiles_n;
-    int G = gridDim.x / p.tiles_n;
-    int t_first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) / p.tiles_n;
+    int cb, G, t_first;
+    ws_block_map<false>(p.tiles_n, cb, G, t_first);
     if constexpr (!RES) {
         // vcx_gemm_units_f16: one weight / bias set per unit of unit_rows rows (a GroupNorm folded into this projection has one per
         // frame or per video).  gridDim.x / units consecutive blocks share a unit; a block keeps that unit's weights for its
@@ -542,28 +576,7 @@ __global__ void __launch_bounds__(WpCfg::THREADS, 1) gemm_ws320_pipe_kernel(Gemm
         }
     };
 
-    int t = t_first, i = 0;
-#pragma unroll
-    for (int k = 0; k < WP_AHEAD; ++k)
-        if (t + k * G < ntiles) issue_tile(t + k * G, k);
-    if (t < ntiles) {
-        tile(WInt<0>{}, WInt<0>{}, t, i);
-        t += G; ++i;
-        for (;;) {
-            if (t >= ntiles) {
-                finish(WInt<0>{}, i);
-                break;
-            }
-            tile(WInt<1>{}, WInt<1>{}, t, i);
-            t += G; ++i;
-            if (t >= ntiles) {
-                finish(WInt<1>{}, i);
-                break;
-            }
-            tile(WInt<0>{}, WInt<1>{}, t, i);
-            t += G; ++i;
-        }
-    }
+    ws_walk<WP_AHEAD - 1>(t_first, G, ntiles, issue_tile, tile, finish);
 #endif
 }
 
@@ -701,11 +714,8 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_geglu_kernel(Gem
     // G row streams of tiles_n column blocks each: 8 (G >> 3) of them with all their blocks on one XCD (block id = 8 slot + xcd), and G & 7
     // more whose blocks take the CUs that division leaves over, across XCDs (ten column blocks: 3 streams per XCD = 240 blocks + 1
     // stream on the 16 spare CUs; its activation tiles come from the memory side ten times instead of once - 4 % of the rows)
-    const int G = gridDim.x / p.tiles_n;
-    const int nb_main = (G >> 3) * 8 * p.tiles_n;
-    const int spare = (int)blockIdx.x - nb_main;
-    const int cb = spare < 0 ? (int)(blockIdx.x >> 3) % p.tiles_n : spare % p.tiles_n;
-    const int t_first = spare < 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) / p.tiles_n : (G & ~7) + spare / p.tiles_n;
+    int cb, G, t_first;
+    ws_block_map<true>(p.tiles_n, cb, G, t_first);
     const int ncol0 = cb * WgCfg::TBN;                     // first PACKED column (weight row) of the block; its outputs start at ncol0 / 2
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -881,28 +891,7 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_geglu_kernel(Gem
         static_for_ws<68>([&](auto C_) __attribute__((always_inline)) { chunk(PAR_, C_); });
     };
 
-    int t = t_first, i = 0;
-#pragma unroll
-    for (int k = 0; k <= WG_AHEAD; ++k)
-        if (t + k * G < ntiles) issue_tile(t + k * G, k);
-    if (t < ntiles) {
-        tile(WInt<0>{}, WInt<0>{}, t, i);
-        t += G; ++i;
-        for (;;) {
-            if (t >= ntiles) {
-                drain(WInt<0>{});
-                break;
-            }
-            tile(WInt<1>{}, WInt<1>{}, t, i);
-            t += G; ++i;
-            if (t >= ntiles) {
-                drain(WInt<1>{});
-                break;
-            }
-            tile(WInt<0>{}, WInt<1>{}, t, i);
-            t += G; ++i;
-        }
-    }
+    ws_walk<WG_AHEAD>(t_first, G, ntiles, issue_tile, tile, [&](auto PAR_, int) __attribute__((always_inline)) { drain(PAR_); });
 #endif
 }
 
@@ -1074,11 +1063,8 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_lnf_kernel(GemmA
 
     const int ntiles = p.tiles_m;
     // the block -> (row stream, column block) map of gemm_ws320_geglu_kernel, spare-CU streams included
-    const int G = gridDim.x / p.tiles_n;
-    const int nb_main = (G >> 3) * 8 * p.tiles_n;
-    const int spare = (int)blockIdx.x - nb_main;
-    const int cb = spare < 0 ? (int)(blockIdx.x >> 3) % p.tiles_n : spare % p.tiles_n;
-    const int t_first = spare < 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) / p.tiles_n : (G & ~7) + spare / p.tiles_n;
+    int cb, G, t_first;
+    ws_block_map<true>(p.tiles_n, cb, G, t_first);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -1265,46 +1251,31 @@ __global__ void __launch_bounds__(WgCfg::THREADS, 1) gemm_ws320_lnf_kernel(GemmA
         static_for_ws<40>([&](auto C_) __attribute__((always_inline)) { chunk(PAR_, C_); });
     };
 
-    int t = t_first, i = 0;
-#pragma unroll
-    for (int k = 0; k <= WG_AHEAD; ++k)
-        if (t + k * G < ntiles) issue_tile(t + k * G, k);
-    if (t < ntiles) {
-        tile(WInt<0>{}, WInt<0>{}, t, i);
-        t += G; ++i;
-        for (;;) {
-            if (t >= ntiles) {
-                drain(WInt<0>{});
-                break;
-            }
-            tile(WInt<1>{}, WInt<1>{}, t, i);
-            t += G; ++i;
-            if (t >= ntiles) {
-                drain(WInt<1>{});
-                break;
-            }
-            tile(WInt<0>{}, WInt<1>{}, t, i);
-            t += G; ++i;
-        }
-    }
+    ws_walk<WG_AHEAD>(t_first, G, ntiles, issue_tile, tile, [&](auto PAR_, int) __attribute__((always_inline)) { drain(PAR_); });
 #endif
+}
+
+// Blocks of a launch: 8 XCDs x (row streams per XCD) x tiles_n column blocks - fewer streams than the chip has room for when the problem
+// has fewer row tiles - plus, with `spare`, whole streams across XCDs on the CUs that per_xcd / tiles_n leaves over (fewer than 8 of them:
+// ws_block_map<true> reads their number as G & 7; ten column blocks: 250 blocks instead of 240).
+int ws_grid(const GemmArgs& a, bool spare) {
+    const int per_xcd = persistent_grid(1 << 30, 1) / 8;
+    int streams_per_xcd = per_xcd / a.tiles_n;
+    if (streams_per_xcd < 1) streams_per_xcd = 1;
+    const int needed = (a.tiles_m + 7) / 8;
+    int spare_streams = 0;
+    if (spare && streams_per_xcd <= needed && 8 * streams_per_xcd * a.tiles_n < 8 * per_xcd)
+        spare_streams = (8 * per_xcd - 8 * streams_per_xcd * a.tiles_n) / a.tiles_n;
+    if (streams_per_xcd > needed) streams_per_xcd = needed;
+    if (spare_streams > 7) spare_streams = 7;
+    return (8 * streams_per_xcd + spare_streams) * a.tiles_n;
 }
 
 int launch_ws_lnf(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
     auto kern = gemm_ws320_lnf_kernel;
     if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WL_SMEM, "vcx_gemm_f16(ws320 lnfold)")) return VCX_ELAUNCH;
-    const int per_xcd = persistent_grid(1 << 30, 1) / 8;
-    int streams_per_xcd = per_xcd / a.tiles_n;
-    if (streams_per_xcd < 1) streams_per_xcd = 1;
-    const int needed = (a.tiles_m + 7) / 8;
-    int spare_streams = 0;                      // (the block map of launch_ws_geglu)
-    if (streams_per_xcd <= needed && 8 * streams_per_xcd * a.tiles_n < 8 * per_xcd)
-        spare_streams = (8 * per_xcd - 8 * streams_per_xcd * a.tiles_n) / a.tiles_n;
-    if (streams_per_xcd > needed) streams_per_xcd = needed;
-    if (spare_streams > 7) spare_streams = 7;
-    hipLaunchKernelGGL(kern, dim3((8 * streams_per_xcd + spare_streams) * a.tiles_n), dim3(WgCfg::THREADS), WL_SMEM, s, a, a.a_bytes,
-                       (unsigned)(8ull * (unsigned long long)a.M));
+    hipLaunchKernelGGL(kern, dim3(ws_grid(a, true)), dim3(WgCfg::THREADS), WL_SMEM, s, a, a.a_bytes, (unsigned)(8ull * (unsigned long long)a.M));
     return vcx_check_launch("vcx_gemm_f16(ws320 lnfold)");
 }
 
@@ -1312,19 +1283,8 @@ int launch_ws_geglu(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
     auto kern = gemm_ws320_geglu_kernel;
     if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WG_SMEM, "vcx_gemm_f16(ws320 geglu)")) return VCX_ELAUNCH;
-    const int per_xcd = persistent_grid(1 << 30, 1) / 8;
-    int streams_per_xcd = per_xcd / a.tiles_n;
-    if (streams_per_xcd < 1) streams_per_xcd = 1;
-    const int needed = (a.tiles_m + 7) / 8;
-    // the CUs that per_xcd / tiles_n leaves over run whole streams of their own across XCDs (fewer than 8 of them: the kernel reads
-    // their number as G & 7) - at ten column blocks 250 blocks instead of 240; not when the problem has fewer row tiles than streams,
-    // and not under knob GEMM_WS = 3 (the A/B setting of tools/ws_geglu_ab.py: one-XCD streams only)
-    int spare_streams = 0;
-    if (streams_per_xcd <= needed && 8 * streams_per_xcd * a.tiles_n < 8 * per_xcd && vcx_tune(VCX_TUNE_GEMM_WS) != 3)
-        spare_streams = (8 * per_xcd - 8 * streams_per_xcd * a.tiles_n) / a.tiles_n;
-    if (streams_per_xcd > needed) streams_per_xcd = needed;
-    if (spare_streams > 7) spare_streams = 7;
-    hipLaunchKernelGGL(kern, dim3((8 * streams_per_xcd + spare_streams) * a.tiles_n), dim3(WgCfg::THREADS), WG_SMEM, s, a, a.a_bytes);
+    // (no spare-CU streams under knob GEMM_WS = 3: the A/B setting of tools/ws_geglu_ab.py, one-XCD streams only)
+    hipLaunchKernelGGL(kern, dim3(ws_grid(a, vcx_tune(VCX_TUNE_GEMM_WS) != 3)), dim3(WgCfg::THREADS), WG_SMEM, s, a, a.a_bytes);
     return vcx_check_launch("vcx_gemm_f16(ws320 geglu)");
 }
 
@@ -1334,11 +1294,7 @@ int launch_ws_pipe(const GemmArgs& a, hipStream_t s) {
     auto kern = gemm_ws320_pipe_kernel<RES, RS>;
     constexpr size_t smem = RS ? WP_SMEM_RS : WP_SMEM;
     if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)smem, "vcx_gemm_f16(ws320 pipe)")) return VCX_ELAUNCH;
-    const int per_xcd = persistent_grid(1 << 30, 1) / 8;
-    int streams_per_xcd = per_xcd / a.tiles_n;
-    const int needed = (a.tiles_m + 7) / 8;
-    if (streams_per_xcd > needed) streams_per_xcd = needed;
-    hipLaunchKernelGGL(kern, dim3(8 * streams_per_xcd * a.tiles_n), dim3(WpCfg::THREADS), smem, s, a, a.a_bytes);
+    hipLaunchKernelGGL(kern, dim3(ws_grid(a, false)), dim3(WpCfg::THREADS), smem, s, a, a.a_bytes);
     return vcx_check_launch("vcx_gemm_f16(ws320 pipe)");
 }
 
@@ -1347,14 +1303,7 @@ int launch_ws(const GemmArgs& a, hipStream_t s) {
     static VcxLdsAttr lds;
     auto kern = gemm_ws320_kernel<MODE>;
     if (!lds.ensure(reinterpret_cast<const void*>(kern), (int)WS_SMEM, "vcx_gemm_f16(ws320)")) return VCX_ELAUNCH;
-    // 8 XCDs x (slots per XCD) blocks; a slot group = the tiles_n column blocks of one row stream.  Fewer streams than the chip
-    // has room for when the problem has fewer row tiles.
-    const int per_xcd = persistent_grid(1 << 30, 1) / 8;
-    int streams_per_xcd = per_xcd / a.tiles_n;
-    const int needed = (a.tiles_m + 7) / 8;
-    if (streams_per_xcd > needed) streams_per_xcd = needed;
-    const int nb = 8 * streams_per_xcd * a.tiles_n;
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(WsCfg::THREADS), WS_SMEM, s, a, a.a_bytes);
+    hipLaunchKernelGGL(kern, dim3(ws_grid(a, false)), dim3(WsCfg::THREADS), WS_SMEM, s, a, a.a_bytes);
     return vcx_check_launch("vcx_gemm_f16(ws320)");
 }
 
