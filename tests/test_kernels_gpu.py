@@ -905,7 +905,8 @@ def test_groupnorm_statistics_from_column_moments_in_one_launch(n, strips, C):
     assert torch.equal(one[0], stats[n - 1]), "the statistics of a sample depend on the batch it is in"
 
 
-@pytest.mark.parametrize("n,pix,C", [(50, 144, 1280), (2, 3600, 1280), (50, 144, 2560), (3, 40, 320), (2, 512, 960), (2, 513, 960), (4, 8, 64), (2, 4096, 640), (2, 4097, 320)])
+@pytest.mark.parametrize("n,pix,C", [(50, 144, 1280), (2, 3600, 1280), (50, 144, 2560), (3, 40, 320), (2, 512, 960), (2, 513, 960), (4, 8, 64), (2, 4096, 640), (2, 4097, 320),
+                                     (1, 1, 64), (2, 3, 32), (1, 2, 96)])      # fewer threads than groups unless the block is padded (found by the fuzz)
 def test_groupnorm_statistics_pass_small_images(n, pix, C):
     """vcx_groupnorm_stats_f16, round 6: up to 512 pixels one block per (n, slice of whole groups) writes the statistics directly (one
     launch); up to 4096 pixels 16-pixel chunks (the 9 x 16-pixel level of the UNet: 18 MB tensors were 58 - 100 blocks).  Against fp64,

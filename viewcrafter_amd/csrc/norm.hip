@@ -375,7 +375,9 @@ bool gn_direct_geometry(int64_t pixels, int C, int groups, int& Cs, int& cw, int
     cw = Cs >> 3;
     pl = 512 / cw;
     if (pl > pixels) pl = (int)pixels;
-    if (pl < 1) return false;
+    const int gslice = Cs / cpg;                        // one thread per group of the slice writes its statistics: the block must have them
+    if (cw * pl < gslice) pl = (gslice + cw - 1) / cw;  // (pixel lanes beyond the image own no pixel: they contribute zeros - found by the fuzz at 1 pixel x 32 channels)
+    if (pl < 1 || cw * pl > 1024) return false;
     return sizeof(float) * (2 * (size_t)pl * Cs + Cs) <= 64 * 1024;
 }
 
