@@ -208,6 +208,55 @@ def test_round5_kernels_are_bit_reproducible_at_the_benchmark_shapes():
     _soak(vae_attn, max(calls // 5, 5), "flash attention, one head of 512")
 
 
+def test_round6_kernels_are_bit_reproducible_at_the_benchmark_shapes():
+    """The kernels of round 6 under a full chip: the weight-stationary layer WITH row statistics (output and statistics; its merge of the
+    four strips of a row passes through LDS between waves), the one-launch GroupNorm statistics (from column moments and the direct
+    statistics pass), the GroupNorm apply over a split concat, and the 3x3 convolution with a two-source K tail and column moments."""
+    from viewcrafter_amd import ops
+    from viewcrafter_amd.packing import pack_conv
+    calls = max(CALLS // 4, 10)
+    M, C = 25 * 9216, 320
+    x = rnd(M, C, seed=71).to(DEV).half()
+    w = (rnd(C, C, seed=72) / math.sqrt(C)).to(DEV).half()
+    bias = rnd(C, seed=73).to(DEV)
+    res = rnd(M, C, seed=74).to(DEV).half()
+
+    def with_rowstats(residual):
+        st = torch.empty(M, 2, device=DEV)
+        return ops.linear(x, w, bias, residual=residual, rowstats=st), st
+    _soak(lambda: with_rowstats(res), calls, "weight-stationary linear + residual + row statistics")
+    _soak(lambda: with_rowstats(None), calls, "weight-stationary linear + row statistics")
+    wn = (rnd(25, C, C, seed=75) / math.sqrt(C)).to(DEV).half()
+    bn = rnd(25, C, seed=76).to(DEV)
+
+    def units_rowstats():
+        st = torch.empty(M, 2, device=DEV)
+        return ops.gemm_units(x, wn, bn, unit_rows=9216, rowstats=st), st
+    _soak(units_rowstats, calls, "one weight set per frame + row statistics")
+    # GroupNorm statistics: column moments of 25 frames x 9216 pixels x 320 (144 strips per frame), of 2 videos x 900 strips x 640, and the
+    # direct statistics pass at the 9 x 16-pixel level
+    cs = ops.colstats_buffer(M, C, DEV)
+    ops.linear(x, w, bias, colstats=cs)
+    _soak(lambda: ops.group_norm_stats_from_colstats(cs, 25, 9216, C), calls, "GroupNorm statistics from column moments, per frame")
+    cs2 = torch.rand(2 * 900, 640, 2, device=DEV)
+    _soak(lambda: ops.group_norm_stats_from_colstats(cs2, 2, 57600, 640), calls, "GroupNorm statistics from column moments, per video")
+    x3 = rnd(50, 144, 1280, seed=77).to(DEV).half()
+    _soak(lambda: ops.group_norm_stats(x3), calls, "GroupNorm statistics pass, direct form")
+    x3v = x3.view(2, 3600, 1280)
+    _soak(lambda: ops.group_norm_stats(x3v), calls, "GroupNorm statistics pass, 16-pixel chunks")
+    # the in_layers norm of an up-path ResBlock over [h | skip] in place, level 0: 640 + 320 channels
+    h, skip = rnd(25, 9216, 640, seed=78).to(DEV).half(), rnd(25, 9216, 320, seed=79).to(DEV).half()
+    g, b = (1 + 0.2 * rnd(960, seed=80)).to(DEV), (0.1 * rnd(960, seed=81)).to(DEV)
+    st960 = ops.group_norm_stats(torch.cat([h, skip], dim=2).contiguous())
+    _soak(lambda: ops.group_norm(h, g, b, 1e-5, True, stats=st960, x2=skip), max(calls // 2, 10), "GroupNorm apply over a split concat")
+    # ... and that block's second convolution with the skip convolution as a K tail: 25 x 72 x 128 x 320, K = 2880 + 640 + 320, column moments
+    a = rnd(25, 72, 128, C, seed=82).to(DEV).half()
+    wcat = torch.cat([pack_conv(rnd(C, C, 3, 3, seed=83) / math.sqrt(9 * C)), rnd(C, 960, seed=84) / math.sqrt(960)], dim=1).to(DEV).half().contiguous()
+    cs3 = ops.colstats_buffer(M, C, DEV)
+    hv, sv = h.view(M, 640), skip.view(M, 320)
+    _soak(lambda: (ops.conv2d(a, wcat, bias, kh=3, kw=3, tail=[hv, sv], colstats=cs3), cs3), max(calls // 5, 5), "3x3 convolution with a two-source K tail + column moments")
+
+
 @pytest.mark.parametrize("share_prefix", [True, False])
 def test_b2_unet_forward_at_25x72x128_is_bit_reproducible_over_20_runs(share_prefix):
     """The cond + uncond evaluation of one DDIM step at the headline latent, as the sampler launches it (B = 2, with the shared
