@@ -69,7 +69,7 @@ int vcx_device_arch(char* name_host, int len);
  * ---------------------------------------------------------------------------------- */
 #define VCX_GEMM_BIAS_N 0x1     /* + bias[n]                                              */
 #define VCX_GEMM_BIAS_M 0x2     /* + bias[m]  (used for the transposed V projection)     */
-#define VCX_GEMM_ROWADD 0x4     /* + rowadd[(m / rowadd_div) * N + n]  (ResBlock emb add,
+#define VCX_GEMM_ROWADD 0x4     /* + rowadd[(m / rowadd_div) * rowadd_ld + n]  (ResBlock emb add,
                                    openaimodel3d.py:216-226)                              */
 #define VCX_GEMM_RESIDUAL 0x8   /* + residual[m*ldr + n]                                  */
 #define VCX_GEMM_GEGLU 0x10     /* out[m, j] = x * gelu_erf(gate), attention.py:415-422;
@@ -115,7 +115,7 @@ typedef struct vcx_gemm_desc {
     const void* W;        /* fp16 weights [N][ldw]                                        */
     void* C;              /* fp16 (or fp32) output [M][ldc]                               */
     const float* bias;    /* fp32 [N] or [M]                                              */
-    const float* rowadd;  /* fp32 [ceil(M/rowadd_div)][N]                                 */
+    const float* rowadd;  /* fp32 [ceil(M/rowadd_div)][rowadd_ld >= N]                    */
     const void* residual; /* fp16 [M][ldr]                                                */
     int64_t lda;          /* linear: row stride; conv: pixel stride (elements)            */
     int32_t M, N, K;
@@ -131,7 +131,8 @@ typedef struct vcx_gemm_desc {
     int64_t ldcs;           /* columns between consecutive strips of colstats; 0 = N                */
     float* rowstats;        /* VCX_GEMM_ROWSTATS: out, fp32 [M][2] = (mean, rstd) of every output row, 8-byte aligned */
     float rowstats_eps;     /* VCX_GEMM_ROWSTATS: the LayerNorm's eps                                */
-    int32_t reserved0;      /* 0                                                                     */
+    int32_t rowadd_ld;      /* VCX_GEMM_ROWADD: elements between consecutive rows of rowadd; 0 = N (round 6: the addends of all
+                             * ResBlocks come from ONE projection of the embedding, each block reads its columns of that matrix) */
     /* K tail of a convolution (mode 1, round 6): K = kh*kw*cin + tail_k0 + tail_k1, and the last tail_k0 + tail_k1 columns of every W
      * row multiply, for output row m, the first tail_k0 elements of row m of tail_a0 and then the first tail_k1 of row m of tail_a1
      * (fp16 [M][tail_lda*], row-for-row like a linear layer).  A ResBlock's 1x1 skip convolution folded into its second 3x3

@@ -66,7 +66,7 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
         acc = acc + (bias.float()[:M].view(M, 1) if bias_m else bias.float()[:N].view(1, N))
     if rowadd is not None:
         rows = torch.arange(M) // rowadd_div
-        acc = acc + rowadd.float().reshape(-1, N)[rows]
+        acc = acc + rowadd.float()[rows]           # [rows, N]; may be a column slice of a wider matrix
     if geglu:
         a3 = acc.view(M, N // 64, 2, 32)
         acc = (a3[:, :, 0] * F.gelu(a3[:, :, 1])).reshape(M, n_out)

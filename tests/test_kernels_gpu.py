@@ -107,6 +107,21 @@ def test_gemm_rowadd():
     out = ops.linear(x, w, None, rowadd=ra, rowadd_div=rows_per)
     ref = x.float() @ w.float().t() + ra.repeat_interleave(rows_per, 0)
     check(out, ref, name="rowadd")
+    # round 6 (rowadd_ld): the addends as a column slice of a wider matrix - the emb_layers of all ResBlocks are ONE projection of the
+    # embedding (reference openaimodel3d.py:216-219) and each block's convolution reads its columns; the same bits as the contiguous form
+    wide = torch.full((B, 3 * N + 8), 9.0, device=DEV)
+    wide[:, N + 4:2 * N + 4] = ra
+    assert torch.equal(ops.linear(x, w, None, rowadd=wide[:, N + 4:2 * N + 4], rowadd_div=rows_per), out)
+    from viewcrafter_amd.packing import pack_conv
+    xc = rnd(B, 10, 10, 64, seed=13).to(DEV).half()
+    wc = pack_conv(rnd(N, 64, 3, 3, seed=14) / 24.0).to(DEV).half()
+    assert torch.equal(ops.conv2d(xc, wc, None, kh=3, kw=3, rowadd=wide[:, N + 4:2 * N + 4], rowadd_div=100), ops.conv2d(xc, wc, None, kh=3, kw=3, rowadd=ra, rowadd_div=100))
+    x_ws = rnd(9216 * 2, 320, seed=15).to(DEV).half()      # the weight-stationary serial form (N = K = 320, ROWADD)
+    w_ws = (rnd(320, 320, seed=16) / 18.0).to(DEV).half()
+    ra2 = rnd(2, 320, seed=17).to(DEV)
+    wide2 = torch.zeros((2, 1000), device=DEV)
+    wide2[:, 100:420] = ra2
+    assert torch.equal(ops.linear(x_ws, w_ws, None, rowadd=wide2[:, 100:420], rowadd_div=9216), ops.linear(x_ws, w_ws, None, rowadd=ra2, rowadd_div=9216))
 
 
 @pytest.mark.parametrize("M,N,K,geglu", [(2853, 5120, 128, False), (1500, 4096, 64, True), (16640, 5120, 64, True), (2048, 2560, 192, False)])

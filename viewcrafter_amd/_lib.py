@@ -40,7 +40,7 @@ class GemmDesc(ctypes.Structure):
         ("kh", c_int32), ("kw", c_int32), ("stride", c_int32), ("pad_h", c_int32), ("pad_w", c_int32),
         ("ups", c_int32), ("rowadd_div", c_int32), ("flags", c_int32), ("alpha", c_float),
         ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("colstats", c_void_p), ("ldcs", c_int64),
-        ("rowstats", c_void_p), ("rowstats_eps", c_float), ("reserved0", c_int32),
+        ("rowstats", c_void_p), ("rowstats_eps", c_float), ("rowadd_ld", c_int32),
         ("tail_a0", c_void_p), ("tail_a1", c_void_p), ("tail_lda0", c_int64), ("tail_lda1", c_int64), ("tail_k0", c_int32), ("tail_k1", c_int32),
     ]
 

@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
                     const int m = mbase + b * 16;
                     const int mc = min(m, p.M - 1);
                     const float bm = (flags & VCX_GEMM_BIAS_M) ? p.bias[mc] : 0.f;
-                    const float* radd = (flags & VCX_GEMM_ROWADD) ? p.rowadd + (int64_t)(mc / p.rowadd_div) * p.N : nullptr;
+                    const float* radd = (flags & VCX_GEMM_ROWADD) ? p.rowadd + (int64_t)(mc / p.rowadd_div) * p.rowadd_ld : nullptr;
 #pragma unroll
                     for (int a = 0; a < NFRAG; ++a) {
                         const int n0 = nbase + a * 16;
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(GemmArgs p) {
     for (int b = 0; b < 4; ++b) {
         const int m = tile_m * BM + wm * 64 + b * 16 + lr;
         if (m >= p.M) continue;
-        const float* radd = (flags & VCX_GEMM_ROWADD) ? p.rowadd + (int64_t)(m / p.rowadd_div) * p.N : nullptr;
+        const float* radd = (flags & VCX_GEMM_ROWADD) ? p.rowadd + (int64_t)(m / p.rowadd_div) * p.rowadd_ld : nullptr;
         if (GEGLU) {
 #pragma unroll
             for (int a = 0; a < NFRAG / 2; ++a) {
@@ -410,7 +410,8 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
                 "vcx_gemm_f16: A/W/C must be 16-byte aligned");
     const int flags = d->flags;
     VCX_REQUIRE(!(flags & (VCX_GEMM_BIAS_N | VCX_GEMM_BIAS_M)) || d->bias, "vcx_gemm_f16: bias flag without bias");
-    VCX_REQUIRE(!(flags & VCX_GEMM_ROWADD) || (d->rowadd && d->rowadd_div > 0), "vcx_gemm_f16: bad rowadd");
+    VCX_REQUIRE(!(flags & VCX_GEMM_ROWADD) || (d->rowadd && d->rowadd_div > 0 && (d->rowadd_ld == 0 || (d->rowadd_ld >= d->N && d->rowadd_ld % 4 == 0))),
+                "vcx_gemm_f16: bad rowadd (rowadd_ld must be 0 or a multiple of 4 >= N)");
     VCX_REQUIRE(!(flags & VCX_GEMM_RESIDUAL) || d->residual, "vcx_gemm_f16: residual flag without pointer");
     const bool conv = d->mode == 1;
     const bool geglu = flags & VCX_GEMM_GEGLU;
@@ -478,6 +479,7 @@ extern "C" int vcx_gemm_f16(const vcx_gemm_desc* d, void* stream) {
     a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w;
     a.cin = d->cin; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.ups = d->ups;
     a.rowadd_div = d->rowadd_div > 0 ? d->rowadd_div : 1;
+    a.rowadd_ld = d->rowadd_ld > 0 ? d->rowadd_ld : d->N;
     a.flags = flags;
     a.alpha = d->alpha;
     const bool use160 = !geglu && (d->N % 160 == 0);
@@ -623,7 +625,7 @@ extern "C" int vcx_gemm_units_f16(const vcx_gemm_desc* d, int unit_rows, int64_t
         GemmArgs a{};
         a.A = (const half_t*)d->A; a.W = (const half_t*)d->W; a.C = d->C; a.bias = d->bias;
         a.lda = d->lda; a.M = d->M; a.N = d->N; a.K = d->K; a.ldw = d->ldw; a.ldc = d->ldc; a.ldr = 0;
-        a.rowadd_div = 1; a.flags = d->flags; a.alpha = d->alpha; a.m_begin = 0;
+        a.rowadd_div = 1; a.rowadd_ld = d->N; a.flags = d->flags; a.alpha = d->alpha; a.m_begin = 0;
         a.ldcs = d->N;
         a.a_bytes = (unsigned)a_ext; a.c_bytes = (unsigned)c_ext; a.w_bytes = 0; a.r_bytes = 0;
         a.unit_rows = unit_rows; a.units = units; a.w_unit_stride = w_unit_stride; a.bias_unit_stride = bias_unit_stride;

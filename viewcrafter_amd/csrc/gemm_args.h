@@ -20,6 +20,7 @@ struct GemmArgs {
     int ldw, ldc, ldr;
     int in_h, in_w, out_h, out_w, cin, kh, kw, stride, pad_h, pad_w, ups;
     int rowadd_div;
+    int rowadd_ld;      // elements between consecutive rows of rowadd (>= N)
     int flags;
     float alpha;
     int tiles_m, tiles_n;

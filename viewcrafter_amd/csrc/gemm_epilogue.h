@@ -207,7 +207,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
             } else {
                 f4 t = (flags & VCX_GEMM_BIAS_N) ? *reinterpret_cast<const f4*>(p.bias + nc) : f4{0.f, 0.f, 0.f, 0.f};
                 if (radd_tile) {
-                    const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)radd_row * p.N + nc);
+                    const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)radd_row * p.rowadd_ld + nc);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) t[r] += rv[r];
                 }
@@ -266,7 +266,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f4 (&acc)[Cfg::
                 const int mc = min(mbase + b * 16, p.M - 1);
                 f4 t = *reinterpret_cast<const f4*>(sB + bopaque + a * 16 + lg * 4);
                 if (flags & VCX_GEMM_ROWADD) {
-                    const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)(mc / p.rowadd_div) * p.N + min(nbase + a * 16, p.N - 4));
+                    const f4 rv = *reinterpret_cast<const f4*>(p.rowadd + (int64_t)(mc / p.rowadd_div) * p.rowadd_ld + min(nbase + a * 16, p.N - 4));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) t[r] += rv[r];
                 }

@@ -26,6 +26,8 @@ from ..flow import CAT_SPLIT, GN_EPILOGUE_STATS, GN_STATS_LEVEL, CatTarget, Flow
 # A ResBlock's 1x1 skip convolution as a K tail of its second 3x3 convolution (round 6, include/vcx.h tail_a0 / tail_a1).  VCX_SKIP_FOLD=0: the
 # separate convolution + residual of rounds 1-5 (A/B runs; also switches the split concat off, which needs the fold).
 SKIP_FOLD = os.environ.get("VCX_SKIP_FOLD", "1") != "0"
+# emb_layers of all ResBlocks as ONE projection per forward (round 6); VCX_EMB_BATCHED=0: one launch per block
+EMB_BATCHED = os.environ.get("VCX_EMB_BATCHED", "1") != "0"
 
 class TimestepBlock(nn.Module):
     """Marker: modules whose forward takes the timestep embedding (reference openaimodel3d.py:19-28)."""
@@ -229,6 +231,7 @@ class ResBlock(PackedModule, TimestepBlock):
         if self.use_temporal_conv:
             self.temopral_conv = TemporalConvBlock(self.out_channels, self.out_channels, dropout=0.1,
                                                    spatial_aware=tempspatial_aware)
+        self._emb_all = None       # set by UNetModel._forward for the length of one forward: this block's columns of the batched emb projection
 
     def _pack(self):
         gn1, c1 = self.in_layers[0], self.in_layers[2]
@@ -268,7 +271,8 @@ class ResBlock(PackedModule, TimestepBlock):
         c1, cin = cin, sum(tail_ks) if x2 is not None else x.shape[-1]
         stats_in = None if colstats is None else ops.group_norm_stats_from_colstats(colstats, n, H * W, cin)
         a = ops.group_norm(x.view(n, H * W, c1 if x2 is not None else cin), *pk["g1"], True, stats=stats_in, x2=None if x2 is None else x2.view(n, H * W, -1))
-        emb_out = ops.linear(emb, pk["we"], pk["be"], out_f32=True)                           # [B, Cout] fp32
+        # [B, Cout] fp32: this block's columns of the one projection UNetModel made of the embedding, or its own launch (a block used alone)
+        emb_out = self._emb_all[:B] if self._emb_all is not None else ops.linear(emb, pk["we"], pk["be"], out_f32=True)
         # The norms behind this block's own convolutions take their statistics from those convolutions' epilogues (column moments
         # per 64-row strip, VCX_GEMM_COLSTATS) instead of a pass over the tensor: out_layers' norm (per frame) from conv 1, the
         # first norm of the temporal block (per video) from conv 2 - where frames are whole strips (not at 9x16 = 144 pixels).
@@ -431,7 +435,24 @@ class UNetModel(PackedModule):
                   te=[(_f16(l.weight), _f32(l.bias)) for l in (self.time_embed[0], self.time_embed[2])])
         if self.fs_condition:
             pk["fe"] = [(_f16(l.weight), _f32(l.bias)) for l in (self.fps_embedding[0], self.fps_embedding[2])]
+        # emb_layers of ALL ResBlocks as one projection (round 6): `self.emb_layers(emb)` of every block (reference openaimodel3d.py:216-219)
+        # reads the same embedding, and 22 launches of an M = 2 GEMM are 22 x 24 us of latency per forward - one launch writes
+        # [B, sum of the blocks' widths] and each block's convolution reads its columns of that matrix (VCX_GEMM_ROWADD with rowadd_ld)
+        rbs = self.resblocks()
+        pk["emb_w"] = torch.cat([_f16(rb.emb_layers[1].weight) for rb in rbs], dim=0).contiguous()
+        pk["emb_b"] = torch.cat([_f32(rb.emb_layers[1].bias) for rb in rbs], dim=0).contiguous()
+        off, pk["emb_off"] = 0, {}
+        for rb in rbs:
+            n_e = rb.emb_layers[1].weight.shape[0]
+            pk["emb_off"][id(rb)] = (off, n_e)
+            off += n_e
         return pk
+
+    def resblocks(self):
+        return [m for m in self.modules() if isinstance(m, ResBlock)]
+
+    def _foreign_params(self):      # the pack embeds the ResBlocks' emb_layers: rebuilt when any of them changes (PackedModule.packed)
+        return [p for rb in self.resblocks() for p in (rb.emb_layers[1].weight, rb.emb_layers[1].bias)]
 
     def spatial_transformers(self):
         return [m for m in self.modules() if isinstance(m, SpatialTransformer)]
@@ -543,6 +564,22 @@ class UNetModel(PackedModule):
         pk = self.packed()
         emb = self._embed(pk, timesteps, fs, b, device)
         ckv = self._context_kv(context, t)
+        rbs = self.resblocks()
+        if EMB_BATCHED and all(o % 4 == 0 for o, _ in pk["emb_off"].values()):
+            emb_all = ops.linear(emb, pk["emb_w"], pk["emb_b"], out_f32=True)                 # [b, sum of widths] fp32: every block's emb_layers at once
+            if r > 1:     # rows of the replicated batch: video v reads row v % b - the first b rows serve the layers ahead of the split
+                n_all = emb_all.shape[1]
+                emb_all = ops.repeat_rows(emb_all.view(torch.float16).view(b, 2 * n_all), r).view(torch.float32).view(r * b, n_all)
+            for rb in rbs:
+                o, n_e = pk["emb_off"][id(rb)]
+                rb._emb_all = emb_all[:, o:o + n_e]
+        try:
+            return self._forward_body(parts, pk, emb, ckv, b, t, hh, ww, cin, r, device, features_adapter)
+        finally:
+            for rb in rbs:
+                rb._emb_all = None
+
+    def _forward_body(self, parts, pk, emb, ckv, b, t, hh, ww, cin, r, device, features_adapter):
         # batch currently flowing through the graph: b until the first SpatialTransformer replicated it, b * r afterwards
         cur_b = b
 

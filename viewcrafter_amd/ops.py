@@ -82,8 +82,11 @@ def gemm(a, w, *, M, N, K, lda, out=None, ldc=None, bias=None, bias_m=False, res
         d.bias = bias.data_ptr()
         flags |= GEMM_BIAS_M if bias_m else GEMM_BIAS_N
     if rowadd is not None:
+        if rowadd.dim() != 2 or rowadd.stride(1) != 1 or rowadd.shape[1] != n_out:
+            raise VcxError(f"rowadd must be [rows, N = {n_out}] fp32 with unit column stride (a column slice of a wider matrix is fine), got {tuple(rowadd.shape)}")
         d.rowadd = rowadd.data_ptr()
         d.rowadd_div = rowadd_div
+        d.rowadd_ld = rowadd.stride(0) if rowadd.shape[0] > 1 else n_out
         flags |= GEMM_ROWADD
     if residual is not None:
         d.residual = residual.data_ptr()
