@@ -93,6 +93,17 @@ def test_two_clips_per_gpu_on_two_streams_equal_the_plain_loop(igs_model):
         assert torch.equal(a, b)
     assert torch.equal(got[1][1], got[2][1]) and torch.equal(got[1][2], got[2][2])
     assert not torch.equal(got[1][0][0], got[1][0][1])
+    # ... and on a COLD model: every kernel-layout pack dropped, two lanes as the first call - the packs are then built on the
+    # caller's stream before the lanes start (interleave.prepack) and the lanes wait on a hand-over event; a lane reading a pack that another
+    # stream is still writing would show up here as differing bits
+    for m in igs_model.modules():
+        if hasattr(m, "_drop_packed"):
+            m._drop_packed()
+    torch.manual_seed(5)
+    cold = parallel.run_sharded(one, clips, gather=False, lanes=2, model=igs_model)
+    torch.cuda.synchronize()
+    for a, b in zip(got[1][0], cold):
+        assert torch.equal(a, b), "two lanes on a cold model differ from the plain loop"
 
 
 def test_inference_cli_end_to_end(tmp_path):

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 from viewcrafter_amd import _lib, ops  # noqa: E402
 
 FIELDS = ["M", "N", "K", "lda", "ldw", "ldc", "ldr", "mode", "in_h", "in_w", "out_h", "out_w", "cin", "kh", "kw", "stride",
-          "pad_h", "pad_w", "ups", "rowadd_div", "flags"]
+          "pad_h", "pad_w", "ups", "rowadd_div", "flags", "tail_k0", "tail_k1", "tail_lda0", "tail_lda1"]
 
 
 def record_forward(workload):
@@ -88,8 +88,10 @@ def make_problem(key):
         bn = torch.randn(units, N, device="cuda")
         out = torch.empty(M, N, device="cuda", dtype=torch.float16)
 
+        rs = ops.rowstats_buffer(M, "cuda") if d["flags"] & 1024 else None
+
         def run_units():
-            ops.gemm_units(a, wn, bn, unit_rows=d["in_h"], out=out)
+            ops.gemm_units(a, wn, bn, unit_rows=d["in_h"], out=out, rowstats=rs)
         return run_units
     conv = d["mode"] == 1
     flags = d["flags"]
@@ -107,6 +109,7 @@ def make_problem(key):
     geom = {k: d[k] for k in ("in_h", "in_w", "out_h", "out_w", "cin", "kh", "kw", "stride", "pad_h", "pad_w", "ups")} if conv else None
     if conv:
         geom["slabk"] = bool(flags & 64)
+    tails = [torch.randn(M, d[f"tail_lda{j}"], device="cuda").half()[:, :d[f"tail_k{j}"]] for j in (0, 1) if d.get(f"tail_k{j}", 0)]
     # the folded-LayerNorm and column-moment epilogues are part of the problem (until round 5's last run this tool timed such layers
     # in their plain form - the K = 320 q | k | v projection even on the weight-stationary kernel, which does not take LNFOLD calls)
     extra = {}
@@ -117,6 +120,10 @@ def make_problem(key):
         extra.update(ln_stats=st, ln_colsum=0.01 * torch.randn((M if ln_t else N), device="cuda"), ln_t=ln_t)
     if flags & 512:
         extra.update(colstats=ops.colstats_buffer(M, n_out, "cuda"))
+    if flags & 1024:      # VCX_GEMM_ROWSTATS
+        extra.update(rowstats=ops.rowstats_buffer(M, "cuda"))
+    if tails:             # the folded skip convolution: K counts the tail columns
+        extra.update(tail=tails)
 
     def run():
         ops.gemm(a, w, M=M, N=N, K=K, lda=d["lda"], ldw=d["ldw"], out=out, ldc=d["ldc"], bias=bias, bias_m=bool(flags & 2),
@@ -138,7 +145,8 @@ def main():
         fl = 2.0 * d["M"] * d["N"] * d["K"]
         taps = d["kh"] * d["kw"] if d["mode"] == 1 else 1
         n_out = d["N"] // 2 if d["flags"] & 16 else d["N"]
-        nbytes = 2.0 * (d["M"] * d["K"] / taps + d["N"] * d["K"] + d["M"] * n_out * (2 if d["flags"] & 32 else 1) + (d["M"] * d["N"] if d["flags"] & 8 else 0))
+        tail = d.get("tail_k0", 0) + d.get("tail_k1", 0)
+        nbytes = 2.0 * (d["M"] * (d["K"] - tail) / taps + d["M"] * tail + d["N"] * d["K"] + d["M"] * n_out * (2 if d["flags"] & 32 else 1) + (d["M"] * d["N"] if d["flags"] & 8 else 0))
         floor = max(fl / 1.35e15, nbytes / 5.5e12) * 1e3       # ms: best isolated MFMA rate seen on this part under load / achievable HBM
         rows.append(dict(d, count=cnt, ms=ms, total_ms=ms * cnt, tflops=fl / ms / 1e9, floor_ms=floor, hbm_bound=nbytes / 5.5e12 > fl / 1.35e15))
     rows.sort(key=lambda r: -r["total_ms"])
@@ -150,7 +158,7 @@ def main():
     cum = 0.0
     for r in rows:
         cum += r["total_ms"]
-        kind = (f"conv{r['kh']}x{r['kw']}" + ("s2" if r["stride"] == 2 else "") + ("u" if r["ups"] else "") if r["mode"] == 1
+        kind = (f"conv{r['kh']}x{r['kw']}" + ("s2" if r["stride"] == 2 else "") + ("u" if r["ups"] else "") + ("+t" if r.get("tail_k0") else "") if r["mode"] == 1
                 else f"units/{r['M'] // r['in_h']}" if r["mode"] == 2 else "linear")
         print(f"{r['count']:4d} {r['M']:8d} {r['N']:6d} {r['K']:6d} {kind:>10} {r['flags']:5d} {r['ms']:8.3f} {r['total_ms']:8.2f} {r['tflops']:7.0f} {100*cum/tot:6.1f} {r['floor_ms']:7.3f} {'hbm' if r['hbm_bound'] else 'mfma':>5} {(r['ms'] - r['floor_ms']) * r['count']:7.2f}")
     if args.json:
