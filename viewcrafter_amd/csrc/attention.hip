@@ -1231,10 +1231,11 @@ extern "C" int vcx_attn_flash_d64_f16(const void* q, const void* k, const void* 
                 "vcx_attn_flash_d64_f16: K / V^T extents per (group, head) must stay below 4 GiB");
     // Long key sequences with base-2 logits and whole 64-key tiles: the software-pipelined kernel (attention_v2.hip: MFMA and
     // softmax overlapped inside one wave per SIMD).  One block per CU and a prologue that is not hidden behind another block:
-    // it pays from ~4000 keys up (same-box A/B, profiles/r03_flash_v2.md: +4.5 % at 9216 keys, level at 2304 / 1152, -18 % at 576;
-    // knob FLASH_IMPL: 1 = never, 2 = whenever the shapes allow)
+    // it pays from ~2000 keys up (same-box A/Bs: round 3, profiles/r03_flash_v2.md: +4.5 % at 9216 keys, level at 2304 / 1152, -18 % at 576;
+    // round 6 with the K rows permuted - no half swaps in the softmax stream - profiles/r06a_flash_variants_ab.txt, r06g_flash_sumv_ab.txt:
+    // +5 ... +7 % at 2304 keys on two boxes, level ... +5 % at 1152, -15 % at 576; knob FLASH_IMPL: 1 = never, 2 = whenever the shapes allow)
     const int impl = vcx_tune(VCX_TUNE_FLASH_IMPL);
-    if (impl != 1 && pre && !(flags & VCX_ATTN_ACCUMULATE) && nk % 64 == 0 && (impl == 2 || nk >= 4096)) {
+    if (impl != 1 && pre && !(flags & VCX_ATTN_ACCUMULATE) && nk % 64 == 0 && (impl == 2 || nk >= 2048)) {
         Flash2Args f;
         f.q = (const half_t*)q; f.k = (const half_t*)k; f.vt = (const half_t*)vt; f.o = (half_t*)o;
         f.heads = heads; f.nq = nq; f.nk = nk; f.kv_rows = kv_rows; f.kv_div = kv_div;
