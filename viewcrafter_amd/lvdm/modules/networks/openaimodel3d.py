@@ -44,6 +44,8 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
         layers after it see batch_size * r videos.  flow (Flow): moments of x in, moments of the result out, and the concat
         target of the last layer; with a target the returned tensor is a strided view of its left columns."""
         layers = list(self)
+        if x2 is not None and not (layers and isinstance(layers[0], ResBlock)):
+            raise ValueError("a split concat [x | x2] can only enter a block that starts with a ResBlock")
         colstats = flow.colstats if flow is not None else None      # column moments of x from the layer that produced it
         for i, layer in enumerate(layers):
             last = i + 1 == len(layers)
@@ -642,13 +644,15 @@ class UNetModel(PackedModule):
             # writes it straight into the left columns of the next block's concatenated input - and its column moments into the left
             # columns of that tensor's moment buffer - so only the skip half is copied, and the GroupNorm in front of the next
             # ResBlock takes its statistics from the two producers' epilogues.
-            def target_for(n_, H_, W_, c_left):
+            def target_for(n_, H_, W_, c_left, consumer):
                 skip, skip_cs = hs[-1]
                 M_ = n_ * H_ * W_
                 ok = skip_cs is not None and ops.colstats_ok(M_, H_ * W_, 64, c_left + skip.shape[-1])
-                return CatTarget(M_, c_left, skip.shape[-1], device, with_moments=ok, split=CAT_SPLIT and SKIP_FOLD and c_left % 64 == 0 and skip.shape[-1] % 64 == 0)
+                # split (the concat is read in place) only into a block that starts with a ResBlock - the layer that can read two halves
+                split = CAT_SPLIT and SKIP_FOLD and c_left % 64 == 0 and skip.shape[-1] % 64 == 0 and isinstance(list(consumer)[0], ResBlock)
+                return CatTarget(M_, c_left, skip.shape[-1], device, with_moments=ok, split=split)
             n, H, W, _ = h.shape
-            tgt = target_for(n, H, W, _out_channels_of(self.middle_block))
+            tgt = target_for(n, H, W, _out_channels_of(self.middle_block), self.output_blocks[0])
             flow = Flow(colstats=cs, target=tgt)
             h = self.middle_block(h, emb, context=ckv, batch_size=b, flow=flow)
             for j, module in enumerate(self.output_blocks):
@@ -665,7 +669,7 @@ class UNetModel(PackedModule):
                 tgt = None
                 if j + 1 < len(self.output_blocks):
                     up = 2 if isinstance(list(module)[-1], Upsample) else 1
-                    tgt = target_for(n, H * up, W * up, _out_channels_of(module))
+                    tgt = target_for(n, H * up, W * up, _out_channels_of(module), self.output_blocks[j + 1])
                 flow = Flow(colstats=cat_cs, want=tgt is None, target=tgt)
                 h = module(hcat, emb, context=ckv, batch_size=b, flow=flow, x2=x2)
             cs = flow.colstats
