@@ -1,6 +1,10 @@
 """Quick A/B of the GEMM engine on representative problems of one UNet forward (prints ms and TF/s)."""
 import math, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if os.environ.get("VCX_LIB"):       # another build of the library (tools/build_abl.sh): VCX_LIB=tools/_abl/libvcx_x.so python tools/gemm_quick.py
+    from viewcrafter_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["VCX_LIB"])
 from viewcrafter_amd import ops
 from viewcrafter_amd.packing import pack_conv, pack_geglu
 dev = "cuda"
