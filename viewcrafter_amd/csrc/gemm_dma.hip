@@ -185,13 +185,6 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
             }
         } else if (!CONV && (parts & 1)) {
             const unsigned soff = (unsigned)kt * (BK * 2);
-#if VCX_GEMM_A_NT       // A/B build (vcx_ablate.h): activation rows that are read exactly once (one column tile) with a cache-policy hint
-            if (p.tiles_n == 1) {
-#pragma unroll
-                for (int i = 0; i < XROWS; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + RSTEP * i * BK), 16, xoff[i], soff, 0, VCX_GEMM_A_NT);
-            } else
-#endif
 #pragma unroll
             for (int i = 0; i < XROWS; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + RSTEP * i * BK), 16, xoff[i], soff, 0, 0);

@@ -15,10 +15,6 @@
 #ifndef VCX_WL_ABL      // gemm_ws320_lnf_kernel, timing only (tools/ws_lnf_ab.py), bits: 1 no arithmetic chunks, 2 no MFMAs, 8 no stores
 #define VCX_WL_ABL 0
 #endif
-// gemm_dma.hip
-#ifndef VCX_GEMM_A_NT   // linear layers with ONE column tile: aux bits of the activation rows' LDS-DMA (2 = nt, 16 = sc1); A/B with tools/gemm_quick.py <library>
-#define VCX_GEMM_A_NT 0
-#endif
 // attention.hip
 #ifndef XABL            // xattn_resident2_d64_kernel, timing only (tools/xattn_ablate.py), bits: 1 no exp2, 2 no softmax arithmetic, 4 no MFMAs,
 #define XABL 0          // 8 no Q loads / O stores, 16 no fragment reads, 32 no deferred-max test
