@@ -6,7 +6,7 @@ knobs, variants interleaved round by round.  Prints ms per step and the per-fami
 A variant is  name:key=value,key=value  with keys
     gnfold   0 | 1   TemporalTransformer.norm folded into proj_in (viewcrafter_amd/lvdm/modules/attention.py GN_FOLD)
     gnspatial 0 | 1  ... and SpatialTransformer.norm at level 0 (GN_FOLD_SPATIAL)
-    lnff     0 | 1   LayerNorm folded into the GEGLU projection (FOLD_LAYERNORM_FF)
+    lnff     0 | 1 | 2   LayerNorm folded into the GEGLU projection (FOLD_LAYERNORM_FF); 2 = only at C >= 640 (levels 1-3)
     xattn    1 | 2   resident cross-attention kernel: second form | first form (knob XATTN_RESIDENT)
     ws       1 | 0   weight-stationary K = 320 kernel (knob GEMM_WS)
     lnrs     1 | 0   LayerNorm statistics from the producing layer's epilogue (VCX_GEMM_ROWSTATS; ops.LN_ROWSTATS)
@@ -68,9 +68,9 @@ def main():
     def apply(settings):
         attention.GN_FOLD = settings.get("gnfold", "1") != "0"
         attention.GN_FOLD_SPATIAL = settings.get("gnspatial", "1") != "0"
-        lnff = settings.get("lnff", "0") == "1"
-        if lnff != attention.FOLD_LAYERNORM_FF:
-            attention.FOLD_LAYERNORM_FF = lnff
+        lnff, lnff_min = settings.get("lnff", "2") != "0", (640 if settings.get("lnff", "2") == "2" else 0)      # 2 (the product): levels 1-3 only (C >= 640)
+        if lnff != attention.FOLD_LAYERNORM_FF or lnff_min != attention.FOLD_LAYERNORM_FF_MIN_DIM:
+            attention.FOLD_LAYERNORM_FF, attention.FOLD_LAYERNORM_FF_MIN_DIM = lnff, lnff_min
             for m in model.modules():
                 if isinstance(m, attention.FeedForward):
                     m._drop_packed()

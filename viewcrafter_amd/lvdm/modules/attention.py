@@ -34,9 +34,13 @@ def _f32(t):
 # (VCX_GEMM_LNFOLD, include/vcx.h): the normalised copy of the token stream is neither written nor re-read.  Needs the DMA GEMM
 # kernel (channel count % 64 == 0); VCX_LN_FOLD=0 keeps the separate LayerNorm kernel (A/B runs, tools/lnfold_ab.py).
 FOLD_LAYERNORM = os.environ.get("VCX_LN_FOLD", "1") != "0"
-# ... except in front of the GEGLU projection: its epilogue is arithmetic-bound (GELU) and the two extra multiply-adds per output pair
-# cost more than the LayerNorm write they save (profiles/r03_experiments.md section 8: +2.6 ... +7.5 % on the pair) - opt-in only.
-FOLD_LAYERNORM_FF = os.environ.get("VCX_LN_FOLD_FF", "0") == "1"
+# ... in front of the GEGLU projection too, from C = 640 up (round 6): there the projection runs on the tiled engine either way and the fold
+# replaces a read + write pass over the token stream by a statistics pass (same box, tools/step_ab.py lnff = 0 / 2 / 1, profiles/r06s_lnff_ab.txt:
+# LayerNorm family 3.14 -> 2.67 ms at no GEMM cost, step -0.45 ms).  NOT at C = 320: the level-0 projection would leave the weight-stationary
+# GEGLU kernel for the tiled engine's folded epilogue, whose two extra multiply-adds per output pair cost more than the pass they save (fold
+# everywhere: GEMM +1.0 ms, step level; round 3: profiles/r03_experiments.md section 8).  VCX_LN_FOLD_FF=0: never; VCX_LN_FOLD_FF_MIN_DIM: the width.
+FOLD_LAYERNORM_FF = os.environ.get("VCX_LN_FOLD_FF", "1") != "0"
+FOLD_LAYERNORM_FF_MIN_DIM = int(os.environ.get("VCX_LN_FOLD_FF_MIN_DIM", "640"))
 
 
 # TemporalTransformer.norm -> proj_in (reference attention.py:331-336,369-372) and SpatialTransformer.norm -> proj_in (:265-269,299):
@@ -234,7 +238,7 @@ class FeedForward(PackedModule):
 
     def _pack(self):
         proj = self.net[0].proj
-        ln = self._pre_norm[0] if (self._pre_norm and FOLD_LAYERNORM and FOLD_LAYERNORM_FF and self.dim % 64 == 0) else None
+        ln = self._pre_norm[0] if (self._pre_norm and FOLD_LAYERNORM and FOLD_LAYERNORM_FF and self.dim % 64 == 0 and self.dim >= FOLD_LAYERNORM_FF_MIN_DIM) else None
         p1 = _ln_projection(proj.weight.detach(), ln, bias=proj.bias)
         w1, b1 = pack_geglu(p1["w"], p1["bias"])
         colsum = None if p1["colsum"] is None else pack_geglu(p1["w"], p1["colsum"])[1]
