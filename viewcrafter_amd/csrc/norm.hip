@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(1024) gn_colstats_direct_kernel(const float2* 
     }
 }
 
-// geometry of the one-launch form: up to 1024 (narrow groups: 4096) strips per n, groups of at most 256 columns.  Strip lanes first - as many as give a
+// geometry of the one-launch form: up to 1024 strips per n, groups of at most 256 columns.  Strip lanes first - as many as give a
 // thread ONE batch of eight loads (the kernel is a latency chain: r06e, 11.4 us per launch with two batches per thread on 200 blocks) -
 // then as many whole groups per block as fit 1024 threads, 80 columns at most.  A function of (strips, C, groups) only.
 bool gn_colstats_direct_geometry(int64_t strips, int C, int groups, int& gpb, int& L) {
@@ -437,9 +437,9 @@ bool gn_colstats_direct_geometry(int64_t strips, int C, int groups, int& gpb, in
     return false;
 #endif
     const int cpg = C / groups;
-    // up to 1024 strips always; up to 4096 where a group is narrow enough for >= 64 strip lanes beside it (the per-video norms of level 0: 3600 strips x
-    // 10-column groups = 102 lanes x 36 strips, five batches of loads - against two launches of the partials + finalize pair)
-    if (strips > 4096 || cpg > 256 || (strips > 1024 && cpg > 16)) return false;
+    // (up to 4096 strips for narrow groups - the per-video norms of level 0, 102 lanes x 36 strips - measured: GroupNorm family +0.35 ms against the
+    // partials + finalize pair, profiles/r06u_step_ab.txt: the pair's 225 blocks stream the 18 MB of moments, 64 blocks with 80-byte rows do not)
+    if (strips > 1024 || cpg > 256) return false;
     int lanes = (int)((strips + 7) / 8);
     if (lanes > 1024 / cpg) lanes = 1024 / cpg;         // (one group per block at least)
     gpb = 1024 / lanes / cpg;
