@@ -19,7 +19,7 @@ def build(rev):
                                "-c", os.path.join(CSRC, "_attention_old.hip"), "-o", "/tmp/attention_old.o"])
     finally:
         os.remove(os.path.join(CSRC, "_attention_old.hip"))
-    others = [os.path.join(CSRC, "build", f"{n}.o") for n in ("api", "gemm", "gemm_dma", "attention_v2", "norm", "elementwise")]
+    others = [os.path.join(CSRC, "build", f"{n}.o") for n in ("api", "gemm", "gemm_dma", "gemm_ws", "attention_v2", "norm", "elementwise")]
     dst = os.path.join(ABL, "libvcx_tattn_old.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", dst, "/tmp/attention_old.o", *others])
     print("built", dst, "from", rev)
