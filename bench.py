@@ -453,7 +453,12 @@ def main():
                                      "(csrc/gemm_ws.hip); <0.5% of FLOPs on the register-staged gemm_kernel fallback",
                            "launches_per_step": gemm["launches"] / args.steps,
                            "avg_launch_ms": gemm["ms"] / max(gemm["launches"], 1),
-                           "algorithmic_tflop_per_launch_avg": gemm["flops"] / max(gemm["launches"], 1) / 1e12}
+                           "algorithmic_tflop_per_launch_avg": gemm["flops"] / max(gemm["launches"], 1) / 1e12,
+                           # context, not the peak `frac` is priced against: what the matrix pipes deliver on this part with nothing else running,
+                           # measured (tools/mfma_shape_probe.py, profiles/r06z_mfma_shape_probe.txt: the engine's wave-tile K-step from registers
+                           # only, 16x16x32 MFMAs, two waves per SIMD on all CUs; the SMU holds ~1.98 GHz at ~1.28 kW)
+                           "peak_sustained_under_power_cap": {"tflops": 1981.0, "sclk_mhz": 1980.0, "power_w": 1283.0,
+                                                              "frac_of_it": ach / 1981.0, "source": "profiles/r06z_mfma_shape_probe.txt"}}
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (bench.py cannot run rocprofv3 itself).  The
         # file records a hash of the GEMM sources it was measured on: a number measured on other kernels is not reported.
         tr = {}
