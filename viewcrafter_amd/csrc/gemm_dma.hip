@@ -129,8 +129,13 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
         tap = 0; ci0 = 0; tap_off = 0; tky = 0; tkx = 0;
     };
 
+    [[maybe_unused]] bool primed = false;
     // issue the DMA of K-step kt of the load tile into LDS buffer `buf`
     auto load_tile = [&](int kt, int buf, int parts = 3) {       // parts: bit 0 = activation rows, bit 1 = weight rows
+        if (VCX_DMA_ABL & 3) {                                    // (timing only, vcx_ablate.h: no activation / no weight DMA behind the kernel's first K-step)
+            if (primed) parts &= ~(VCX_DMA_ABL & 3);
+            primed = true;
+        }
         half_t* dx = sX + buf * TBM * BK + wave * 8 * BK;
         half_t* dw = sW + buf * BN * BK + wave * 8 * BK;
         if (TAIL && CONV && (parts & 1) && kt >= nk_main) {
@@ -160,7 +165,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
                     const unsigned v = ok ? xoff[i] + oy_ + ox_ + cb : OOB;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(dx + RSTEP * i * BK), 16, v, 0, 0, 0);
                 }
-            } else {
+            } else if (!(VCX_CONV_XSKIP_ABL && p.kw == 3 && tkx != 0)) {      // (timing-only ablation: the activation rows of 2 of 3 horizontal taps are not fetched)
 #pragma unroll
                 for (int i = 0; i < XROWS; ++i) {
                     const unsigned ok = (xmask[i] >> tap) & 1u;
@@ -257,22 +262,29 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
         // one exposed LDS round trip per MFMA group - and on gfx950 nothing else runs on the SIMD while it waits:
         // tools/ubench.hip shows MFMA and VALU/other issue of the two waves of a SIMD do not overlap.)
         {
+            constexpr bool NOREAD = (VCX_DMA_ABL & 8) != 0;       // (timing only: the fragments of the kernel's first K-step stay in their registers)
             h8 xf[MFRAG];
 #pragma unroll
             for (int b = 0; b < MFRAG; ++b) xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(wm * WM + b * 16 + lr, lg));
             h8 wcur = *reinterpret_cast<const h8*>(cw + lds_off(wn * WN + lr, lg));
+            if (NOREAD) {
+#pragma unroll
+                for (int b = 0; b < MFRAG; ++b) asm volatile("" : "+v"(xf[b]));
+                asm volatile("" : "+v"(wcur));
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 if (kk == 1 && more && late_parts) load_tile(lkt, cur ^ 1, late_parts);
 #pragma unroll
                 for (int a = 0; a < NFRAG; ++a) {
                     h8 wnext = wcur;
-                    if (a + 1 < NFRAG) wnext = *reinterpret_cast<const h8*>(cw + lds_off(wn * WN + (a + 1) * 16 + lr, kk * 4 + lg));
+                    if (NOREAD) asm volatile("" : "+v"(wnext));
+                    else if (a + 1 < NFRAG) wnext = *reinterpret_cast<const h8*>(cw + lds_off(wn * WN + (a + 1) * 16 + lr, kk * 4 + lg));
                     else if (kk == 0) wnext = *reinterpret_cast<const h8*>(cw + lds_off(wn * WN + lr, 4 + lg));
 #pragma unroll
                     for (int b = 0; b < MFRAG; ++b) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur, xf[b], acc[a][b], 0, 0, 0);
-                        if (a == NFRAG - 1 && kk == 0)
+                        if (a == NFRAG - 1 && kk == 0 && !NOREAD)
                             xf[b] = *reinterpret_cast<const h8*>(cx + lds_off(wm * WM + b * 16 + lr, 4 + lg));
                     }
                     wcur = wnext;
@@ -290,8 +302,10 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) gemm_dma_kernel(GemmArgs p, u
                 for (int b = 0; b < MFRAG; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
         }
         // the DMA of the next K-step must have landed, and every wave must be done reading `cur`, before the roles swap
-        __builtin_amdgcn_s_waitcnt(0x0f70 | 0);
-        __syncthreads();
+        if (!(VCX_DMA_ABL & 16)) {                                // (timing only: no wait, no barrier)
+            __builtin_amdgcn_s_waitcnt(0x0f70 | 0);
+            __syncthreads();
+        }
         cur ^= 1;
         if (++ckt == nk) {
             ckt = 0;

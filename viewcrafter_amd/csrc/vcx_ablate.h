@@ -15,6 +15,13 @@
 #ifndef VCX_WL_ABL      // gemm_ws320_lnf_kernel, timing only (tools/ws_lnf_ab.py), bits: 1 no arithmetic chunks, 2 no MFMAs, 8 no stores
 #define VCX_WL_ABL 0
 #endif
+// gemm_dma.hip
+#ifndef VCX_CONV_XSKIP_ABL   // timing only: a 3x3 convolution fetches the activation rows of its horizontal centre taps only (what one LDS image per (slab, ky)
+#define VCX_CONV_XSKIP_ABL 0 // serving all three kx by row-shifted fragment reads would save in DMA: the upper bound of that change)
+#endif
+#ifndef VCX_DMA_ABL          // gemm_dma_kernel's main loop, timing only (tools/calls/r06_call13.sh), bits: 1 no activation DMA / 2 no weight DMA behind the
+#define VCX_DMA_ABL 0        // kernel's first K-step, 8 no fragment reads (the first K-step's fragments stay in registers), 16 no DMA wait / barrier per K-step
+#endif
 // attention.hip
 #ifndef XABL            // xattn_resident2_d64_kernel, timing only (tools/xattn_ablate.py), bits: 1 no exp2, 2 no softmax arithmetic, 4 no MFMAs,
 #define XABL 0          // 8 no Q loads / O stores, 16 no fragment reads, 32 no deferred-max test
