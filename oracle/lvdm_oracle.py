@@ -176,13 +176,15 @@ def transformer_block(sd, p, x, context, heads, image_cross_attention):
 
 
 def spatial_transformer(sd, p, x, context, heads, depth=1):
-    """attention.py:294-310 with use_linear=True.  x [(b t), c, h, w]; context [(b t), L, ctx_dim]."""
+    """attention.py:294-310.  x [(b t), c, h, w]; context [(b t), L, ctx_dim].  proj_in / proj_out are Linear (use_linear=True) or 1x1
+    Conv2d (:266-267, :287-288, applied on the NCHW tensor at :300 / :309) - the same matmul on a [.., C] row."""
     n, c, h, w = x.shape
     t = _gn(sd, p + ".norm", x, 1e-6).permute(0, 2, 3, 1).reshape(n, h * w, c)
-    t = _lin(sd, p + ".proj_in", t)
+    w_in, w_out = sd[p + ".proj_in.weight"], sd[p + ".proj_out.weight"]
+    t = F.linear(t, w_in.reshape(w_in.shape[0], -1), sd[p + ".proj_in.bias"])
     for i in range(depth):
         t = transformer_block(sd, f"{p}.transformer_blocks.{i}", t, context, heads, True)
-    t = _lin(sd, p + ".proj_out", t)
+    t = F.linear(t, w_out.reshape(w_out.shape[0], -1), sd[p + ".proj_out.bias"])
     return t.view(n, h, w, c).permute(0, 3, 1, 2) + x
 
 

@@ -154,6 +154,24 @@ def gen_unet_ssn(out):
         print("unet ssn", tuple(y.shape), float(y.abs().mean()))
 
 
+def gen_unet_conv1x1(out):
+    """The same tiny graph with use_linear=False (attention.py:266-267, 287-288, 331-336: proj_in / proj_out of both transformer kinds as
+    1x1 Conv2d / Conv1d instead of Linear) - not used by the two shipped YAMLs, accepted by the reference's constructor, so accepted here."""
+    from lvdm.modules.networks.openaimodel3d import UNetModel
+    torch.manual_seed(0)
+    unet = UNetModel(**dict(TINY_UNET, use_linear=False)).eval()
+    shapes = load_synth(unet)
+    out["unet_keys"] = np.array(sorted(shapes.keys()))
+    out["unet_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    with torch.no_grad():
+        b, t, h, w, L = 2, 3, 16, 32, 77 + 40
+        x = synth_input("unet_c11_x", (b, 8, t, h, w))
+        ctx = synth_input("unet_c11_ctx", (b, L, TINY_UNET["context_dim"]))
+        y = unet(x, torch.tensor([999, 399]), context=ctx, fs=torch.tensor([10, 3]))
+        out["unet_out"] = y.numpy()
+        print("unet conv1x1", tuple(y.shape), float(y.abs().mean()))
+
+
 def adapter_features(b, t, h, w, mc=TINY_UNET["model_channels"], mult=TINY_UNET["channel_mult"]):
     """What a T2I-adapter hands to UNetModel.forward(features_adapter=...): one [(b t), C, h, w] map per level, added behind input
     blocks 2, 5, 8, 11 (openaimodel3d.py:582-588)."""
@@ -499,7 +517,7 @@ def main():
         print("transformers not importable:", e)
     import_reference()
     torch.set_num_threads(8)
-    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("unet_tiny_adapter", gen_unet_adapter), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
+    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("unet_tiny_conv1x1", gen_unet_conv1x1), ("unet_tiny_adapter", gen_unet_adapter), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
                      ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs),
                      ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli), ("api_signatures", gen_api), ("reference_yaml", gen_yaml)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:

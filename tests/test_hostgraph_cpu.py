@@ -243,6 +243,27 @@ def test_host_graph_with_scale_shift_norm_vs_reference_golden(monkeypatch):
     assert e <= UNET_TOL
 
 
+def test_host_graph_with_conv1x1_projections_vs_reference_golden(monkeypatch):
+    """use_linear=False: SpatialTransformer / TemporalTransformer projections as 1x1 Conv2d / Conv1d parameters (strict state-dict names and
+    shapes of the reference), packed as the same [out, in] matrices."""
+    import numpy as np
+    import os
+    cpu_kernels.install(monkeypatch)
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    m = UNetModel(**dict(TINY_UNET, use_linear=False)).eval()
+    load_synth(m)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_conv1x1.npz"))
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g["unet_keys"]]
+    assert [str(tuple(m.state_dict()[str(k)].shape)) for k in g["unet_keys"]] == [str(s) for s in g["unet_shapes"]]
+    x = synth_input("unet_c11_x", (2, 8, 3, 16, 32))
+    ctx = synth_input("unet_c11_ctx", (2, 77 + 40, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = m(x, torch.tensor([999, 399]), context=ctx, fs=torch.tensor([10, 3]))
+    e = rel_l2(y, g["unet_out"])
+    print(f"host graph with use_linear=False vs the reference golden: {e:.3e}")
+    assert e <= UNET_TOL
+
+
 def test_host_graph_with_features_adapter_vs_reference_golden(monkeypatch):
     """UNetModel.forward(features_adapter=[...]) (reference openaimodel3d.py:582-588), also under the shared CFG prefix (the maps are
     given once per video and shared by the r evaluations); a list of the wrong length is refused like the reference's assert."""

@@ -81,6 +81,23 @@ def test_unet_with_scale_shift_norm_vs_reference_golden():
     assert e <= UNET_TOL
 
 
+def test_unet_with_conv1x1_projections_vs_reference_golden():
+    """use_linear=False (reference attention.py:266-267, 287-288, 331-336; golden by the reference's own UNetModel): the transformers'
+    proj_in / proj_out as 1x1 convolutions - the same kernels on the same [out, in] matrices, parameters in the reference's shapes."""
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    m = UNetModel(**dict(TINY_UNET, use_linear=False)).eval()
+    load_synth(m)
+    m = m.to(DEV)
+    g = golden("unet_tiny_conv1x1")
+    x = synth_input("unet_c11_x", (2, 8, 3, 16, 32)).to(DEV)
+    ctx = synth_input("unet_c11_ctx", (2, 77 + 40, TINY_UNET["context_dim"])).to(DEV)
+    with torch.no_grad():
+        y = m(x, torch.tensor([999, 399], device=DEV), context=ctx, fs=torch.tensor([10, 3], device=DEV))
+    e = rel_l2(y, g["unet_out"])
+    print(f"unet with use_linear=False: rel-L2 vs reference = {e:.3e}")
+    assert e <= UNET_TOL
+
+
 def test_unet_with_features_adapter_vs_reference_golden(unet):
     """features_adapter (reference openaimodel3d.py:582-588): adapter maps in the reference's own [(b t), C, h, w] layout, added
     behind input blocks 2, 5, 8, 11 by vcx_add_nchw_f32_to_nhwc_f16; golden by the reference's own forward."""

@@ -294,6 +294,20 @@ def test_oracle_unet_with_scale_shift_norm_matches_reference():
     assert np.abs(y.numpy() - g["unet_out"]).max() <= 2e-5 * np.abs(g["unet_out"]).max() + 1e-6
 
 
+def test_oracle_unet_with_conv1x1_projections_matches_reference():
+    """use_linear=False (reference attention.py:266-267, 287-288, 331-336: proj_in / proj_out as 1x1 Conv2d / Conv1d) - not used by the shipped
+    YAMLs, accepted by the reference's constructor: golden written by the reference's own UNetModel with that flag (gen_golden.py::gen_unet_conv1x1)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_conv1x1.npz"))
+    shapes = {str(k): eval(str(s)) for k, s in zip(g["unet_keys"], g["unet_shapes"])}
+    assert shapes["input_blocks.1.1.proj_in.weight"][2:] == (1, 1) and len(shapes["input_blocks.1.2.proj_in.weight"]) == 3
+    sd = synth_state_dict(shapes)
+    x = synth_input("unet_c11_x", (2, 8, 3, 16, 32))
+    ctx = synth_input("unet_c11_ctx", (2, 77 + 40, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = O.unet_forward(sd, dict(TINY_UNET, use_linear=False), x, torch.tensor([999, 399]), ctx, torch.tensor([10, 3]))
+    assert np.abs(y.numpy() - g["unet_out"]).max() <= 2e-5 * np.abs(g["unet_out"]).max() + 1e-6
+
+
 def _adapter_features(b, t, h, w):
     return [synth_input(f"adapter_{i}", (b * t, TINY_UNET["model_channels"] * m, h >> i, w >> i), scale=0.5)
             for i, m in enumerate(TINY_UNET["channel_mult"])]

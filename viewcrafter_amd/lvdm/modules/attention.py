@@ -324,20 +324,20 @@ def project_context(attn2, ctx):
 
 
 class SpatialTransformer(PackedModule):
-    """Reference attention.py:249-310 (use_linear=True): GN(eps 1e-6) -> proj_in -> [LN, self-attn, LN, text (+) image
+    """Reference attention.py:249-310 (use_linear=True, or False = 1x1 Conv2d projections): GN(eps 1e-6) -> proj_in -> [LN, self-attn, LN, text (+) image
     cross-attn, LN, GEGLU-FF] -> proj_out -> + x."""
 
     def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None, use_checkpoint=True,
                  disable_self_attn=False, use_linear=False, video_length=None, image_cross_attention=False,
                  image_cross_attention_scale_learnable=False):
         super().__init__()
-        if not use_linear:
-            raise NotImplementedError("the ViewCrafter configs set use_linear: true (1x1-conv projections unsupported)")
         self.in_channels = in_channels
         inner_dim = n_heads * d_head
         self.n_heads = n_heads
         self.norm = nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
-        self.proj_in = nn.Linear(in_channels, inner_dim)
+        # use_linear=False (reference attention.py:266-267, 287-288; not used by the ViewCrafter YAMLs): 1x1 Conv2d projections - the same
+        # matmul on a channels-last row; the parameters keep the reference's [out, in, 1, 1] shape so a checkpoint loads strictly
+        self.proj_in = nn.Linear(in_channels, inner_dim) if use_linear else nn.Conv2d(in_channels, inner_dim, kernel_size=1, stride=1, padding=0)
         self.transformer_blocks = nn.ModuleList([
             BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim,
                                   disable_self_attn=disable_self_attn, checkpoint=use_checkpoint, attention_cls=None,
@@ -346,14 +346,16 @@ class SpatialTransformer(PackedModule):
             for _ in range(depth)])
         for blk in self.transformer_blocks:
             blk.set_kind("spatial")
-        self.proj_out = nn.Linear(inner_dim, in_channels)
+        self.proj_out = nn.Linear(inner_dim, in_channels) if use_linear else nn.Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0)
         nn.init.zeros_(self.proj_out.weight)
         nn.init.zeros_(self.proj_out.bias)
         self.use_linear = use_linear
 
     def _pack(self):
-        return dict(gn_w=_f32(self.norm.weight), gn_b=_f32(self.norm.bias), win=_f16(self.proj_in.weight), win32=_f32(self.proj_in.weight),
-                    bin=_f32(self.proj_in.bias), wout=_f16(self.proj_out.weight), bout=_f32(self.proj_out.bias))
+        win = self.proj_in.weight.detach().reshape(self.proj_in.weight.shape[0], -1)       # ([out, in, 1, 1] of the 1x1-conv form)
+        wout = self.proj_out.weight.detach().reshape(self.proj_out.weight.shape[0], -1)
+        return dict(gn_w=_f32(self.norm.weight), gn_b=_f32(self.norm.bias), win=_f16(win), win32=_f32(win),
+                    bin=_f32(self.proj_in.bias), wout=_f16(wout), bout=_f32(self.proj_out.bias))
 
     def project_context(self, ctx):
         return [project_context(blk.attn2, ctx) for blk in self.transformer_blocks]
