@@ -38,7 +38,7 @@ extern "C" {
  * vcx_add_nchw_f32_to_nhwc_f16.  6: vcx_ddim_ws_bytes, ws_bytes argument of the DDIM steps.  7: vcx_groupnorm_fold_linear_f16,
  * vcx_gemm_units_f16, vcx_attn_flash_d512_f16.  8: vcx_gemm_desc grows rowstats / rowstats_eps (VCX_GEMM_ROWSTATS) and
  * tail_a0 / tail_a1 (K tail of a convolution from linear sources); vcx_groupnorm_apply2_f16. */
-#define VCX_ABI_VERSION 8
+#define VCX_ABI_VERSION 9
 
 int vcx_abi_version(void);
 const char* vcx_last_error(void);
@@ -285,6 +285,12 @@ int vcx_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream);
  * openaimodel3d.py:596). cols, ldd, lds multiples of 8. */
 int vcx_copy2d_f16(const void* src, void* dst, int64_t rows, int cols, int64_t lds, int64_t ldd,
                    void* stream);
+/* ABI 9.  2x2 average pool / nearest 2x of a channels-last fp16 image batch: y[n][H/2][W/2][C] = mean of the 2x2 window (fp32 sum, one
+ * rounding; odd H / W drop the last row / column) and y[n][2H][2W][C] = x[n][y/2][x/2][C].  C % 8 == 0.  The sampling halves of the
+ * reference's ResBlock(up / down) - `h_upd` / `x_upd`, openaimodel3d.py:160-165, 210-215 (`resblock_updown: true`) - and of Downsample /
+ * Upsample without a convolution (`conv_resample: false`, openaimodel3d.py:70-72, 98-103); neither is used by the ViewCrafter YAMLs. */
+int vcx_avgpool2x2_f16(const void* x, void* y, int n, int H, int W, int C, void* stream);
+int vcx_upsample2x_f16(const void* x, void* y, int n, int H, int W, int C, void* stream);
 /* h[n][p][c] += src[n][c][p] (h fp16 channels-last [n, HW, C], src fp32 [n, C, HW]): the adapter feature maps the reference adds
  * behind every third input block when `features_adapter` is given (openaimodel3d.py:582-585). */
 int vcx_add_nchw_f32_to_nhwc_f16(const float* src, void* h, int n, int C, int64_t HW, void* stream);

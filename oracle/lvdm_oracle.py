@@ -212,12 +212,18 @@ def temporal_conv_block(sd, p, x):
     return x + y
 
 
-def res_block(sd, p, x, emb, batch, temporal_conv=True):
-    """openaimodel3d.py:210-236 (no up/down): GN->SiLU->conv3x3, + Linear(SiLU(emb)), GN->SiLU->conv3x3, + skip (identity or
+def res_block(sd, p, x, emb, batch, temporal_conv=True, updown=None):
+    """openaimodel3d.py:210-236: GN->SiLU->conv3x3, + Linear(SiLU(emb)), GN->SiLU->conv3x3, + skip (identity or
     1x1 conv), then the TemporalConvBlock on 'b c t h w'.  use_scale_shift_norm (:221-225: emb_layers emits 2 x C_out and the
-    second norm becomes norm(h) * (1 + scale) + shift) is recognised by the shape of emb_layers.1.weight."""
-    h = F.conv2d(F.silu(_gn(sd, p + ".in_layers.0", x, 1e-5)), sd[p + ".in_layers.2.weight"], sd[p + ".in_layers.2.bias"],
-                 padding=1)
+    second norm becomes norm(h) * (1 + scale) + shift) is recognised by the shape of emb_layers.1.weight.
+    updown = "up" / "down" (:210-215, ResBlock(up=True / down=True) of `resblock_updown`): h_upd between SiLU and the convolution, x_upd
+    on the skip path - nearest 2x (:98-103) / AvgPool2d(2, 2) (:70-72), no parameters."""
+    h = F.silu(_gn(sd, p + ".in_layers.0", x, 1e-5))
+    if updown == "up":
+        h, x = F.interpolate(h, scale_factor=2, mode="nearest"), F.interpolate(x, scale_factor=2, mode="nearest")
+    elif updown == "down":
+        h, x = F.avg_pool2d(h, 2, 2), F.avg_pool2d(x, 2, 2)
+    h = F.conv2d(h, sd[p + ".in_layers.2.weight"], sd[p + ".in_layers.2.bias"], padding=1)
     emb_out = _lin(sd, p + ".emb_layers.1", F.silu(emb))[:, :, None, None]
     cout = sd[p + ".out_layers.3.weight"].shape[0]
     if emb_out.shape[1] == 2 * cout:
@@ -258,7 +264,7 @@ def unet_layout(hp):
                     layers.append(("tt", ch, ch // dh))
             inputs.append(layers)
         if level != len(mult) - 1:
-            inputs.append([("down", ch, 0)])
+            inputs.append([("res_down" if hp.get("resblock_updown", False) else "down" if hp.get("conv_resample", True) else "down_pool", ch, 0)])
             ds *= 2
     middle = [("res", ch, 0), ("st", ch, ch // dh)] + ([("tt", ch, ch // dh)] if tattn else []) + [("res", ch, 0)]
     outputs = []
@@ -271,7 +277,7 @@ def unet_layout(hp):
                 if tattn:
                     layers.append(("tt", ch, ch // dh))
             if level and i == nrb:
-                layers.append(("up", ch, 0))
+                layers.append(("res_up" if hp.get("resblock_updown", False) else "up" if hp.get("conv_resample", True) else "up_nearest", ch, 0))
                 ds //= 2
             outputs.append(layers)
     return inputs, middle, outputs
@@ -292,6 +298,12 @@ def _run_layers(sd, prefix, layers, h, emb, context, batch):
             h5 = h.view(batch, n // batch, c, hh, ww).permute(0, 2, 1, 3, 4)
             h5 = temporal_transformer(sd, p, h5, heads)
             h = h5.permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)
+        elif kind in ("res_down", "res_up"):    # resblock_updown, openaimodel3d.py:441-451, 529-538 (no temporal convolution in these blocks)
+            h = res_block(sd, p, h, emb, batch, updown=kind[4:])
+        elif kind == "down_pool":               # Downsample(use_conv=False), openaimodel3d.py:70-72
+            h = F.avg_pool2d(h, 2, 2)
+        elif kind == "up_nearest":              # Upsample(use_conv=False), openaimodel3d.py:98-103
+            h = F.interpolate(h, scale_factor=2, mode="nearest")
         elif kind == "down":   # Downsample, openaimodel3d.py:51-77: conv3x3 stride 2 pad 1
             h = F.conv2d(h, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=2, padding=1)
         elif kind == "up":     # Upsample, openaimodel3d.py:98-106: nearest 2x then conv3x3

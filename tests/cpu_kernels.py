@@ -233,6 +233,14 @@ def copy2d(src, dst, rows, cols, lds, ldd):
     _view2d(dst, rows, cols, ldd).copy_(_view2d(src, rows, cols, lds))
 
 
+def avgpool2x2(x):
+    return F.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).to(_f16).contiguous()
+
+
+def upsample2x(x):
+    return F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1).contiguous()
+
+
 def add_nchw_(h, feat):
     h.copy_((h.float() + feat.float().permute(0, 2, 3, 1)).to(_f16))
     return h
@@ -267,7 +275,7 @@ def install(monkeypatch):
     table = dict(require_gpu=lambda: None, gemm=gemm, group_norm_stats_from_colstats=group_norm_stats_from_colstats, group_norm=group_norm,
                  group_norm_stats=group_norm_stats, group_norm_fold_linear=group_norm_fold_linear, gemm_units=gemm_units,
                  row_stats=row_stats, layer_norm=layer_norm, conv_tail_ok=conv_tail_ok, flash_attn=flash_attn, flash_attn_d512=flash_attn_d512, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn,
-                 softmax_rows_=softmax_rows_, copy2d=copy2d, add_nchw_=add_nchw_, ncthw_to_nthwc=ncthw_to_nthwc, nthwc_to_ncthw=nthwc_to_ncthw,
+                 softmax_rows_=softmax_rows_, copy2d=copy2d, avgpool2x2=avgpool2x2, upsample2x=upsample2x, add_nchw_=add_nchw_, ncthw_to_nthwc=ncthw_to_nthwc, nthwc_to_ncthw=nthwc_to_ncthw,
                  timestep_embedding=timestep_embedding, silu_f32=lambda x: F.silu(x.float()), gelu_=lambda x: x.copy_(F.gelu(x.float()).to(_f16)),
                  to_f16=lambda x: x.to(_f16).contiguous(), to_f32=lambda x: x.float().contiguous(),
                  tune_get=lambda name: _TUNE.get(name, _lib.TUNE[name][1]),

@@ -172,6 +172,33 @@ def gen_unet_conv1x1(out):
         print("unet conv1x1", tuple(y.shape), float(y.abs().mean()))
 
 
+def _gen_unet_variant(out, tag, **flags):
+    from lvdm.modules.networks.openaimodel3d import UNetModel
+    torch.manual_seed(0)
+    unet = UNetModel(**dict(TINY_UNET, **flags)).eval()
+    shapes = load_synth(unet)
+    out["unet_keys"] = np.array(sorted(shapes.keys()))
+    out["unet_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    with torch.no_grad():
+        b, t, h, w, L = 2, 3, 16, 32, 77 + 40
+        x = synth_input(f"unet_{tag}_x", (b, 8, t, h, w))
+        ctx = synth_input(f"unet_{tag}_ctx", (b, L, TINY_UNET["context_dim"]))
+        y = unet(x, torch.tensor([999, 399]), context=ctx, fs=torch.tensor([10, 3]))
+        out["unet_out"] = y.numpy()
+        print("unet", tag, flags, tuple(y.shape), float(y.abs().mean()))
+
+
+def gen_unet_updown(out):
+    """resblock_updown=True (openaimodel3d.py:441-451, 529-538: ResBlock(down=True) / ResBlock(up=True) - AvgPool2d / nearest 2x between SiLU and
+    the first convolution and on the skip path - in the place of the strided / post-interpolation convolutions); not used by the shipped YAMLs."""
+    _gen_unet_variant(out, "ud", resblock_updown=True)
+
+
+def gen_unet_noconv(out):
+    """conv_resample=False (openaimodel3d.py:70-72, 98-103: Downsample = AvgPool2d(2, 2), Upsample = nearest 2x, no parameters); not used by the shipped YAMLs."""
+    _gen_unet_variant(out, "nc", conv_resample=False)
+
+
 def adapter_features(b, t, h, w, mc=TINY_UNET["model_channels"], mult=TINY_UNET["channel_mult"]):
     """What a T2I-adapter hands to UNetModel.forward(features_adapter=...): one [(b t), C, h, w] map per level, added behind input
     blocks 2, 5, 8, 11 (openaimodel3d.py:582-588)."""
@@ -517,7 +544,7 @@ def main():
         print("transformers not importable:", e)
     import_reference()
     torch.set_num_threads(8)
-    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("unet_tiny_conv1x1", gen_unet_conv1x1), ("unet_tiny_adapter", gen_unet_adapter), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
+    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("unet_tiny_conv1x1", gen_unet_conv1x1), ("unet_tiny_updown", gen_unet_updown), ("unet_tiny_noconv", gen_unet_noconv), ("unet_tiny_adapter", gen_unet_adapter), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
                      ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs),
                      ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli), ("api_signatures", gen_api), ("reference_yaml", gen_yaml)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:

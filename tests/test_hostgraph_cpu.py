@@ -264,6 +264,33 @@ def test_host_graph_with_conv1x1_projections_vs_reference_golden(monkeypatch):
     assert e <= UNET_TOL
 
 
+@pytest.mark.parametrize("level", [2, 0])
+@pytest.mark.parametrize("name,tag,flags", [("unet_tiny_updown", "ud", dict(resblock_updown=True)), ("unet_tiny_noconv", "nc", dict(conv_resample=False))])
+def test_host_graph_with_sampling_variants_vs_reference_golden(monkeypatch, name, tag, flags, level):
+    """resblock_updown=True: ResBlock(down / up) - AvgPool2d / nearest 2x between SiLU and the first convolution (up: the convolution's fused
+    gather) and on the skip path - in the place of the resampling convolutions; conv_resample=False: the resampling layers without a
+    convolution (their results copied into the up path's concat targets).  Same state-dict keys as the reference's modules."""
+    import numpy as np
+    import os
+    cpu_kernels.install(monkeypatch)
+    from viewcrafter_amd.lvdm.modules import attention, flow
+    from viewcrafter_amd.lvdm.modules.networks import openaimodel3d as om
+    for mod in (flow, attention, om):
+        monkeypatch.setattr(mod, "GN_STATS_LEVEL", level, raising=False)
+        monkeypatch.setattr(mod, "GN_EPILOGUE_STATS", level >= 1, raising=False)
+    m = om.UNetModel(**dict(TINY_UNET, **flags)).eval()
+    load_synth(m)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g["unet_keys"]]
+    x = synth_input(f"unet_{tag}_x", (2, 8, 3, 16, 32))
+    ctx = synth_input(f"unet_{tag}_ctx", (2, 77 + 40, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = m(x, torch.tensor([999, 399]), context=ctx, fs=torch.tensor([10, 3]))
+    e = rel_l2(y, g["unet_out"])
+    print(f"host graph with {flags} (GN statistics level {level}) vs the reference golden: {e:.3e}")
+    assert y.shape == g["unet_out"].shape and e <= UNET_TOL
+
+
 def test_host_graph_with_features_adapter_vs_reference_golden(monkeypatch):
     """UNetModel.forward(features_adapter=[...]) (reference openaimodel3d.py:582-588), also under the shared CFG prefix (the maps are
     given once per video and shared by the r evaluations); a list of the wrong length is refused like the reference's assert."""

@@ -1570,3 +1570,18 @@ def test_clip_preprocess_kernel_vs_fp64_numpy(shape):
         assert out.dtype == torch.float32 and tuple(out.shape) == (B, C, 224, 224)
         err = float(np.abs(out.cpu().double().numpy() - ref).max())
         assert err <= 2e-5, f"{shape} antialias={aa}: max |diff| {err:.2e} (values up to {np.abs(ref).max():.2f})"
+
+
+@pytest.mark.parametrize("n,H,W,C", [(3, 16, 32, 64), (2, 9, 7, 320), (50, 72, 128, 320), (1, 2, 2, 8)])
+def test_avgpool2x2_and_upsample2x(n, H, W, C):
+    """vcx_avgpool2x2_f16 / vcx_upsample2x_f16 (ABI 9) against torch on the NCHW view: AvgPool2d(2, 2) - fp32 sum, one rounding, odd sizes drop the
+    last row / column - and F.interpolate(scale_factor=2, mode='nearest') (bit-exact: a copy)."""
+    from viewcrafter_amd import ops
+    torch.manual_seed(n * H + W + C)
+    x = (torch.randn(n, H, W, C, device=DEV) * 3 + 1).half()
+    y = ops.avgpool2x2(x)
+    ref = F.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert y.shape == (n, H // 2, W // 2, C)
+    assert torch.equal(y, ref.half())
+    u = ops.upsample2x(x)
+    assert torch.equal(u, F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1))

@@ -98,6 +98,24 @@ def test_unet_with_conv1x1_projections_vs_reference_golden():
     assert e <= UNET_TOL
 
 
+@pytest.mark.parametrize("name,tag,flags", [("unet_tiny_updown", "ud", dict(resblock_updown=True)), ("unet_tiny_noconv", "nc", dict(conv_resample=False))])
+def test_unet_sampling_variants_vs_reference_golden(name, tag, flags):
+    """resblock_updown=True (reference openaimodel3d.py:441-451, 529-538, 210-215) and conv_resample=False (:70-72, 98-103); goldens by the
+    reference's own UNetModel: vcx_avgpool2x2_f16 / vcx_upsample2x_f16 (ABI 9) and the fused nearest-2x gather of the convolution."""
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    m = UNetModel(**dict(TINY_UNET, **flags)).eval()
+    load_synth(m)
+    m = m.to(DEV)
+    g = golden(name)
+    x = synth_input(f"unet_{tag}_x", (2, 8, 3, 16, 32)).to(DEV)
+    ctx = synth_input(f"unet_{tag}_ctx", (2, 77 + 40, TINY_UNET["context_dim"])).to(DEV)
+    with torch.no_grad():
+        y = m(x, torch.tensor([999, 399], device=DEV), context=ctx, fs=torch.tensor([10, 3], device=DEV))
+    e = rel_l2(y, g["unet_out"])
+    print(f"unet with {flags}: rel-L2 vs reference = {e:.3e}")
+    assert e <= UNET_TOL
+
+
 def test_unet_with_features_adapter_vs_reference_golden(unet):
     """features_adapter (reference openaimodel3d.py:582-588): adapter maps in the reference's own [(b t), C, h, w] layout, added
     behind input blocks 2, 5, 8, 11 by vcx_add_nchw_f32_to_nhwc_f16; golden by the reference's own forward."""

@@ -308,6 +308,20 @@ def test_oracle_unet_with_conv1x1_projections_matches_reference():
     assert np.abs(y.numpy() - g["unet_out"]).max() <= 2e-5 * np.abs(g["unet_out"]).max() + 1e-6
 
 
+@pytest.mark.parametrize("name,tag,flags", [("unet_tiny_updown", "ud", dict(resblock_updown=True)), ("unet_tiny_noconv", "nc", dict(conv_resample=False))])
+def test_oracle_unet_sampling_variants_match_reference(name, tag, flags):
+    """resblock_updown=True (reference openaimodel3d.py:441-451, 529-538, 210-215) and conv_resample=False (:70-72, 98-103) - not used by the
+    shipped YAMLs, accepted by the reference's constructor: goldens written by the reference's own UNetModel (gen_golden.py::_gen_unet_variant)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    shapes = {str(k): eval(str(s)) for k, s in zip(g["unet_keys"], g["unet_shapes"])}
+    sd = synth_state_dict(shapes)
+    x = synth_input(f"unet_{tag}_x", (2, 8, 3, 16, 32))
+    ctx = synth_input(f"unet_{tag}_ctx", (2, 77 + 40, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = O.unet_forward(sd, dict(TINY_UNET, **flags), x, torch.tensor([999, 399]), ctx, torch.tensor([10, 3]))
+    assert np.abs(y.numpy() - g["unet_out"]).max() <= 2e-5 * np.abs(g["unet_out"]).max() + 1e-6
+
+
 def _adapter_features(b, t, h, w):
     return [synth_input(f"adapter_{i}", (b * t, TINY_UNET["model_channels"] * m, h >> i, w >> i), scale=0.5)
             for i, m in enumerate(TINY_UNET["channel_mult"])]

@@ -17,11 +17,11 @@ SYMBOLS = [
     "vcx_groupnorm_ws_bytes", "vcx_groupnorm_stats_f16", "vcx_groupnorm_apply_f16", "vcx_groupnorm_apply2_f16", "vcx_groupnorm_stats_from_colstats_f32", "vcx_groupnorm_fold_linear_f16", "vcx_layernorm_f16", "vcx_rowstats_f16",
     "vcx_attn_flash_d64_f16", "vcx_attn_flash_d512_f16", "vcx_attn_flash_dual_d64_f16", "vcx_attn_temporal_d64_f16", "vcx_softmax_rows_f16",
     "vcx_silu_f32", "vcx_gelu_f16", "vcx_clip_preprocess_f32", "vcx_add_nchw_f32_to_nhwc_f16", "vcx_timestep_embedding_f32", "vcx_cast_f32_to_f16", "vcx_cast_f16_to_f32",
-    "vcx_copy2d_f16", "vcx_ncthw_f32_to_nthwc_f16", "vcx_nthwc_to_ncthw_f32", "vcx_ddim_ws_bytes", "vcx_ddim_step_f32", "vcx_ddim_step3_f32",
+    "vcx_copy2d_f16", "vcx_avgpool2x2_f16", "vcx_upsample2x_f16", "vcx_ncthw_f32_to_nthwc_f16", "vcx_nthwc_to_ncthw_f32", "vcx_ddim_ws_bytes", "vcx_ddim_step_f32", "vcx_ddim_step3_f32",
     "vcx_profile_begin", "vcx_profile_end", "vcx_tune_set", "vcx_tune_get",
 ]
 
-ABI_VERSION = 8          # include/vcx.h VCX_ABI_VERSION
+ABI_VERSION = 9          # include/vcx.h VCX_ABI_VERSION
 # experiment knobs (include/vcx.h VCX_TUNE_*): name -> (index, default)
 TUNE = {"GEMM_CFG": (0, -1), "GEMM_DMA": (1, 1), "FLASH_QB": (2, 0), "XATTN_RESIDENT": (3, 1), "FLASH_IMPL": (4, 0), "EXP0": (5, 0),
         "EXP1": (6, 0), "GEMM_WS": (7, 1)}
@@ -106,6 +106,8 @@ def lib():
     L.vcx_cast_f32_to_f16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
     L.vcx_cast_f16_to_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
     L.vcx_copy2d_f16.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p]
+    L.vcx_avgpool2x2_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    L.vcx_upsample2x_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     L.vcx_ncthw_f32_to_nthwc_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_float,
                                              c_void_p]
     L.vcx_nthwc_to_ncthw_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]

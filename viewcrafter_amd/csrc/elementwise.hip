@@ -297,6 +297,64 @@ extern "C" int vcx_gelu_f16(const void* x, void* y, int64_t n, void* stream) {
     return vcx_check_launch("vcx_gelu_f16");
 }
 
+namespace {
+
+// 2x2 average pool / nearest 2x of a channels-last fp16 image batch [n][H][W][C], eight channels (16 bytes) per thread.  The pool sums in fp32 and
+// rounds once (what torch's avg_pool2d does for half inputs); odd H / W drop the last row / column like AvgPool2d(2, 2).
+__global__ void avgpool2x2_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int H, int W, int C8, int64_t total) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        int64_t r = i / C8;
+        const int xo = (int)(r % Wo);
+        r /= Wo;
+        const int yo = (int)(r % Ho);
+        const int64_t img = r / Ho;
+        const half_t* src = x + (((img * H + 2 * yo) * W + 2 * xo) * C8 + c) * 8;
+        const h8 a = *reinterpret_cast<const h8*>(src), b = *reinterpret_cast<const h8*>(src + (int64_t)C8 * 8);
+        const h8 d = *reinterpret_cast<const h8*>(src + (int64_t)W * C8 * 8), e = *reinterpret_cast<const h8*>(src + ((int64_t)W + 1) * C8 * 8);
+        h8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (half_t)(((float)a[k] + (float)b[k] + (float)d[k] + (float)e[k]) * 0.25f);
+        *reinterpret_cast<h8*>(y + i * 8) = o;
+    }
+}
+
+__global__ void upsample2x_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int H, int W, int C8, int64_t total) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        int64_t r = i / C8;
+        const int xo = (int)(r % Wo);
+        r /= Wo;
+        const int yo = (int)(r % Ho);
+        const int64_t img = r / Ho;
+        *reinterpret_cast<h8*>(y + i * 8) = *reinterpret_cast<const h8*>(x + (((img * H + (yo >> 1)) * W + (xo >> 1)) * C8 + c) * 8);
+    }
+}
+
+}  // namespace
+
+extern "C" int vcx_avgpool2x2_f16(const void* x, void* y, int n, int H, int W, int C, void* stream) {
+    VCX_REQUIRE(x && y && n > 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0, "vcx_avgpool2x2_f16: need H, W >= 2 and C %% 8 == 0 (H=%d W=%d C=%d)", H, W, C);
+    VCX_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "vcx_avgpool2x2_f16: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)n * (H / 2) * (W / 2) * (C / 8);
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 2.0 * n * (double)H * W * C + 16.0 * total);
+    hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, s, (const half_t*)x, (half_t*)y, H, W, C / 8, total);
+    return vcx_check_launch("vcx_avgpool2x2_f16");
+}
+
+extern "C" int vcx_upsample2x_f16(const void* x, void* y, int n, int H, int W, int C, void* stream) {
+    VCX_REQUIRE(x && y && n > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "vcx_upsample2x_f16: need C %% 8 == 0 (C=%d)", C);
+    VCX_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "vcx_upsample2x_f16: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)n * (2 * H) * (2 * W) * (C / 8);
+    VcxProfScope prof(VCX_FAM_ELT, s, 0.0, 2.0 * n * (double)H * W * C + 16.0 * total);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, s, (const half_t*)x, (half_t*)y, H, W, C / 8, total);
+    return vcx_check_launch("vcx_upsample2x_f16");
+}
+
 extern "C" int vcx_silu_f32(const float* x, float* y, int64_t n, void* stream) {
     VCX_REQUIRE(x && y && n > 0, "vcx_silu_f32: bad arguments");
     hipStream_t s = (hipStream_t)stream;

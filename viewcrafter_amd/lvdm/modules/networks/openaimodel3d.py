@@ -70,10 +70,13 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 x, colstats = layer(x.view(batch_size, n // batch_size, H * W, C), colstats=colstats, want_colstats=want, target=target)
                 x = x.view(n, H, W, -1)
             elif isinstance(layer, (Downsample, Upsample)):
-                x, colstats = layer(x, want_colstats=want, target=target)
+                # (without a convolution - conv_resample: false - there is no epilogue to write moments or a concat target from: the plain result
+                # is copied into the target below, like any other layer that cannot write there)
+                x, colstats = layer(x, want_colstats=want, target=target if layer.use_conv else None)
             else:
                 x, colstats = layer(x), None
-            if target is not None and not isinstance(layer, (ResBlock, TemporalTransformer, Downsample, Upsample)):
+            if target is not None and (not isinstance(layer, (ResBlock, TemporalTransformer, Downsample, Upsample))
+                                       or (isinstance(layer, (Downsample, Upsample)) and not layer.use_conv)):
                 # a last layer that cannot write into a concat target (a SpatialTransformer in a graph without temporal attention, a
                 # bare convolution): its result is copied into the target's left columns, and the next norm makes its statistics pass
                 n_, H_, W_, C_ = x.shape
@@ -111,17 +114,24 @@ class Downsample(PackedModule):
 
     def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
         super().__init__()
-        if not use_conv or dims != 2 or padding != 1:
-            raise NotImplementedError("ViewCrafter uses conv_resample=True, dims=2")
+        if dims != 2 or padding != 1:
+            raise NotImplementedError("ViewCrafter uses dims=2")
         self.channels = channels
         self.out_channels = out_channels or channels
-        self.op = nn.Conv2d(self.channels, self.out_channels, 3, stride=2, padding=padding)
+        self.use_conv = use_conv
+        if use_conv:
+            self.op = nn.Conv2d(self.channels, self.out_channels, 3, stride=2, padding=padding)
+        else:       # conv_resample: false (reference openaimodel3d.py:70-72; not used by the ViewCrafter YAMLs): AvgPool2d(2, 2), no parameters
+            assert self.channels == self.out_channels
+            self.op = nn.AvgPool2d(kernel_size=2, stride=2)
 
     def _pack(self):
-        return dict(w=_f16(pack_conv(self.op.weight.detach())), b=_f32(self.op.bias))
+        return dict(w=_f16(pack_conv(self.op.weight.detach())), b=_f32(self.op.bias)) if self.use_conv else {}
 
     def forward(self, x, want_colstats=False, target=None):
         """-> (y [n, H/2, W/2, C] - or [.., ld] when written into a concat target -, column moments of y or None)"""
+        if not self.use_conv:
+            return ops.avgpool2x2(x), None
         pk = self.packed()
         n, H, W, cin = x.shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
@@ -135,16 +145,20 @@ class Upsample(PackedModule):
 
     def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
         super().__init__()
-        if not use_conv or dims != 2 or padding != 1:
-            raise NotImplementedError("ViewCrafter uses conv_resample=True, dims=2")
+        if dims != 2 or padding != 1:
+            raise NotImplementedError("ViewCrafter uses dims=2")
         self.channels = channels
         self.out_channels = out_channels or channels
-        self.conv = nn.Conv2d(self.channels, self.out_channels, 3, padding=padding)
+        self.use_conv = use_conv
+        if use_conv:
+            self.conv = nn.Conv2d(self.channels, self.out_channels, 3, padding=padding)
 
     def _pack(self):
-        return dict(w=_f16(pack_conv(self.conv.weight.detach())), b=_f32(self.conv.bias))
+        return dict(w=_f16(pack_conv(self.conv.weight.detach())), b=_f32(self.conv.bias)) if self.use_conv else {}
 
     def forward(self, x, want_colstats=False, target=None):
+        if not self.use_conv:      # conv_resample: false (reference openaimodel3d.py:98-103): the nearest 2x alone
+            return ops.upsample2x(x), None
         pk = self.packed()
         n, H, W, cin = x.shape
         kw, cs = _out_kwargs(target, want_colstats, n * 4 * H * W, 4 * H * W, cin, self.out_channels, x.device, in_rows=n * H * W)
@@ -214,8 +228,12 @@ class ResBlock(PackedModule, TimestepBlock):
                  use_checkpoint=False, use_conv=False, up=False, down=False, use_temporal_conv=False,
                  tempspatial_aware=False):
         super().__init__()
-        if up or down or use_conv or dims != 2:
+        if use_conv or dims != 2 or (up and down):
             raise NotImplementedError("ResBlock variant not used by the ViewCrafter configs")
+        # up / down (reference openaimodel3d.py:160-165, 210-215; `resblock_updown: true`, not used by the ViewCrafter YAMLs): the sampling sits
+        # between SiLU and the first convolution (h_upd) and on the skip path (x_upd), both without parameters
+        self.up, self.down = bool(up), bool(down)
+        self.updown = self.up or self.down
         self.channels, self.emb_channels = channels, emb_channels
         self.out_channels = out_channels or channels
         self.use_temporal_conv = use_temporal_conv
@@ -273,21 +291,33 @@ class ResBlock(PackedModule, TimestepBlock):
         c1, cin = cin, sum(tail_ks) if x2 is not None else x.shape[-1]
         stats_in = None if colstats is None else ops.group_norm_stats_from_colstats(colstats, n, H * W, cin)
         a = ops.group_norm(x.view(n, H * W, c1 if x2 is not None else cin), *pk["g1"], True, stats=stats_in, x2=None if x2 is None else x2.view(n, H * W, -1))
+        conv1_kw = {}
+        if self.updown:
+            if x2 is not None:
+                raise ValueError("an up / down ResBlock does not take a split concat")
+            a = a.view(n, H, W, cin)
+            if self.up:       # nearest 2x in front of the convolution = the convolution's fused gather; the skip path needs the tensor
+                conv1_kw, x, H, W = dict(ups=1), ops.upsample2x(x), 2 * H, 2 * W
+            else:
+                a, x, H, W = ops.avgpool2x2(a), ops.avgpool2x2(x), H // 2, W // 2
+            M = n * H * W
+            fold_skip = SKIP_FOLD and "ws" in pk and ops.conv_tail_ok(M, cout, cout, 9, [cin])
         # [B, Cout] fp32: this block's columns of the one projection UNetModel made of the embedding, or its own launch (a block used alone)
         emb_out = self._emb_all[:B] if self._emb_all is not None else ops.linear(emb, pk["we"], pk["be"], out_f32=True)
         # The norms behind this block's own convolutions take their statistics from those convolutions' epilogues (column moments
         # per 64-row strip, VCX_GEMM_COLSTATS) instead of a pass over the tensor: out_layers' norm (per frame) from conv 1, the
         # first norm of the temporal block (per video) from conv 2 - where frames are whole strips (not at 9x16 = 144 pixels).
-        cs1 = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and ops.colstats_ok(M, H * W, cin, cout)) else None
+        hin, win = a.shape[1:3] if self.updown else (H, W)       # the first convolution's INPUT grid (up: half the output's)
+        cs1 = ops.colstats_buffer(M, cout, x.device) if (GN_EPILOGUE_STATS and ops.colstats_ok(M, H * W, cin, cout, in_rows=n * hin * win)) else None
         if not self.use_scale_shift_norm:
-            h = ops.conv2d(a.view(n, H, W, cin), pk["w1"], pk["b1"], kh=3, kw=3, rowadd=emb_out, rowadd_div=(n // B) * H * W, colstats=cs1)
+            h = ops.conv2d(a.view(n, hin, win, cin), pk["w1"], pk["b1"], kh=3, kw=3, rowadd=emb_out, rowadd_div=(n // B) * H * W, colstats=cs1, **conv1_kw)
             stats = None if cs1 is None else ops.group_norm_stats_from_colstats(cs1, n, H * W, cout)
             a = ops.group_norm(h.view(n, H * W, cout), *pk["g2"], True, stats=stats)
         else:
             # norm(h) * (1 + scale) + shift with (scale, shift) = the two halves of emb_out, one pair per video: the GroupNorm's
             # affine parameters of that video become gamma (1 + scale) and beta (1 + scale) + shift ([C] vectors, a few hundred
             # floats of host-side plumbing per video), the statistics are untouched
-            h = ops.conv2d(a.view(n, H, W, cin), pk["w1"], pk["b1"], kh=3, kw=3, colstats=cs1)
+            h = ops.conv2d(a.view(n, hin, win, cin), pk["w1"], pk["b1"], kh=3, kw=3, colstats=cs1, **conv1_kw)
             stats = None if cs1 is None else ops.group_norm_stats_from_colstats(cs1, n, H * W, cout)
             h3, a, fpv = h.view(n, H * W, cout), torch.empty((n, H * W, cout), dtype=torch.float16, device=x.device), n // B
             gam, bet, eps = pk["g2"]
@@ -332,7 +362,7 @@ class UNetModel(PackedModule):
         super().__init__()
         if num_head_channels == -1:
             raise NotImplementedError("set num_head_channels (the ViewCrafter configs use 64)")
-        if resblock_updown or dims != 2 or not conv_resample:
+        if dims != 2:
             raise NotImplementedError("UNet variant not used by the ViewCrafter configs")
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
         self.num_res_blocks, self.attention_resolutions = num_res_blocks, attention_resolutions
@@ -388,7 +418,11 @@ class UNetModel(PackedModule):
                 self.input_blocks.append(TimestepEmbedSequential(*layers))
                 input_block_chans.append(ch)
             if level != len(channel_mult) - 1:
-                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims, out_channels=ch)))
+                # (resblock_updown: reference openaimodel3d.py:441-451 - a ResBlock(down=True) without temporal convolution in the place of the stride-2 convolution)
+                self.input_blocks.append(TimestepEmbedSequential(
+                    ResBlock(ch, time_embed_dim, dropout, out_channels=ch, dims=dims, use_checkpoint=use_checkpoint,
+                             use_scale_shift_norm=use_scale_shift_norm, down=True)
+                    if resblock_updown else Downsample(ch, conv_resample, dims=dims, out_channels=ch)))
                 input_block_chans.append(ch)
                 ds *= 2
         layers = [res(ch, ch), spatial(ch)]
@@ -407,7 +441,9 @@ class UNetModel(PackedModule):
                     if temporal_attention:
                         layers.append(temporal(ch))
                 if level and i == num_res_blocks:
-                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=ch))
+                    layers.append(ResBlock(ch, time_embed_dim, dropout, out_channels=ch, dims=dims, use_checkpoint=use_checkpoint,
+                                           use_scale_shift_norm=use_scale_shift_norm, up=True)
+                                  if resblock_updown else Upsample(ch, conv_resample, dims=dims, out_channels=ch))
                     ds //= 2
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
         self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
@@ -668,7 +704,8 @@ class UNetModel(PackedModule):
                 x2 = skip if tgt.split else None          # split: the ResBlock reads [h | skip] in place
                 tgt = None
                 if j + 1 < len(self.output_blocks):
-                    up = 2 if isinstance(list(module)[-1], Upsample) else 1
+                    last = list(module)[-1]
+                    up = 2 if isinstance(last, Upsample) or (isinstance(last, ResBlock) and last.up) else 1
                     tgt = target_for(n, H * up, W * up, _out_channels_of(module), self.output_blocks[j + 1])
                 flow = Flow(colstats=cat_cs, want=tgt is None, target=tgt)
                 h = module(hcat, emb, context=ckv, batch_size=b, flow=flow, x2=x2)

@@ -466,6 +466,24 @@ def copy2d(src, dst, rows, cols, lds, ldd):
     check(lib().vcx_copy2d_f16(src.data_ptr(), dst.data_ptr(), rows, cols, lds, ldd, _stream()), "copy2d")
 
 
+def avgpool2x2(x):
+    """[n, H, W, C] fp16 channels-last -> [n, H // 2, W // 2, C]: AvgPool2d(2, 2) (reference Downsample(use_conv=False), openaimodel3d.py:70-72)."""
+    n, H, W, C = x.shape
+    x = x.contiguous()
+    out = torch.empty((n, H // 2, W // 2, C), dtype=_f16, device=x.device)
+    check(lib().vcx_avgpool2x2_f16(x.data_ptr(), out.data_ptr(), n, H, W, C, _stream()), "avgpool2x2")
+    return out
+
+
+def upsample2x(x):
+    """[n, H, W, C] fp16 channels-last -> [n, 2H, 2W, C]: F.interpolate(scale_factor=2, mode='nearest') (reference Upsample, openaimodel3d.py:98-103)."""
+    n, H, W, C = x.shape
+    x = x.contiguous()
+    out = torch.empty((n, 2 * H, 2 * W, C), dtype=_f16, device=x.device)
+    check(lib().vcx_upsample2x_f16(x.data_ptr(), out.data_ptr(), n, H, W, C, _stream()), "upsample2x")
+    return out
+
+
 def repeat_rows(x, r):
     """[rows, C] (row stride may exceed C) -> [r * rows, C]: r copies stacked (the batch axis of a channels-last activation)."""
     rows, C = x.shape
