@@ -255,6 +255,13 @@ int vcx_attn_flash_d512_f16(const void* q, const void* k, const void* vt, void* 
 int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads,
                               int64_t ld, int k_off, int v_off, int64_t ldo, float scale,
                               void* stream);
+/* ABI 9.  The same with flags: VCX_ATTN_CAUSAL masks the keys of later frames (frame t attends to frames <= t) -
+ * TemporalTransformer(causal_attention=True): the lower-triangular mask of attention.py:343-345, 377-384 applied at :111-115
+ * (`use_causal_attention`; not used by the ViewCrafter YAMLs).  flags = 0 is vcx_attn_temporal_d64_f16. */
+#define VCX_ATTN_CAUSAL 4
+int vcx_attn_temporal_d64_masked_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads,
+                                     int64_t ld, int k_off, int v_off, int64_t ldo, float scale,
+                                     int flags, void* stream);
 
 /* Row softmax in place on fp16 [rows][ld] over the first n columns (fp32 math): VAE AttnBlock, ae_modules.py:66-69.
  * ld % 8 == 0; when n is not a multiple of 8 the columns up to the next multiple of 8 (ld must cover them) are written as zeros. */

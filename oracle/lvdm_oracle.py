@@ -121,11 +121,17 @@ def _unheads(t, h):
 SDPA_MAX_SCORES = 1 << 31      # scores materialised at once (8 GiB of fp32); larger problems are walked in batch-head chunks
 
 
-def _sdpa(q, k, v, scale):
+def _sdpa(q, k, v, scale, causal=False):
     """attention.py:101-125 (vanilla): the full score matrix per (batch, head).  Batch-heads are independent, so a problem
-    whose scores would not fit comfortably (N = 9216: 42 GB in fp32) is evaluated chunk by chunk - same arithmetic."""
+    whose scores would not fit comfortably (N = 9216: 42 GB in fp32) is evaluated chunk by chunk - same arithmetic.
+    causal: the lower-triangular mask of the temporal transformer (:343-345, 377-384) filled with -finfo.max (:111-115)."""
     per = q.shape[1] * k.shape[1]
     step = max(1, min(q.shape[0], SDPA_MAX_SCORES // max(per, 1)))
+    if causal:
+        sim = torch.einsum("bid,bjd->bij", q, k) * scale
+        keep = torch.tril(torch.ones(q.shape[1], k.shape[1], device=q.device)) > 0.5
+        sim = sim.masked_fill(~keep, -torch.finfo(sim.dtype).max)
+        return torch.einsum("bij,bjd->bid", sim.softmax(dim=-1), v)
     if step >= q.shape[0]:
         sim = torch.einsum("bid,bjd->bij", q, k) * scale
         return torch.einsum("bij,bjd->bid", sim.softmax(dim=-1), v)
@@ -137,7 +143,7 @@ def _sdpa(q, k, v, scale):
     return out
 
 
-def cross_attention(sd, p, x, context, heads, image_cross_attention, text_len=77):
+def cross_attention(sd, p, x, context, heads, image_cross_attention, text_len=77, causal=False):
     """lvdm/modules/attention.py:81-144 (vanilla forward; the xformers path :146-209 is the same math).
     context None -> self-attention.  With image_cross_attention the context splits into 77 text tokens
     (to_k/to_v) and image tokens (to_k_ip/to_v_ip); the two softmax outputs are summed (scale 1.0)."""
@@ -156,7 +162,7 @@ def cross_attention(sd, p, x, context, heads, image_cross_attention, text_len=77
         if not self_attn:
             ctx = ctx[:, :text_len]
         k, v = _lin(sd, p + ".to_k", ctx), _lin(sd, p + ".to_v", ctx)
-    out = _unheads(_sdpa(q, _heads(k, heads), _heads(v, heads), scale), heads)
+    out = _unheads(_sdpa(q, _heads(k, heads), _heads(v, heads), scale, causal), heads)
     if out_ip is not None:
         out = out + out_ip
     return _lin(sd, p + ".to_out.0", out)
@@ -168,10 +174,10 @@ def feed_forward(sd, p, x):
     return _lin(sd, p + ".net.2", a * F.gelu(gate))
 
 
-def transformer_block(sd, p, x, context, heads, image_cross_attention):
-    """attention.py:241-246 BasicTransformerBlock._forward (attn1 is always self-attention here)."""
-    x = cross_attention(sd, p + ".attn1", _ln(sd, p + ".norm1", x), None, heads, False) + x
-    x = cross_attention(sd, p + ".attn2", _ln(sd, p + ".norm2", x), context, heads, image_cross_attention) + x
+def transformer_block(sd, p, x, context, heads, image_cross_attention, causal=False):
+    """attention.py:241-246 BasicTransformerBlock._forward (attn1 is always self-attention here; a mask goes to attn1 AND attn2)."""
+    x = cross_attention(sd, p + ".attn1", _ln(sd, p + ".norm1", x), None, heads, False, causal=causal) + x
+    x = cross_attention(sd, p + ".attn2", _ln(sd, p + ".norm2", x), context, heads, image_cross_attention, causal=causal) + x
     return feed_forward(sd, p + ".ff", _ln(sd, p + ".norm3", x)) + x
 
 
@@ -188,7 +194,7 @@ def spatial_transformer(sd, p, x, context, heads, depth=1):
     return t.view(n, h, w, c).permute(0, 3, 1, 2) + x
 
 
-def temporal_transformer(sd, p, x, heads, depth=1):
+def temporal_transformer(sd, p, x, heads, depth=1, causal=False):
     """attention.py:365-412, only_self_att=True: tokens are the T frames of one pixel; both attn1 and attn2 are
     self-attention (context None, :389-390).  x [b, c, t, h, w].  proj_in/out are Linear (use_linear) or Conv1d k=1
     (init_attn, openaimodel3d.py:389-399) - the same matmul on a [.., C] row."""
@@ -197,7 +203,7 @@ def temporal_transformer(sd, p, x, heads, depth=1):
     w_in, w_out = sd[p + ".proj_in.weight"], sd[p + ".proj_out.weight"]
     tok = F.linear(tok, w_in.reshape(w_in.shape[0], -1), sd[p + ".proj_in.bias"])
     for i in range(depth):
-        tok = transformer_block(sd, f"{p}.transformer_blocks.{i}", tok, None, heads, False)
+        tok = transformer_block(sd, f"{p}.transformer_blocks.{i}", tok, None, heads, False, causal=causal)
     tok = F.linear(tok, w_out.reshape(w_out.shape[0], -1), sd[p + ".proj_out.bias"])
     return tok.view(b, h, w, t, c).permute(0, 4, 3, 1, 2) + x
 
@@ -283,8 +289,8 @@ def unet_layout(hp):
     return inputs, middle, outputs
 
 
-def _run_layers(sd, prefix, layers, h, emb, context, batch):
-    """TimestepEmbedSequential.forward, openaimodel3d.py:36-48."""
+def _run_layers(sd, prefix, layers, h, emb, context, batch, causal=False):
+    """TimestepEmbedSequential.forward, openaimodel3d.py:36-48.  causal: `use_causal_attention` of the temporal transformers (not of init_attn, :398)."""
     for j, (kind, ch, heads) in enumerate(layers):
         p = f"{prefix}.{j}"
         if kind == "conv":
@@ -296,7 +302,7 @@ def _run_layers(sd, prefix, layers, h, emb, context, batch):
         elif kind == "tt":
             n, c, hh, ww = h.shape
             h5 = h.view(batch, n // batch, c, hh, ww).permute(0, 2, 1, 3, 4)
-            h5 = temporal_transformer(sd, p, h5, heads)
+            h5 = temporal_transformer(sd, p, h5, heads, causal=causal)
             h = h5.permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)
         elif kind in ("res_down", "res_up"):    # resblock_updown, openaimodel3d.py:441-451, 529-538 (no temporal convolution in these blocks)
             h = res_block(sd, p, h, emb, batch, updown=kind[4:])
@@ -337,10 +343,11 @@ def unet_forward(sd, hp, x, timesteps, context, fs=None, taps=None, features_ada
         fe = _lin(sd, "fps_embedding.2", F.silu(_lin(sd, "fps_embedding.0", timestep_embedding(fs, mc))))
         emb = emb + fe.repeat_interleave(t, dim=0)
     inputs, middle, outputs = unet_layout(hp)
+    causal = bool(hp.get("use_causal_attention", False))
     hs = []
     adapter_idx = 0
     for i, layers in enumerate(inputs):
-        h = _run_layers(sd, f"input_blocks.{i}", layers, h, emb, context, b)
+        h = _run_layers(sd, f"input_blocks.{i}", layers, h, emb, context, b, causal)
         if i == 0 and hp.get("addition_attention", False):
             n, c, hh, ww = h.shape
             h5 = h.view(b, t, c, hh, ww).permute(0, 2, 1, 3, 4)
@@ -353,12 +360,12 @@ def unet_forward(sd, hp, x, timesteps, context, fs=None, taps=None, features_ada
         if taps is not None:
             taps[f"input_blocks.{i}"] = h
     assert features_adapter is None or len(features_adapter) == adapter_idx, "Wrong features_adapter"
-    h = _run_layers(sd, "middle_block", middle, h, emb, context, b)
+    h = _run_layers(sd, "middle_block", middle, h, emb, context, b, causal)
     if taps is not None:
         taps["middle_block"] = h
     for i, layers in enumerate(outputs):
         h = torch.cat([h, hs.pop()], dim=1)
-        h = _run_layers(sd, f"output_blocks.{i}", layers, h, emb, context, b)
+        h = _run_layers(sd, f"output_blocks.{i}", layers, h, emb, context, b, causal)
         if taps is not None:
             taps[f"output_blocks.{i}"] = h
     y = F.conv2d(F.silu(_gn(sd, "out.0", h, 1e-5)), sd["out.2.weight"], sd["out.2.bias"], padding=1)

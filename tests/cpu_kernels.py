@@ -209,14 +209,17 @@ def flash_attn_dual(q, k1, vt1, k2, vt2, out, *, n_groups, heads, nq, nk1, kv_ro
     return out
 
 
-def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale):
+def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale, causal=False):
     x = qkv.as_strided((B, T, P, ld), (T * P * ld, P * ld, ld, 1), qkv.storage_offset()).float()
     o = out.as_strided((B, T, P, ldo), (T * P * ldo, P * ldo, ldo, 1), out.storage_offset())
     for h in range(heads):
         qh = x[..., h * 64:h * 64 + 64].permute(0, 2, 1, 3)                           # [B, P, T, 64]
         kh = x[..., k_off + h * 64:k_off + h * 64 + 64].permute(0, 2, 1, 3)
         vh = x[..., v_off + h * 64:v_off + h * 64 + 64].permute(0, 2, 1, 3)
-        p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1).to(_f16).float()
+        logits = qh @ kh.transpose(-1, -2) * scale
+        if causal:
+            logits = logits.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool)), float("-inf"))
+        p = torch.softmax(logits, dim=-1).to(_f16).float()
         o[..., h * 64:h * 64 + 64] = (p @ vh).permute(0, 2, 1, 3).to(_f16)
     return out
 

@@ -199,6 +199,12 @@ def gen_unet_noconv(out):
     _gen_unet_variant(out, "nc", conv_resample=False)
 
 
+def gen_unet_causal(out):
+    """use_causal_attention=True (attention.py:343-345, 377-384: a lower-triangular mask over the frames for every TemporalTransformer but init_attn);
+    not used by the shipped YAMLs."""
+    _gen_unet_variant(out, "ca", use_causal_attention=True)
+
+
 def adapter_features(b, t, h, w, mc=TINY_UNET["model_channels"], mult=TINY_UNET["channel_mult"]):
     """What a T2I-adapter hands to UNetModel.forward(features_adapter=...): one [(b t), C, h, w] map per level, added behind input
     blocks 2, 5, 8, 11 (openaimodel3d.py:582-588)."""
@@ -544,7 +550,7 @@ def main():
         print("transformers not importable:", e)
     import_reference()
     torch.set_num_threads(8)
-    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("unet_tiny_conv1x1", gen_unet_conv1x1), ("unet_tiny_updown", gen_unet_updown), ("unet_tiny_noconv", gen_unet_noconv), ("unet_tiny_adapter", gen_unet_adapter), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
+    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("unet_tiny_conv1x1", gen_unet_conv1x1), ("unet_tiny_updown", gen_unet_updown), ("unet_tiny_noconv", gen_unet_noconv), ("unet_tiny_causal", gen_unet_causal), ("unet_tiny_adapter", gen_unet_adapter), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
                      ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs),
                      ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli), ("api_signatures", gen_api), ("reference_yaml", gen_yaml)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:

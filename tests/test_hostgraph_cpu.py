@@ -265,7 +265,8 @@ def test_host_graph_with_conv1x1_projections_vs_reference_golden(monkeypatch):
 
 
 @pytest.mark.parametrize("level", [2, 0])
-@pytest.mark.parametrize("name,tag,flags", [("unet_tiny_updown", "ud", dict(resblock_updown=True)), ("unet_tiny_noconv", "nc", dict(conv_resample=False))])
+@pytest.mark.parametrize("name,tag,flags", [("unet_tiny_updown", "ud", dict(resblock_updown=True)), ("unet_tiny_noconv", "nc", dict(conv_resample=False)),
+                                            ("unet_tiny_causal", "ca", dict(use_causal_attention=True))])
 def test_host_graph_with_sampling_variants_vs_reference_golden(monkeypatch, name, tag, flags, level):
     """resblock_updown=True: ResBlock(down / up) - AvgPool2d / nearest 2x between SiLU and the first convolution (up: the convolution's fused
     gather) and on the skip path - in the place of the resampling convolutions; conv_resample=False: the resampling layers without a

@@ -1405,6 +1405,34 @@ def test_temporal_attention(B, T, P, heads):
     check(out, ref, tol=3e-3, name="temporal attn")
 
 
+@pytest.mark.parametrize("B,T,P,heads", [(1, 16, 40, 2), (2, 25, 37, 5), (1, 32, 9, 1), (1, 1, 8, 1)])
+def test_temporal_attention_causal(B, T, P, heads):
+    """VCX_ATTN_CAUSAL (vcx_attn_temporal_d64_masked_f16, ABI 9): frame t attends to frames <= t - the lower-triangular mask of the reference's
+    TemporalTransformer(causal_attention=True) (attention.py:343-345, 377-384, 111-115) - against masked fp32 softmax attention; frame 0 returns
+    its own value rows, and the unmasked entry point is untouched by the flag (same bits as flags = 0)."""
+    from viewcrafter_amd import ops
+    C = heads * 64
+    qkv = rnd(B * T * P, 3 * C, seed=62).to(DEV).half()
+    out = torch.empty(B * T * P, C, device=DEV, dtype=torch.float16)
+    ops.temporal_attn(qkv, out, B=B, T=T, P=P, heads=heads, ld=3 * C, k_off=C, v_off=2 * C, ldo=C, scale=0.125, causal=True)
+
+    def split(t):  # [(b t p), C] -> [(b p h), t, 64]
+        return t.view(B, T, P, heads, 64).permute(0, 2, 3, 1, 4).reshape(B * P * heads, T, 64).float()
+    q, k, v = split(qkv[:, :C]), split(qkv[:, C:2 * C]), split(qkv[:, 2 * C:])
+    sim = (q @ k.transpose(1, 2)) * 0.125
+    sim = sim.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool, device=DEV)), float("-inf"))
+    ref = (sim.softmax(-1) @ v).view(B, P, heads, T, 64).permute(0, 3, 1, 2, 4).reshape(B * T * P, C)
+    check(out, ref, tol=3e-3, name="causal temporal attn")
+    o4, v4 = out.view(B, T, P, C), qkv[:, 2 * C:].view(B, T, P, C)
+    assert torch.equal(o4[:, 0], v4[:, 0])          # frame 0 sees itself only: P = 1 exactly
+    plain, plain2 = torch.empty_like(out), torch.empty_like(out)
+    ops.temporal_attn(qkv, plain, B=B, T=T, P=P, heads=heads, ld=3 * C, k_off=C, v_off=2 * C, ldo=C, scale=0.125)
+    from viewcrafter_amd import _lib
+    ops.check(_lib.lib().vcx_attn_temporal_d64_masked_f16(qkv.data_ptr(), plain2.data_ptr(), B, T, P, heads, 3 * C, C, 2 * C, C, 0.125, 0,
+                                                        torch.cuda.current_stream().cuda_stream), "masked, flags = 0")
+    assert torch.equal(plain, plain2) and (T == 1 or not torch.equal(plain, out))
+
+
 def test_softmax_rows():
     from viewcrafter_amd import ops
     x = (rnd(100, 520, seed=61) * 3).to(DEV).half()

@@ -98,7 +98,8 @@ def test_unet_with_conv1x1_projections_vs_reference_golden():
     assert e <= UNET_TOL
 
 
-@pytest.mark.parametrize("name,tag,flags", [("unet_tiny_updown", "ud", dict(resblock_updown=True)), ("unet_tiny_noconv", "nc", dict(conv_resample=False))])
+@pytest.mark.parametrize("name,tag,flags", [("unet_tiny_updown", "ud", dict(resblock_updown=True)), ("unet_tiny_noconv", "nc", dict(conv_resample=False)),
+                                            ("unet_tiny_causal", "ca", dict(use_causal_attention=True))])
 def test_unet_sampling_variants_vs_reference_golden(name, tag, flags):
     """resblock_updown=True (reference openaimodel3d.py:441-451, 529-538, 210-215) and conv_resample=False (:70-72, 98-103); goldens by the
     reference's own UNetModel: vcx_avgpool2x2_f16 / vcx_upsample2x_f16 (ABI 9) and the fused nearest-2x gather of the convolution."""

@@ -308,7 +308,8 @@ def test_oracle_unet_with_conv1x1_projections_matches_reference():
     assert np.abs(y.numpy() - g["unet_out"]).max() <= 2e-5 * np.abs(g["unet_out"]).max() + 1e-6
 
 
-@pytest.mark.parametrize("name,tag,flags", [("unet_tiny_updown", "ud", dict(resblock_updown=True)), ("unet_tiny_noconv", "nc", dict(conv_resample=False))])
+@pytest.mark.parametrize("name,tag,flags", [("unet_tiny_updown", "ud", dict(resblock_updown=True)), ("unet_tiny_noconv", "nc", dict(conv_resample=False)),
+                                            ("unet_tiny_causal", "ca", dict(use_causal_attention=True))])
 def test_oracle_unet_sampling_variants_match_reference(name, tag, flags):
     """resblock_updown=True (reference openaimodel3d.py:441-451, 529-538, 210-215) and conv_resample=False (:70-72, 98-103) - not used by the
     shipped YAMLs, accepted by the reference's constructor: goldens written by the reference's own UNetModel (gen_golden.py::_gen_unet_variant)."""

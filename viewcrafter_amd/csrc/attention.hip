@@ -1041,6 +1041,9 @@ struct TAttnArgs {
 // cross-lane movement.  Q, K and V rows (a frame row of one head is one 128-byte line) go through a wave-private LDS
 // patch 3 x [32][72]: the Q / K fragments are ds_read_b128 from it, the V^T fragments are gathered with 16-bit reads
 // (rows >= T zero-filled).  Traffic is the algorithmic minimum (q, k, v read once, o written once).
+// CAUSAL (VCX_ATTN_CAUSAL; TemporalTransformer(causal_attention=True), reference attention.py:343-345, 377-384, 111-115 - not used by the ViewCrafter
+// YAMLs): frame t attends to frames <= t.  An own instantiation: the unmasked kernel keeps its listing.
+template <bool CAUSAL>
 __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
     constexpr int VLD = 72;                                           // LDS row pitch (halfs): 144 B keeps 16-B alignment
     constexpr int WAVES = 8;
@@ -1108,7 +1111,7 @@ __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (key >= p.T) sacc[r] = -1e30f;
+        if (key >= p.T || (CAUSAL && key > lq)) sacc[r] = -1e30f;
         mx = fmaxf(mx, sacc[r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32)) * c;
@@ -1381,9 +1384,17 @@ extern "C" int vcx_attn_flash_d512_f16(const void* q, const void* k, const void*
     return vcx_check_launch("vcx_attn_flash_d512_f16");
 }
 
+extern "C" int vcx_attn_temporal_d64_masked_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads, int64_t ld,
+                                                int k_off, int v_off, int64_t ldo, float scale, int flags, void* stream);
 extern "C" int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads, int64_t ld,
                                          int k_off, int v_off, int64_t ldo, float scale, void* stream) {
+    return vcx_attn_temporal_d64_masked_f16(qkv, o, B, T, P, heads, ld, k_off, v_off, ldo, scale, 0, stream);
+}
+
+extern "C" int vcx_attn_temporal_d64_masked_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads, int64_t ld,
+                                                int k_off, int v_off, int64_t ldo, float scale, int flags, void* stream) {
     VCX_REQUIRE(qkv && o, "vcx_attn_temporal_d64_f16: null pointer");
+    VCX_REQUIRE((flags & ~VCX_ATTN_CAUSAL) == 0, "vcx_attn_temporal_d64_masked_f16: unknown flags 0x%x (VCX_ATTN_CAUSAL is the only one)", flags);
     VCX_REQUIRE(B > 0 && T > 0 && T <= 32 && P > 0 && heads > 0, "vcx_attn_temporal_d64_f16: need 0 < T <= 32 (T=%d)", T);
     VCX_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0,
                 "vcx_attn_temporal_d64_f16: strides/offsets must be multiples of 8");
@@ -1397,7 +1408,8 @@ extern "C" int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T,
     VcxProfScope prof(VCX_FAM_TATTN, s, 4.0 * a.npairs * (double)T * T * 64, 2.0 * a.npairs * T * 64 * 4.0);
     const int64_t nblk = (a.npairs + 7) / 8;
     VCX_REQUIRE(nblk < (1ll << 31), "vcx_attn_temporal_d64_f16: grid too large");
-    hipLaunchKernelGGL(tattn_d64_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    if (flags & VCX_ATTN_CAUSAL) hipLaunchKernelGGL(tattn_d64_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(tattn_d64_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, s, a);
     return vcx_check_launch("vcx_attn_temporal_d64_f16");
 }
 

@@ -157,8 +157,8 @@ class PackedModule(nn.Module):
 
 class CrossAttention(PackedModule):
     """Reference attention.py:42-209.  Parameter container + packing; the attention itself is launched by the owning
-    transformer (it needs the token geometry).  Relative position / causal masks are not part of the ViewCrafter
-    graph (use_relative_position=false, use_causal_attention=False) and are rejected."""
+    transformer (it needs the token geometry).  Relative position is not part of the ViewCrafter graph (use_relative_position=false) and is
+    rejected; the causal mask of the temporal transformer is a flag of the temporal attention kernel."""
 
     def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0., relative_position=False,
                  temporal_length=None, video_length=None, image_cross_attention=False, image_cross_attention_scale=1.0,
@@ -460,8 +460,14 @@ class TemporalTransformer(PackedModule):
                  use_linear=False, only_self_att=True, causal_attention=False, causal_block_size=1,
                  relative_position=False, temporal_length=None):
         super().__init__()
-        if not only_self_att or causal_attention or relative_position:
-            raise NotImplementedError("ViewCrafter uses temporal self-attention only, no causal mask / relative position")
+        if not only_self_att or relative_position:
+            raise NotImplementedError("ViewCrafter uses temporal self-attention only, no relative position")
+        # causal_attention (reference attention.py:343-345, 377-384: a lower-triangular mask over the frames, handed to attn1 AND attn2 of every block,
+        # :241-243; `use_causal_attention`, not used by the ViewCrafter YAMLs): VCX_ATTN_CAUSAL of the temporal attention kernel
+        if causal_attention and temporal_length is None:
+            raise AssertionError("causal_attention needs temporal_length (reference attention.py:344)")
+        self.causal_attention = bool(causal_attention)
+        self.temporal_length = temporal_length
         self.only_self_att = only_self_att
         self.in_channels = in_channels
         inner_dim = n_heads * d_head
@@ -527,7 +533,7 @@ class TemporalTransformer(PackedModule):
                 qkv = ln_linear(t, ap["qkv"], lnp, stats=st)                         # [tokens, 3D]
                 o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
                 ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D, ldo=D,
-                                  scale=attn.scale)
+                                  scale=attn.scale, causal=self.causal_attention)
                 st = None
                 if ai == 0 and _folded(blk.attn2.packed()["qkv"], tokens, D, D) and ops.rowstats_ok(tokens, D, D, ldr=D):
                     st = ops.rowstats_buffer(tokens, x.device)

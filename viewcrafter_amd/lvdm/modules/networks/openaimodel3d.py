@@ -384,10 +384,10 @@ class UNetModel(PackedModule):
                                       image_cross_attention=image_cross_attention,
                                       image_cross_attention_scale_learnable=image_cross_attention_scale_learnable)
 
-        def temporal(ch, heads=None, linear=use_linear):
+        def temporal(ch, heads=None, linear=use_linear, causal=use_causal_attention):
             return TemporalTransformer(ch, heads or ch // num_head_channels, num_head_channels, depth=transformer_depth,
                                        context_dim=context_dim, use_linear=linear, use_checkpoint=use_checkpoint,
-                                       only_self_att=temporal_selfatt_only, causal_attention=use_causal_attention,
+                                       only_self_att=temporal_selfatt_only, causal_attention=causal,
                                        relative_position=use_relative_position, temporal_length=temporal_length)
 
         def res(cin, cout):
@@ -404,7 +404,7 @@ class UNetModel(PackedModule):
             nn.init.zeros_(self.fps_embedding[-1].bias)
         self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
         if addition_attention:   # 8 heads, Conv1d projections (use_linear not forwarded), openaimodel3d.py:387-399
-            self.init_attn = TimestepEmbedSequential(temporal(model_channels, heads=8, linear=False))
+            self.init_attn = TimestepEmbedSequential(temporal(model_channels, heads=8, linear=False, causal=False))       # (causal_attention=False there, :398)
         input_block_chans = [model_channels]
         ch, ds = model_channels, 1
         for level, mult in enumerate(channel_mult):

@@ -362,7 +362,7 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 # ------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------
-ATTN_ACCUMULATE, ATTN_LOG2_LOGITS = 1, 2
+ATTN_ACCUMULATE, ATTN_LOG2_LOGITS, ATTN_CAUSAL = 1, 2, 4
 LOG2E = 1.4426950408889634
 
 
@@ -397,10 +397,15 @@ def flash_attn_dual(q, k1, vt1, k2, vt2, out, *, n_groups, heads, nq, nk1, kv_ro
     return out
 
 
-def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale):
+def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale, causal=False):
+    """causal: frame t attends to frames <= t (TemporalTransformer(causal_attention=True), reference attention.py:343-345, 377-384)."""
     _dev16(qkv, out)
-    check(lib().vcx_attn_temporal_d64_f16(qkv.data_ptr(), out.data_ptr(), B, T, P, heads, ld, k_off, v_off, ldo, scale,
-                                          _stream()), "attn_temporal_d64")
+    if causal:
+        check(lib().vcx_attn_temporal_d64_masked_f16(qkv.data_ptr(), out.data_ptr(), B, T, P, heads, ld, k_off, v_off, ldo, scale, ATTN_CAUSAL,
+                                                     _stream()), "attn_temporal_d64(causal)")
+    else:
+        check(lib().vcx_attn_temporal_d64_f16(qkv.data_ptr(), out.data_ptr(), B, T, P, heads, ld, k_off, v_off, ldo, scale,
+                                              _stream()), "attn_temporal_d64")
     return out
 
 
