@@ -248,7 +248,7 @@ int vcx_attn_flash_dual_d64_f16(const void* q, const void* k1, const void* vt1, 
 int vcx_attn_flash_d512_f16(const void* q, const void* k, const void* vt, void* o, int n_groups, int nq, int nk, int kv_rows,
                             int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, float scale, void* stream);
 
-/* Temporal self-attention over T <= 32 frames per pixel, head dim 64
+/* Temporal self-attention over T <= 64 frames per pixel (one 32 x 32 score tile per (pixel, head) up to 32 frames, 2 x 2 tiles beyond), head dim 64
  * (TemporalTransformer -> CrossAttention.forward, attention.py:365-412, 81-126).
  * qkv is [(b t p)][ld] with q at col 0, k at col k_off, v at col v_off (+ h*64);
  * token (b, t, p) is row (b*T + t)*P + p.  o is [(b t p)][ldo]. */

@@ -147,7 +147,7 @@ def test_fuzz_flash_attention(n, heads, nq8, nk, accumulate, log2, seed):
 
 
 @FUZZ
-@given(B=st.integers(1, 2), T=st.integers(1, 32), P=st.integers(1, 300), heads=st.integers(1, 5), seed=st.integers(0, 1 << 16))
+@given(B=st.integers(1, 2), T=st.integers(1, 64), P=st.integers(1, 300), heads=st.integers(1, 5), seed=st.integers(0, 1 << 16))
 def test_fuzz_temporal_attention(B, T, P, heads, seed):
     from viewcrafter_amd import ops
     D = heads * 64

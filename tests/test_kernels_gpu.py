@@ -1390,7 +1390,7 @@ def test_flash_attention_one_head_of_512(n, nq, nk, gain):
     assert torch.equal(again[:n * nq], out[:n * nq])
 
 
-@pytest.mark.parametrize("B,T,P,heads", [(1, 16, 40, 2), (2, 25, 37, 5), (1, 4, 8, 1)])
+@pytest.mark.parametrize("B,T,P,heads", [(1, 16, 40, 2), (2, 25, 37, 5), (1, 4, 8, 1), (1, 33, 21, 2), (2, 40, 37, 5), (1, 64, 16, 1), (1, 57, 9, 3)])
 def test_temporal_attention(B, T, P, heads):
     from viewcrafter_amd import ops
     C = heads * 64
@@ -1405,7 +1405,7 @@ def test_temporal_attention(B, T, P, heads):
     check(out, ref, tol=3e-3, name="temporal attn")
 
 
-@pytest.mark.parametrize("B,T,P,heads", [(1, 16, 40, 2), (2, 25, 37, 5), (1, 32, 9, 1), (1, 1, 8, 1)])
+@pytest.mark.parametrize("B,T,P,heads", [(1, 16, 40, 2), (2, 25, 37, 5), (1, 32, 9, 1), (1, 1, 8, 1), (1, 33, 21, 2), (2, 48, 19, 5), (1, 64, 8, 1)])
 def test_temporal_attention_causal(B, T, P, heads):
     """VCX_ATTN_CAUSAL (vcx_attn_temporal_d64_masked_f16, ABI 9): frame t attends to frames <= t - the lower-triangular mask of the reference's
     TemporalTransformer(causal_attention=True) (attention.py:343-345, 377-384, 111-115) - against masked fp32 softmax attention; frame 0 returns

@@ -98,6 +98,23 @@ def test_unet_with_conv1x1_projections_vs_reference_golden():
     assert e <= UNET_TOL
 
 
+def test_unet_forward_with_40_frames_vs_fp32_oracle(unet):
+    """More than 32 frames (no ViewCrafter checkpoint has them; the temporal attention kernel used to refuse T > 32): tattn64_d64_kernel in every
+    TemporalTransformer of the tiny graph, against the fp32 oracle run on the same GPU with the same weights."""
+    from oracle import lvdm_oracle as O
+    m, sd = unet
+    b, t, h, w = 1, 40, 16, 16
+    x = synth_input("unet_x_t40", (b, 8, t, h, w)).to(DEV)
+    ctx = synth_input("unet_ctx_t40", (b, 77 + 40, TINY_UNET["context_dim"])).to(DEV)
+    ts, fs = torch.tensor([499], device=DEV), torch.tensor([10], device=DEV)
+    with torch.no_grad():
+        y = m(x, ts, context=ctx, fs=fs)
+        ref = O.unet_forward({k: v.to(DEV) for k, v in m.state_dict().items()}, TINY_UNET, x, ts, ctx, fs)
+    e = rel_l2(y, ref)
+    print(f"unet with 40 frames: rel-L2 vs the fp32 oracle = {e:.3e}")
+    assert y.shape == (b, 4, t, h, w) and e <= UNET_TOL
+
+
 @pytest.mark.parametrize("name,tag,flags", [("unet_tiny_updown", "ud", dict(resblock_updown=True)), ("unet_tiny_noconv", "nc", dict(conv_resample=False)),
                                             ("unet_tiny_causal", "ca", dict(use_causal_attention=True))])
 def test_unet_sampling_variants_vs_reference_golden(name, tag, flags):

@@ -1167,6 +1167,145 @@ __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
     }
 }
 
+// 32 < T <= 64 frames (no ViewCrafter checkpoint has that many - the UNet's temporal attention would otherwise refuse such a video): the same
+// wave-per-(pixel, head) scheme on 2 x 2 score tiles.  Q / K fragment kt / qt: rows 32 kt + lq of the patch; S^T tile (kt, qt) holds keys
+// 32 kt + (r&3) + 8 (r>>2) + 4 hi of query 32 qt + lq; the row maximum / sum of a query runs over both key tiles and both lane halves.  The patch is
+// 2 x [64][72] halfs per wave (18 KB): one block per CU.  A separate kernel: the T <= 32 one keeps its listing.
+template <bool CAUSAL>
+__global__ void __launch_bounds__(512) tattn64_d64_kernel(TAttnArgs p) {
+    constexpr int VLD = 72;
+    constexpr int WAVES = 8;
+    __shared__ __attribute__((aligned(16))) half_t sVt[WAVES][2 * 64 * VLD];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int64_t pair = (int64_t)blockIdx.x * WAVES + wave;
+    if (pair >= p.npairs) return;                                     // wave-uniform; no block-level sync below
+    const int h = (int)(pair % p.heads);
+    const int64_t pix = (pair / p.heads) % p.P;
+    const int b = (int)(pair / (p.heads * p.P));
+    const half_t* base = p.qkv + ((int64_t)b * p.T * p.P + pix) * p.ld + h * 64;
+    const int64_t fstride = p.P * p.ld;
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    half_t* sv = sVt[wave];
+    half_t* sqk = sv + 64 * VLD;
+    h8 qf[2][4], kf[2][4];
+    {
+        h8 q4[8], k4[8], v4[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = (lane >> 3) + 8 * it, ch = lane & 7;
+            const half_t* src = base + (int64_t)row * fstride + ch * 8;
+            const bool ok = row < p.T;
+            q4[it] = ok ? *reinterpret_cast<const h8*>(src) : zero8;
+            k4[it] = ok ? *reinterpret_cast<const h8*>(src + p.k_off) : zero8;
+            v4[it] = ok ? *reinterpret_cast<const h8*>(src + p.v_off) : zero8;
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = (lane >> 3) + 8 * it, ch = lane & 7;
+            *reinterpret_cast<h8*>(sqk + row * VLD + ch * 8) = q4[it];
+            *reinterpret_cast<h8*>(sv + row * VLD + ch * 8) = v4[it];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[t][s] = *reinterpret_cast<const h8*>(sqk + (32 * t + lq) * VLD + s * 16 + hi * 8);
+        asm volatile("" ::: "memory");                                // the K rows overwrite the Q rows behind the (in-order) Q fragment reads
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = (lane >> 3) + 8 * it, ch = lane & 7;
+            *reinterpret_cast<h8*>(sqk + row * VLD + ch * 8) = k4[it];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kf[t][s] = *reinterpret_cast<const h8*>(sqk + (32 * t + lq) * VLD + s * 16 + hi * 8);
+    }
+    const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float c = p.scale * 1.4426950408889634f;
+    f16v sacc[2][2];                                                  // [key tile][query tile]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            sacc[kt][qt] = zero16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sacc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[qt][s], sacc[kt][qt], 0, 0, 0);
+        }
+    h8 pf[2][2][2];                                                   // [key tile][query tile][k-step of 16 keys]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = 32 * qt + lq;
+        float mx = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (key >= p.T || (CAUSAL && key > q)) sacc[kt][qt][r] = -1e30f;
+                mx = fmaxf(mx, sacc[kt][qt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * c;
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][qt][r], c, -mx));
+                sacc[kt][qt][r] = e;
+                l += e;
+            }
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[kt][qt][s][j] = (half_t)(sacc[kt][qt][8 * s + j] * inv);
+    }
+    // O^T[d, q] = sum_key V^T[d, key] P^T[key, q]: a V^T fragment (d half db, key tile kt, k-step s) serves both query tiles
+    f16v oacc[2][2];                                                  // [d half][query tile]
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        oacc[db][0] = zero16;
+        oacc[db][1] = zero16;
+        const int d = db * 32 + lq;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                h8 vf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vf[j] = sv[(32 * kt + 16 * s + (j & 3) + 8 * (j >> 2) + 4 * hi) * VLD + d];
+                oacc[db][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt][0][s], oacc[db][0], 0, 0, 0);
+                oacc[db][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt][1][s], oacc[db][1], 0, 0, 0);
+            }
+    }
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        u2v pk[8];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                pk[db * 4 + gq] = __builtin_bit_cast(u2v, h4{(half_t)oacc[db][qt][gq * 4 + 0], (half_t)oacc[db][qt][gq * 4 + 1],
+                                                            (half_t)oacc[db][qt][gq * 4 + 2], (half_t)oacc[db][qt][gq * 4 + 3]});
+        const int frame = 32 * qt + lq;
+        half_t* dst = p.o + (((int64_t)b * p.T + frame) * p.P + pix) * p.ldo + h * 64 + hi * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const unsigned a0 = pk[k][0], a1 = pk[k][1], b0 = pk[k + 1][0], b1 = pk[k + 1][1];
+            const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            if (frame < p.T) *reinterpret_cast<u4v*>(dst + 8 * k) = u4v{s0[0], s1[0], s0[1], s1[1]};
+        }
+    }
+}
+
 // =======================================================================================
 // Row softmax in place (fp16 storage, fp32 math), one block per row.
 // =======================================================================================
@@ -1395,7 +1534,7 @@ extern "C" int vcx_attn_temporal_d64_masked_f16(const void* qkv, void* o, int B,
                                                 int k_off, int v_off, int64_t ldo, float scale, int flags, void* stream) {
     VCX_REQUIRE(qkv && o, "vcx_attn_temporal_d64_f16: null pointer");
     VCX_REQUIRE((flags & ~VCX_ATTN_CAUSAL) == 0, "vcx_attn_temporal_d64_masked_f16: unknown flags 0x%x (VCX_ATTN_CAUSAL is the only one)", flags);
-    VCX_REQUIRE(B > 0 && T > 0 && T <= 32 && P > 0 && heads > 0, "vcx_attn_temporal_d64_f16: need 0 < T <= 32 (T=%d)", T);
+    VCX_REQUIRE(B > 0 && T > 0 && T <= 64 && P > 0 && heads > 0, "vcx_attn_temporal_d64_f16: need 0 < T <= 64 (T=%d)", T);
     VCX_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0,
                 "vcx_attn_temporal_d64_f16: strides/offsets must be multiples of 8");
     VCX_REQUIRE((((uintptr_t)qkv | (uintptr_t)o) & 15) == 0, "vcx_attn_temporal_d64_f16: pointers must be 16-byte aligned");
@@ -1408,7 +1547,10 @@ extern "C" int vcx_attn_temporal_d64_masked_f16(const void* qkv, void* o, int B,
     VcxProfScope prof(VCX_FAM_TATTN, s, 4.0 * a.npairs * (double)T * T * 64, 2.0 * a.npairs * T * 64 * 4.0);
     const int64_t nblk = (a.npairs + 7) / 8;
     VCX_REQUIRE(nblk < (1ll << 31), "vcx_attn_temporal_d64_f16: grid too large");
-    if (flags & VCX_ATTN_CAUSAL) hipLaunchKernelGGL(tattn_d64_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    if (T > 32) {         // 2 x 2 score tiles, 18 KB of LDS per wave
+        if (flags & VCX_ATTN_CAUSAL) hipLaunchKernelGGL(tattn64_d64_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL(tattn64_d64_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    } else if (flags & VCX_ATTN_CAUSAL) hipLaunchKernelGGL(tattn_d64_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(tattn_d64_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, s, a);
     return vcx_check_launch("vcx_attn_temporal_d64_f16");
 }
