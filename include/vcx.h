@@ -262,6 +262,15 @@ int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T, int64_t P,
 int vcx_attn_temporal_d64_masked_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads,
                                      int64_t ld, int k_off, int v_off, int64_t ldo, float scale,
                                      int flags, void* stream);
+/* ABI 9.  ... with relative position (CrossAttention(relative_position=True), attention.py:20-40, 59-62, 104-108, 120-123; `use_relative_position`,
+ * not used by the ViewCrafter YAMLs; T <= 32, 1 <= R <= 31):  logits = scale (q_t . k_s + q_t . Ek[c(s - t)]),  out_t = sum_s P[t, s] (v_s + Ev[c(s - t)]),
+ * c(d) = clamp(d, -R, R) + R, tables of 2R + 1 <= 64 rows.  The two table contractions are 64-wide GEMMs of the CALLER:
+ *   relg [(b t p)][heads][64] fp16 (in)  = q Ek^T per query row and head (slots 2R + 1 .. 63 unused) - added to the scores before scale and softmax;
+ *   relp [(b t p)][heads][64] fp16 (out) = the probabilities of a query by clipped distance (keys beyond +-R summed into slots 0 / 2R); the caller
+ *   ZEROES it before the call and adds relp Ev to o afterwards.  flags: VCX_ATTN_CAUSAL. */
+int vcx_attn_temporal_d64_rel_f16(const void* qkv, void* o, const void* relg, void* relp, int R, int B, int T, int64_t P,
+                                  int heads, int64_t ld, int k_off, int v_off, int64_t ldo, float scale, int flags,
+                                  void* stream);
 
 /* Row softmax in place on fp16 [rows][ld] over the first n columns (fp32 math): VAE AttnBlock, ae_modules.py:66-69.
  * ld % 8 == 0; when n is not a multiple of 8 the columns up to the next multiple of 8 (ld must cover them) are written as zeros. */

@@ -162,7 +162,20 @@ def cross_attention(sd, p, x, context, heads, image_cross_attention, text_len=77
         if not self_attn:
             ctx = ctx[:, :text_len]
         k, v = _lin(sd, p + ".to_k", ctx), _lin(sd, p + ".to_v", ctx)
-    out = _unheads(_sdpa(q, _heads(k, heads), _heads(v, heads), scale, causal), heads)
+    if p + ".relative_position_k.embeddings_table" in sd:
+        # relative position (attention.py:20-40, 104-108, 120-123): sim += q . Ek[c(j - i)] (scaled like sim), out += softmax(sim) . Ev[c(j - i)]
+        ek, ev = sd[p + ".relative_position_k.embeddings_table"], sd[p + ".relative_position_v.embeddings_table"]
+        R = (ek.shape[0] - 1) // 2
+        kh, vh = _heads(k, heads), _heads(v, heads)
+        n_q, n_k = q.shape[1], kh.shape[1]
+        idx = (torch.arange(n_k, device=q.device)[None, :] - torch.arange(n_q, device=q.device)[:, None]).clamp(-R, R) + R
+        sim = torch.einsum("bid,bjd->bij", q, kh) * scale + torch.einsum("btd,tsd->bts", q, ek[idx]) * scale
+        if causal:
+            sim = sim.masked_fill(~(torch.tril(torch.ones(n_q, n_k, device=q.device)) > 0.5), -torch.finfo(sim.dtype).max)
+        sim = sim.softmax(dim=-1)
+        out = _unheads(torch.einsum("bij,bjd->bid", sim, vh) + torch.einsum("bts,tsd->btd", sim, ev[idx]), heads)
+    else:
+        out = _unheads(_sdpa(q, _heads(k, heads), _heads(v, heads), scale, causal), heads)
     if out_ip is not None:
         out = out + out_ip
     return _lin(sd, p + ".to_out.0", out)

@@ -224,6 +224,27 @@ def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale, cau
     return out
 
 
+def temporal_attn_rel(qkv, out, relg, relp, *, R, B, T, P, heads, ld, k_off, v_off, ldo, scale, causal=False):
+    x = qkv.as_strided((B, T, P, ld), (T * P * ld, P * ld, ld, 1), qkv.storage_offset()).float()
+    o = out.as_strided((B, T, P, ldo), (T * P * ldo, P * ldo, ldo, 1), out.storage_offset())
+    g = relg.view(B, T, P, heads, 64).float()
+    pr = relp.view(B, T, P, heads, 64)
+    dist = (torch.arange(T)[None, :] - torch.arange(T)[:, None]).clamp(-R, R) + R                    # [t, s]
+    for h in range(heads):
+        qh = x[..., h * 64:h * 64 + 64].permute(0, 2, 1, 3)                           # [B, P, T, 64]
+        kh = x[..., k_off + h * 64:k_off + h * 64 + 64].permute(0, 2, 1, 3)
+        vh = x[..., v_off + h * 64:v_off + h * 64 + 64].permute(0, 2, 1, 3)
+        gh = g[:, :, :, h].permute(0, 2, 1, 3)                                          # [B, P, T(query), 64(slot)]
+        logits = (qh @ kh.transpose(-1, -2) + torch.gather(gh, -1, dist.expand(B, P, T, T))) * scale
+        if causal:
+            logits = logits.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool)), float("-inf"))
+        p = torch.softmax(logits, dim=-1).to(_f16).float()
+        o[..., h * 64:h * 64 + 64] = (p @ vh).permute(0, 2, 1, 3).to(_f16)
+        slots = torch.zeros(B, P, T, 64).scatter_add_(-1, dist.expand(B, P, T, T), p)
+        pr[:, :, :, h] = slots.permute(0, 2, 1, 3).to(_f16)
+    return out
+
+
 def softmax_rows_(x, n=None):
     n = x.shape[1] if n is None else n
     n8 = (n + 7) // 8 * 8
@@ -277,7 +298,7 @@ def install(monkeypatch):
     _TUNE.clear()
     table = dict(require_gpu=lambda: None, gemm=gemm, group_norm_stats_from_colstats=group_norm_stats_from_colstats, group_norm=group_norm,
                  group_norm_stats=group_norm_stats, group_norm_fold_linear=group_norm_fold_linear, gemm_units=gemm_units,
-                 row_stats=row_stats, layer_norm=layer_norm, conv_tail_ok=conv_tail_ok, flash_attn=flash_attn, flash_attn_d512=flash_attn_d512, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn,
+                 row_stats=row_stats, layer_norm=layer_norm, conv_tail_ok=conv_tail_ok, flash_attn=flash_attn, flash_attn_d512=flash_attn_d512, flash_attn_dual=flash_attn_dual, temporal_attn=temporal_attn, temporal_attn_rel=temporal_attn_rel,
                  softmax_rows_=softmax_rows_, copy2d=copy2d, avgpool2x2=avgpool2x2, upsample2x=upsample2x, add_nchw_=add_nchw_, ncthw_to_nthwc=ncthw_to_nthwc, nthwc_to_ncthw=nthwc_to_ncthw,
                  timestep_embedding=timestep_embedding, silu_f32=lambda x: F.silu(x.float()), gelu_=lambda x: x.copy_(F.gelu(x.float()).to(_f16)),
                  to_f16=lambda x: x.to(_f16).contiguous(), to_f32=lambda x: x.float().contiguous(),

@@ -205,6 +205,24 @@ def gen_unet_causal(out):
     _gen_unet_variant(out, "ca", use_causal_attention=True)
 
 
+def gen_unet_relpos(out):
+    """use_relative_position=True (attention.py:20-40, 59-62, 104-108, 120-123) in every temporal attention; temporal_length = 2 with 5 frames, so that
+    distances beyond +-R are clipped (the ViewCrafter_25 YAML, too, has temporal_length 16 for 25 frames); not used by the shipped YAMLs."""
+    from lvdm.modules.networks.openaimodel3d import UNetModel
+    torch.manual_seed(0)
+    unet = UNetModel(**dict(TINY_UNET, use_relative_position=True, temporal_length=2)).eval()
+    shapes = load_synth(unet)
+    out["unet_keys"] = np.array(sorted(shapes.keys()))
+    out["unet_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes.keys())])
+    with torch.no_grad():
+        b, t, h, w, L = 1, 5, 16, 16, 77 + 40
+        x = synth_input("unet_rp_x", (b, 8, t, h, w))
+        ctx = synth_input("unet_rp_ctx", (b, L, TINY_UNET["context_dim"]))
+        y = unet(x, torch.tensor([599]), context=ctx, fs=torch.tensor([10]))
+        out["unet_out"] = y.numpy()
+        print("unet relpos", tuple(y.shape), float(y.abs().mean()))
+
+
 def adapter_features(b, t, h, w, mc=TINY_UNET["model_channels"], mult=TINY_UNET["channel_mult"]):
     """What a T2I-adapter hands to UNetModel.forward(features_adapter=...): one [(b t), C, h, w] map per level, added behind input
     blocks 2, 5, 8, 11 (openaimodel3d.py:582-588)."""
@@ -550,7 +568,7 @@ def main():
         print("transformers not importable:", e)
     import_reference()
     torch.set_num_threads(8)
-    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("unet_tiny_conv1x1", gen_unet_conv1x1), ("unet_tiny_updown", gen_unet_updown), ("unet_tiny_noconv", gen_unet_noconv), ("unet_tiny_causal", gen_unet_causal), ("unet_tiny_adapter", gen_unet_adapter), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
+    for name, fn in (("schedules", gen_schedules), ("unet_tiny", gen_unet), ("unet_tiny_ssn", gen_unet_ssn), ("unet_tiny_conv1x1", gen_unet_conv1x1), ("unet_tiny_updown", gen_unet_updown), ("unet_tiny_noconv", gen_unet_noconv), ("unet_tiny_causal", gen_unet_causal), ("unet_tiny_relpos", gen_unet_relpos), ("unet_tiny_adapter", gen_unet_adapter), ("vae_tiny", gen_vae), ("ddim_tiny", gen_ddim),
                      ("resampler_tiny", gen_resampler), ("clip_tiny", gen_clip), ("igs_tiny", gen_igs),
                      ("state_dict_full", gen_state_dict_full), ("cli_flags", gen_cli), ("api_signatures", gen_api), ("reference_yaml", gen_yaml)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:

@@ -292,6 +292,27 @@ def test_host_graph_with_sampling_variants_vs_reference_golden(monkeypatch, name
     assert y.shape == g["unet_out"].shape and e <= UNET_TOL
 
 
+def test_host_graph_with_relative_position_vs_reference_golden(monkeypatch):
+    """use_relative_position=True: the embedding tables as parameters of every temporal CrossAttention (the reference's names and shapes), q Ek^T and
+    (probabilities by clipped distance) Ev as GEMMs around the temporal attention launcher; temporal_length 2 with 5 frames (clipping)."""
+    import numpy as np
+    import os
+    cpu_kernels.install(monkeypatch)
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    m = UNetModel(**dict(TINY_UNET, use_relative_position=True, temporal_length=2)).eval()
+    load_synth(m)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_relpos.npz"))
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g["unet_keys"]]
+    assert [str(tuple(m.state_dict()[str(k)].shape)) for k in g["unet_keys"]] == [str(s) for s in g["unet_shapes"]]
+    x = synth_input("unet_rp_x", (1, 8, 5, 16, 16))
+    ctx = synth_input("unet_rp_ctx", (1, 77 + 40, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = m(x, torch.tensor([599]), context=ctx, fs=torch.tensor([10]))
+    e = rel_l2(y, g["unet_out"])
+    print(f"host graph with use_relative_position vs the reference golden: {e:.3e}")
+    assert e <= UNET_TOL
+
+
 def test_host_graph_with_features_adapter_vs_reference_golden(monkeypatch):
     """UNetModel.forward(features_adapter=[...]) (reference openaimodel3d.py:582-588), also under the shared CFG prefix (the maps are
     given once per video and shared by the r evaluations); a list of the wrong length is refused like the reference's assert."""

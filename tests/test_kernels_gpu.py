@@ -1433,6 +1433,38 @@ def test_temporal_attention_causal(B, T, P, heads):
     assert torch.equal(plain, plain2) and (T == 1 or not torch.equal(plain, out))
 
 
+@pytest.mark.parametrize("B,T,P,heads,R,causal", [(1, 16, 40, 2, 16, False), (2, 25, 37, 5, 16, False), (1, 25, 9, 1, 3, True), (1, 32, 8, 2, 31, False), (1, 5, 8, 1, 2, False)])
+def test_temporal_attention_relative_position(B, T, P, heads, R, causal):
+    """vcx_attn_temporal_d64_rel_f16 (ABI 9): logits += relg[query][clamp(s - t, -R, R) + R] before scale and softmax; relp[query][slot] receives the
+    probabilities by clipped distance (keys beyond +-R summed into the end slots, untouched slots stay as the caller zeroed them) - against fp32
+    torch; the reference's use (attention.py:104-108, 120-123) is relg = q Ek^T and out += relp Ev, checked at model level."""
+    from viewcrafter_amd import ops
+    C = heads * 64
+    tokens = B * T * P
+    qkv = rnd(tokens, 3 * C, seed=63).to(DEV).half()
+    relg = (rnd(tokens, heads, 64, seed=64) * 4).to(DEV).half()
+    relp = torch.zeros(tokens, heads, 64, device=DEV, dtype=torch.float16)
+    out = torch.empty(tokens, C, device=DEV, dtype=torch.float16)
+    ops.temporal_attn_rel(qkv, out, relg, relp, R=R, B=B, T=T, P=P, heads=heads, ld=3 * C, k_off=C, v_off=2 * C, ldo=C, scale=0.125, causal=causal)
+
+    def split(t):  # [(b t p), C] -> [(b p h), t, 64]
+        return t.view(B, T, P, heads, 64).permute(0, 2, 3, 1, 4).reshape(B * P * heads, T, 64).float()
+    q, k, v = split(qkv[:, :C]), split(qkv[:, C:2 * C]), split(qkv[:, 2 * C:])
+    g = relg.view(B, T, P, heads, 64).permute(0, 2, 3, 1, 4).reshape(B * P * heads, T, 64).float()
+    idx = ((torch.arange(T, device=DEV)[None, :] - torch.arange(T, device=DEV)[:, None]).clamp(-R, R) + R).expand(B * P * heads, T, T)
+    sim = (q @ k.transpose(1, 2) + torch.gather(g, 2, idx)) * 0.125
+    if causal:
+        sim = sim.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool, device=DEV)), float("-inf"))
+    prob = sim.softmax(-1)
+    ref = (prob @ v).view(B, P, heads, T, 64).permute(0, 3, 1, 2, 4).reshape(tokens, C)
+    check(out, ref, tol=3e-3, name="temporal attn with relative position")
+    slots = torch.zeros(B * P * heads, T, 64, device=DEV).scatter_add_(2, idx, prob)
+    slots = slots.view(B, P, heads, T, 64).permute(0, 3, 1, 2, 4).reshape(tokens, heads, 64)
+    assert (relp.float() - slots).abs().max().item() <= 2e-3
+    assert (relp[:, :, 2 * R + 1:] == 0).all()
+    assert torch.allclose(relp.float().sum(-1), torch.ones(tokens, heads, device=DEV), atol=4e-3)
+
+
 def test_softmax_rows():
     from viewcrafter_amd import ops
     x = (rnd(100, 520, seed=61) * 3).to(DEV).half()

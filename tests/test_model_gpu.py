@@ -134,6 +134,23 @@ def test_unet_sampling_variants_vs_reference_golden(name, tag, flags):
     assert e <= UNET_TOL
 
 
+def test_unet_with_relative_position_vs_reference_golden():
+    """use_relative_position=True (reference attention.py:20-40, 59-62, 104-108, 120-123; golden by the reference's own UNetModel, temporal_length 2
+    with 5 frames: clipped distances): vcx_attn_temporal_d64_rel_f16 (ABI 9) between the two table GEMMs."""
+    from viewcrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    m = UNetModel(**dict(TINY_UNET, use_relative_position=True, temporal_length=2)).eval()
+    load_synth(m)
+    m = m.to(DEV)
+    g = golden("unet_tiny_relpos")
+    x = synth_input("unet_rp_x", (1, 8, 5, 16, 16)).to(DEV)
+    ctx = synth_input("unet_rp_ctx", (1, 77 + 40, TINY_UNET["context_dim"])).to(DEV)
+    with torch.no_grad():
+        y = m(x, torch.tensor([599], device=DEV), context=ctx, fs=torch.tensor([10], device=DEV))
+    e = rel_l2(y, g["unet_out"])
+    print(f"unet with use_relative_position: rel-L2 vs reference = {e:.3e}")
+    assert e <= UNET_TOL
+
+
 def test_unet_with_features_adapter_vs_reference_golden(unet):
     """features_adapter (reference openaimodel3d.py:582-588): adapter maps in the reference's own [(b t), C, h, w] layout, added
     behind input blocks 2, 5, 8, 11 by vcx_add_nchw_f32_to_nhwc_f16; golden by the reference's own forward."""

@@ -323,6 +323,20 @@ def test_oracle_unet_sampling_variants_match_reference(name, tag, flags):
     assert np.abs(y.numpy() - g["unet_out"]).max() <= 2e-5 * np.abs(g["unet_out"]).max() + 1e-6
 
 
+def test_oracle_unet_with_relative_position_matches_reference():
+    """use_relative_position=True (reference attention.py:20-40, 59-62, 104-108, 120-123), temporal_length 2 with 5 frames (distances clipped):
+    golden written by the reference's own UNetModel (gen_golden.py::gen_unet_relpos)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_relpos.npz"))
+    shapes = {str(k): eval(str(s)) for k, s in zip(g["unet_keys"], g["unet_shapes"])}
+    assert shapes["input_blocks.1.2.transformer_blocks.0.attn1.relative_position_k.embeddings_table"] == (5, 64)
+    sd = synth_state_dict(shapes)
+    x = synth_input("unet_rp_x", (1, 8, 5, 16, 16))
+    ctx = synth_input("unet_rp_ctx", (1, 77 + 40, TINY_UNET["context_dim"]))
+    with torch.no_grad():
+        y = O.unet_forward(sd, dict(TINY_UNET, use_relative_position=True, temporal_length=2), x, torch.tensor([599]), ctx, torch.tensor([10]))
+    assert np.abs(y.numpy() - g["unet_out"]).max() <= 2e-5 * np.abs(g["unet_out"]).max() + 1e-6
+
+
 def _adapter_features(b, t, h, w):
     return [synth_input(f"adapter_{i}", (b * t, TINY_UNET["model_channels"] * m, h >> i, w >> i), scale=0.5)
             for i, m in enumerate(TINY_UNET["channel_mult"])]

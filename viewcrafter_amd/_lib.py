@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libvcx.so")
 SYMBOLS = [
     "vcx_abi_version", "vcx_last_error", "vcx_device_arch", "vcx_gemm_f16", "vcx_gemm_units_f16",
     "vcx_groupnorm_ws_bytes", "vcx_groupnorm_stats_f16", "vcx_groupnorm_apply_f16", "vcx_groupnorm_apply2_f16", "vcx_groupnorm_stats_from_colstats_f32", "vcx_groupnorm_fold_linear_f16", "vcx_layernorm_f16", "vcx_rowstats_f16",
-    "vcx_attn_flash_d64_f16", "vcx_attn_flash_d512_f16", "vcx_attn_flash_dual_d64_f16", "vcx_attn_temporal_d64_f16", "vcx_attn_temporal_d64_masked_f16", "vcx_softmax_rows_f16",
+    "vcx_attn_flash_d64_f16", "vcx_attn_flash_d512_f16", "vcx_attn_flash_dual_d64_f16", "vcx_attn_temporal_d64_f16", "vcx_attn_temporal_d64_masked_f16", "vcx_attn_temporal_d64_rel_f16", "vcx_softmax_rows_f16",
     "vcx_silu_f32", "vcx_gelu_f16", "vcx_clip_preprocess_f32", "vcx_add_nchw_f32_to_nhwc_f16", "vcx_timestep_embedding_f32", "vcx_cast_f32_to_f16", "vcx_cast_f16_to_f32",
     "vcx_copy2d_f16", "vcx_avgpool2x2_f16", "vcx_upsample2x_f16", "vcx_ncthw_f32_to_nthwc_f16", "vcx_nthwc_to_ncthw_f32", "vcx_ddim_ws_bytes", "vcx_ddim_step_f32", "vcx_ddim_step3_f32",
     "vcx_profile_begin", "vcx_profile_end", "vcx_tune_set", "vcx_tune_get",
@@ -98,6 +98,8 @@ def lib():
                                             c_int64, c_float, c_void_p]
     L.vcx_attn_temporal_d64_masked_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int64, c_int, c_int,
                                             c_int64, c_float, c_int, c_void_p]
+    L.vcx_attn_temporal_d64_rel_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int64, c_int, c_int,
+                                                c_int64, c_float, c_int, c_void_p]
     L.vcx_softmax_rows_f16.argtypes = [c_void_p, c_int64, c_int, c_int64, c_void_p]
     L.vcx_silu_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
     L.vcx_gelu_f16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]

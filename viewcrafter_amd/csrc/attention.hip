@@ -1034,6 +1034,11 @@ struct TAttnArgs {
     int k_off, v_off;
     float scale;
     int64_t npairs;
+    // relative position (tattn_d64_kernel<.., REL>; behind everything else, so that the other kernels' argument offsets stay):
+    // relg [(b t p)][heads][64] = q . Ek[rel] per query, relp [(b t p)][heads][64] <- the probabilities by clipped distance, R = max distance
+    const half_t* relg;
+    half_t* relp;
+    int R;
 };
 
 // One wave per (pixel, head): S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x16_f16 (T <= 32 keys = one MFMA
@@ -1043,7 +1048,12 @@ struct TAttnArgs {
 // (rows >= T zero-filled).  Traffic is the algorithmic minimum (q, k, v read once, o written once).
 // CAUSAL (VCX_ATTN_CAUSAL; TemporalTransformer(causal_attention=True), reference attention.py:343-345, 377-384, 111-115 - not used by the ViewCrafter
 // YAMLs): frame t attends to frames <= t.  An own instantiation: the unmasked kernel keeps its listing.
-template <bool CAUSAL>
+// REL (CrossAttention(relative_position=True), reference attention.py:20-40, 59-62, 104-108, 120-123 - `use_relative_position`, not used by the
+// ViewCrafter YAMLs): logits += q_t . Ek[clamp(s - t, -R, R) + R] and out += sum_s P[t, s] Ev[clamp(s - t) + R].  Both tables have 2R + 1 <= 64 rows, so
+// the two extra contractions are plain 64-wide GEMMs of the caller around this kernel: it ADDS the row relg[query][.] (= q Ek^T, one value per
+// clipped distance) to its scores before scale and softmax, and WRITES the probabilities of a query by clipped distance (all keys beyond +-R summed
+// into the end slots) to relp[query][.] - which the caller has zeroed and then multiplies with Ev.  Own instantiations.
+template <bool CAUSAL, bool REL = false>
 __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
     constexpr int VLD = 72;                                           // LDS row pitch (halfs): 144 B keeps 16-B alignment
     constexpr int WAVES = 8;
@@ -1107,6 +1117,15 @@ __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[s], s == 0 ? zero16 : sacc, 0, 0, 0);
     const float c = p.scale * 1.4426950408889634f;
+    [[maybe_unused]] const int64_t relrow = REL ? ((((int64_t)b * p.T + (lq < p.T ? lq : p.T - 1)) * p.P + pix) * p.heads + h) * 64 : 0;
+    if (REL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int dist = min(max(key - lq, -p.R), p.R) + p.R;
+            if (key < p.T) sacc[r] += (float)p.relg[relrow + dist];
+        }
+    }
     float mx = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1129,6 +1148,28 @@ __global__ void __launch_bounds__(512) tattn_d64_kernel(TAttnArgs p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[s][j] = (half_t)(sacc[8 * s + j] * inv);   // normalised P, fp16 like the reference's einsum input
+    if (REL) {
+        // the probabilities of this lane's query by clipped distance: unique inside (-R, R), summed beyond (this lane's 16 keys, then the
+        // other half of the row in lane ^ 32); masked / padded keys have probability 0
+        float lo = 0.f, up = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int d = key - lq;
+            const float pv = (float)pf[r >> 3][r & 7];
+            if (key < p.T) {
+                if (d <= -p.R) lo += pv;
+                else if (d >= p.R) up += pv;
+                else if (lq < p.T) p.relp[relrow + d + p.R] = (half_t)pv;
+            }
+        }
+        lo += __shfl_xor(lo, 32);
+        up += __shfl_xor(up, 32);
+        if (hi == 0 && lq < p.T) {
+            p.relp[relrow] = (half_t)lo;
+            p.relp[relrow + 2 * p.R] = (half_t)up;
+        }
+    }
 
     // O^T[d, q] = sum_key V^T[d, key] P^T[key, q]; V^T fragment slot j <-> key 16s + (j&3) + 8*(j>>2) + 4*hi
     __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): this wave's V rows are in LDS (wave-private patch: no barrier)
@@ -1530,8 +1571,23 @@ extern "C" int vcx_attn_temporal_d64_f16(const void* qkv, void* o, int B, int T,
     return vcx_attn_temporal_d64_masked_f16(qkv, o, B, T, P, heads, ld, k_off, v_off, ldo, scale, 0, stream);
 }
 
+static int tattn_launch(const void* qkv, void* o, const void* relg, void* relp, int R, int B, int T, int64_t P, int heads, int64_t ld,
+                        int k_off, int v_off, int64_t ldo, float scale, int flags, void* stream);
+
 extern "C" int vcx_attn_temporal_d64_masked_f16(const void* qkv, void* o, int B, int T, int64_t P, int heads, int64_t ld,
                                                 int k_off, int v_off, int64_t ldo, float scale, int flags, void* stream) {
+    return tattn_launch(qkv, o, nullptr, nullptr, 0, B, T, P, heads, ld, k_off, v_off, ldo, scale, flags, stream);
+}
+
+extern "C" int vcx_attn_temporal_d64_rel_f16(const void* qkv, void* o, const void* relg, void* relp, int R, int B, int T, int64_t P, int heads,
+                                             int64_t ld, int k_off, int v_off, int64_t ldo, float scale, int flags, void* stream) {
+    VCX_REQUIRE(relg && relp && R >= 1 && 2 * R + 1 <= 64 && T <= 32 && (((uintptr_t)relg | (uintptr_t)relp) & 1) == 0,
+                "vcx_attn_temporal_d64_rel_f16: need relg / relp, 1 <= R <= 31 (2R + 1 distances in 64 slots), T <= 32 (R=%d T=%d)", R, T);
+    return tattn_launch(qkv, o, relg, relp, R, B, T, P, heads, ld, k_off, v_off, ldo, scale, flags, stream);
+}
+
+static int tattn_launch(const void* qkv, void* o, const void* relg, void* relp, int R, int B, int T, int64_t P, int heads, int64_t ld,
+                        int k_off, int v_off, int64_t ldo, float scale, int flags, void* stream) {
     VCX_REQUIRE(qkv && o, "vcx_attn_temporal_d64_f16: null pointer");
     VCX_REQUIRE((flags & ~VCX_ATTN_CAUSAL) == 0, "vcx_attn_temporal_d64_masked_f16: unknown flags 0x%x (VCX_ATTN_CAUSAL is the only one)", flags);
     VCX_REQUIRE(B > 0 && T > 0 && T <= 64 && P > 0 && heads > 0, "vcx_attn_temporal_d64_f16: need 0 < T <= 64 (T=%d)", T);
@@ -1543,6 +1599,7 @@ extern "C" int vcx_attn_temporal_d64_masked_f16(const void* qkv, void* o, int B,
     a.B = B; a.T = T; a.heads = heads; a.P = P; a.ld = ld; a.ldo = ldo;
     a.k_off = k_off; a.v_off = v_off; a.scale = scale;
     a.npairs = (int64_t)B * P * heads;
+    a.relg = (const half_t*)relg; a.relp = (half_t*)relp; a.R = R;
     hipStream_t s = (hipStream_t)stream;
     VcxProfScope prof(VCX_FAM_TATTN, s, 4.0 * a.npairs * (double)T * T * 64, 2.0 * a.npairs * T * 64 * 4.0);
     const int64_t nblk = (a.npairs + 7) / 8;
@@ -1550,6 +1607,9 @@ extern "C" int vcx_attn_temporal_d64_masked_f16(const void* qkv, void* o, int B,
     if (T > 32) {         // 2 x 2 score tiles, 18 KB of LDS per wave
         if (flags & VCX_ATTN_CAUSAL) hipLaunchKernelGGL(tattn64_d64_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, a);
         else hipLaunchKernelGGL(tattn64_d64_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    } else if (relg) {
+        if (flags & VCX_ATTN_CAUSAL) hipLaunchKernelGGL((tattn_d64_kernel<true, true>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((tattn_d64_kernel<false, true>), dim3((unsigned)nblk), dim3(512), 0, s, a);
     } else if (flags & VCX_ATTN_CAUSAL) hipLaunchKernelGGL(tattn_d64_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(tattn_d64_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, s, a);
     return vcx_check_launch("vcx_attn_temporal_d64_f16");

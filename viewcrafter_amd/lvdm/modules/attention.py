@@ -155,17 +155,28 @@ class PackedModule(nn.Module):
         raise NotImplementedError
 
 
+class RelativePosition(nn.Module):
+    """Reference attention.py:20-40: a table of 2 R + 1 embeddings indexed by clamp(s - t, -R, R) + R.  Parameter container: the two contractions
+    with it are 64-wide GEMMs around the temporal attention kernel (TemporalTransformer.forward)."""
+
+    def __init__(self, num_units, max_relative_position):
+        super().__init__()
+        self.num_units, self.max_relative_position = num_units, max_relative_position
+        self.embeddings_table = nn.Parameter(torch.empty(max_relative_position * 2 + 1, num_units))
+        nn.init.xavier_uniform_(self.embeddings_table)
+
+
 class CrossAttention(PackedModule):
     """Reference attention.py:42-209.  Parameter container + packing; the attention itself is launched by the owning
-    transformer (it needs the token geometry).  Relative position is not part of the ViewCrafter graph (use_relative_position=false) and is
-    rejected; the causal mask of the temporal transformer is a flag of the temporal attention kernel."""
+    transformer (it needs the token geometry).  relative_position (`use_relative_position`; false in the ViewCrafter YAMLs) and the causal
+    mask exist in the temporal transformer only: two table GEMMs around / a flag of the temporal attention kernel."""
 
     def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0., relative_position=False,
                  temporal_length=None, video_length=None, image_cross_attention=False, image_cross_attention_scale=1.0,
                  image_cross_attention_scale_learnable=False, text_context_len=77):
         super().__init__()
-        if relative_position:
-            raise NotImplementedError("relative_position attention is not on the ViewCrafter inference path")
+        if relative_position and (temporal_length is None or 2 * temporal_length + 1 > 64 or context_dim is not None):
+            raise NotImplementedError("relative_position: temporal self-attention with temporal_length <= 31 (2R + 1 table rows in 64 slots)")
         if image_cross_attention_scale_learnable:
             raise NotImplementedError("image_cross_attention_scale_learnable is not used by the ViewCrafter configs")
         if dim_head != 64:
@@ -182,6 +193,10 @@ class CrossAttention(PackedModule):
         self.to_k = nn.Linear(context_dim, inner_dim, bias=False)
         self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
+        self.relative_position = bool(relative_position)
+        if self.relative_position:      # (reference attention.py:59-62)
+            self.relative_position_k = RelativePosition(num_units=dim_head, max_relative_position=temporal_length)
+            self.relative_position_v = RelativePosition(num_units=dim_head, max_relative_position=temporal_length)
         self.video_length = video_length
         self.image_cross_attention = image_cross_attention
         self.image_cross_attention_scale = image_cross_attention_scale
@@ -210,6 +225,14 @@ class CrossAttention(PackedModule):
             pk["v"] = _ln_projection(wv, ln)
         if self.image_cross_attention:
             pk["wk_ip"], pk["wv_ip"] = _f16(self.to_k_ip.weight), _f16(self.to_v_ip.weight)
+        if self.relative_position:
+            # Ek as the weight of  relg = q Ek^T  ([64 slots, 64 dims], rows 2R + 1 .. 63 zero) and Ev^T as the weight of  out += relp Ev  ([64 dims, 64 slots])
+            ek, ev = self.relative_position_k.embeddings_table.detach(), self.relative_position_v.embeddings_table.detach()
+            wk_rel = torch.zeros((64, 64), dtype=torch.float32, device=ek.device)
+            wv_rel = torch.zeros((64, 64), dtype=torch.float32, device=ek.device)
+            wk_rel[:ek.shape[0]] = ek.float()
+            wv_rel[:, :ev.shape[0]] = ev.float().t()
+            pk["rel_k"], pk["rel_v"], pk["rel_R"] = _f16(wk_rel), _f16(wv_rel), self.relative_position_k.max_relative_position
         return pk
 
     def forward(self, *args, **kwargs):
@@ -460,8 +483,10 @@ class TemporalTransformer(PackedModule):
                  use_linear=False, only_self_att=True, causal_attention=False, causal_block_size=1,
                  relative_position=False, temporal_length=None):
         super().__init__()
-        if not only_self_att or relative_position:
-            raise NotImplementedError("ViewCrafter uses temporal self-attention only, no relative position")
+        if not only_self_att:
+            raise NotImplementedError("ViewCrafter uses temporal self-attention only")
+        if relative_position and temporal_length is None:
+            raise AssertionError("relative_position needs temporal_length (reference attention.py:339)")
         # causal_attention (reference attention.py:343-345, 377-384: a lower-triangular mask over the frames, handed to attn1 AND attn2 of every block,
         # :241-243; `use_causal_attention`, not used by the ViewCrafter YAMLs): VCX_ATTN_CAUSAL of the temporal attention kernel
         if causal_attention and temporal_length is None:
@@ -483,7 +508,7 @@ class TemporalTransformer(PackedModule):
         nn.init.zeros_(self.proj_out.bias)
 
         def attention_cls(**kw):
-            return CrossAttention(temporal_length=temporal_length, **kw)
+            return CrossAttention(temporal_length=temporal_length, relative_position=bool(relative_position), **kw)
         self.transformer_blocks = nn.ModuleList([
             BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=None,
                                   attention_cls=attention_cls, checkpoint=use_checkpoint) for _ in range(depth)])
@@ -532,8 +557,19 @@ class TemporalTransformer(PackedModule):
                 ap = attn.packed()
                 qkv = ln_linear(t, ap["qkv"], lnp, stats=st)                         # [tokens, 3D]
                 o = torch.empty((tokens, D), dtype=torch.float16, device=x.device)
-                ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D, ldo=D,
-                                  scale=attn.scale, causal=self.causal_attention)
+                if attn.relative_position:
+                    # logits += q Ek^T (per head: a [tokens, 64] x [64, 64] GEMM on the q columns of qkv), out += (probabilities by clipped distance) Ev
+                    relg = torch.empty((tokens, heads, 64), dtype=torch.float16, device=x.device)
+                    relp = torch.zeros((tokens, heads, 64), dtype=torch.float16, device=x.device)
+                    for h_ in range(heads):
+                        ops.gemm(qkv[:, h_ * 64:], ap["rel_k"], M=tokens, N=64, K=64, lda=3 * D, out=relg[:, h_], ldc=heads * 64)
+                    ops.temporal_attn_rel(qkv, o, relg, relp, R=ap["rel_R"], B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D, ldo=D,
+                                          scale=attn.scale, causal=self.causal_attention)
+                    for h_ in range(heads):
+                        ops.gemm(relp[:, h_], ap["rel_v"], M=tokens, N=64, K=64, lda=heads * 64, out=o[:, h_ * 64:], ldc=D, residual=o[:, h_ * 64:], ldr=D)
+                else:
+                    ops.temporal_attn(qkv, o, B=B, T=T, P=P, heads=heads, ld=3 * D, k_off=D, v_off=2 * D, ldo=D,
+                                      scale=attn.scale, causal=self.causal_attention)
                 st = None
                 if ai == 0 and _folded(blk.attn2.packed()["qkv"], tokens, D, D) and ops.rowstats_ok(tokens, D, D, ldr=D):
                     st = ops.rowstats_buffer(tokens, x.device)

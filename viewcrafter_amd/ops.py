@@ -409,6 +409,15 @@ def temporal_attn(qkv, out, *, B, T, P, heads, ld, k_off, v_off, ldo, scale, cau
     return out
 
 
+def temporal_attn_rel(qkv, out, relg, relp, *, R, B, T, P, heads, ld, k_off, v_off, ldo, scale, causal=False):
+    """Temporal attention with relative position (reference attention.py:104-108, 120-123): relg [tokens, heads, 64] = q Ek^T is added to the
+    logits, relp [tokens, heads, 64] (zeroed by the caller) receives the probabilities by clipped distance; see include/vcx.h."""
+    _dev16(qkv, out, relg, relp)
+    check(lib().vcx_attn_temporal_d64_rel_f16(qkv.data_ptr(), out.data_ptr(), relg.data_ptr(), relp.data_ptr(), int(R), B, T, P, heads, ld, k_off, v_off,
+                                              ldo, scale, ATTN_CAUSAL if causal else 0, _stream()), "attn_temporal_d64(rel)")
+    return out
+
+
 def softmax_rows_(x, n=None):
     rows = x.shape[0]
     check(lib().vcx_softmax_rows_f16(x.data_ptr(), rows, n if n is not None else x.shape[1], x.stride(0), _stream()),
