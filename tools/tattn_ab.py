@@ -28,7 +28,10 @@ def build(rev):
 def run():
     import torch
     from viewcrafter_amd import _lib
-    libs = {"shipped": ctypes.CDLL(_lib.LIB_PATH), "previous": ctypes.CDLL(os.path.join(ABL, "libvcx_tattn_old.so"))}
+    # python tools/tattn_ab.py run name=path [name=path ...]: the shipped library against the named builds (default: "previous" = libvcx_tattn_old.so)
+    extra = dict(a.split("=", 1) for a in sys.argv[2:]) if len(sys.argv) > 2 else {"previous": os.path.join(ABL, "libvcx_tattn_old.so")}
+    libs = {"shipped": ctypes.CDLL(_lib.LIB_PATH)}
+    libs.update({k: ctypes.CDLL(os.path.join(ROOT, v) if not os.path.isabs(v) else v) for k, v in extra.items()})
     for L in libs.values():
         L.vcx_attn_temporal_d64_f16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]
@@ -59,7 +62,7 @@ def run():
             m = sorted(res[k])[2]
             tot[k] += m * cnt
             row += f"{k} {m * 1e3:7.1f} us ({gb / m:5.2f} TB/s)   "
-        print(row + ("bit-identical" if torch.equal(outs["shipped"], outs["previous"]) else "OUTPUTS DIFFER"), flush=True)
+        print(row + ("bit-identical" if all(torch.equal(outs["shipped"], o) for o in outs.values()) else "OUTPUTS DIFFER"), flush=True)
     print("per DDIM step (576x1024x25 launch counts): " + "   ".join(f"{k} {v:.2f} ms" for k, v in tot.items()))
 
 
